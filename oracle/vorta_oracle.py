@@ -1,0 +1,356 @@
+"""CPU ORACLE for the routed sparse-attention denoising path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain numpy restatement of the reference algorithm (wenhao728/VORTA) for the hot path named in
+BASELINE.json.  Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module; the product path (`vorta_amd/`) never does and fails loudly without its HIP library.
+
+Parity status: PINNED.  Every function below is checked against golden vectors produced by running the
+reference itself in the authoring container (tools/gen_goldens.py -> tests/golden/*.npz; see
+tests/test_oracle_golden.py).
+
+All citations are relative to /root/reference/.  Arithmetic is float64 unless `dtype` says otherwise,
+so that the oracle is a stricter target than the reference's own bf16/fp32 execution.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+Triple = Tuple[int, int, int]
+
+
+# ----------------------------------------------------------------------------------------------- A4
+@dataclass
+class GroupInfo:
+    """vorta/attention/coreset_select.py:8-12 (LowresGroupInfo)."""
+    center: np.ndarray  # (G, 1) int64
+    margin: np.ndarray  # (G, g-1) int64
+    n_keep_margin: int  # "num_unpooled_tokens_per_group"
+
+    @property
+    def n_groups(self) -> int:
+        return self.center.shape[0]
+
+    @property
+    def group_size(self) -> int:
+        return 1 + self.margin.shape[1]
+
+
+def group_info(latent: Triple, window: Triple, rate: float = 0.5) -> GroupInfo:
+    """vorta/attention/coreset_select.py:15-60.
+
+    Raster index cube cropped to whole windows, regrouped so each row lists one window's tokens in
+    in-window raster order; the centre is the token at (fw//2, hw//2, ww//2)."""
+    f, h, w = latent
+    fw, hw, ww = window
+    fg, hg, wg = f // fw, h // hw, w // ww
+    cube = np.arange(f * h * w, dtype=np.int64).reshape(f, h, w)[: fg * fw, : hg * hw, : wg * ww]
+    groups = cube.reshape(fg, fw, hg, hw, wg, ww).transpose(0, 2, 4, 1, 3, 5).reshape(fg * hg * wg, fw * hw * ww)
+    c = (fw // 2) * hw * ww + (hw // 2) * ww + ww // 2
+    center = groups[:, c:c + 1]
+    margin = np.concatenate([groups[:, :c], groups[:, c + 1:]], axis=1)
+    n_keep = int(fw * hw * ww * (1 - rate)) - 1
+    return GroupInfo(center=center, margin=margin, n_keep_margin=n_keep)
+
+
+# ----------------------------------------------------------------------------------------------- A5 / A7
+def _l2_normalize(x: np.ndarray, eps: float = 1e-12) -> np.ndarray:
+    # torch.nn.functional.normalize: x / max(||x||_2, eps)   (coreset_select.py:100-101)
+    n = np.sqrt((x * x).sum(-1, keepdims=True))
+    return x / np.maximum(n, eps)
+
+
+def coreset_similarity(x: np.ndarray, gi: GroupInfo) -> np.ndarray:
+    """cos-sim(centre, each margin) -> (B,h,G,g-1).  coreset_select.py:91-103."""
+    c = x[:, :, gi.center[:, 0], :]  # (B,h,G,D)
+    m = x[:, :, gi.margin, :]  # (B,h,G,g-1,D)
+    return np.einsum("bhgd,bhgmd->bhgm", _l2_normalize(c), _l2_normalize(m))
+
+
+def coreset_match(x: np.ndarray, gi: GroupInfo) -> Tuple[np.ndarray, np.ndarray]:
+    """Ascending argsort of the similarities, split into (kept, dropped) margin slots.
+
+    coreset_select.py:105-114.  Ties are broken by slot index (stable sort); the reference's argsort is
+    unstable, so index parity is only asserted on tie-free data."""
+    order = np.argsort(coreset_similarity(x, gi), axis=-1, kind="stable")
+    return order[..., : gi.n_keep_margin], order[..., gi.n_keep_margin:]
+
+
+def coreset_pool(x: np.ndarray, gi: GroupInfo, kept: np.ndarray) -> np.ndarray:
+    """Packed sequence [G centres | G x n_keep kept margins (group-major, least similar first)].
+    coreset_select.py:116-124."""
+    B, h, _, D = x.shape
+    c = x[:, :, gi.center[:, 0], :]
+    m = x[:, :, gi.margin, :]
+    km = np.take_along_axis(m, kept[..., None], axis=3)  # (B,h,G,n_keep,D)
+    return np.concatenate([c, km.reshape(B, h, -1, D)], axis=2)
+
+
+def coreset_row_lists(gi: GroupInfo, kept: np.ndarray, dropped: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Raster token ids of the packed sequence, and per-group raster ids of the dropped margins.
+
+    keep_rows (B,h,G*(1+n_keep)); drop_rows (B,h,G,g-1-n_keep).  This is the index form of
+    coreset_select.py:116-124 (gather) and :159-166 (scatter destinations)."""
+    B, h = kept.shape[:2]
+    margin = np.broadcast_to(gi.margin[None, None], (B, h) + gi.margin.shape)
+    kept_rows = np.take_along_axis(margin, kept, axis=3).reshape(B, h, -1)
+    drop_rows = np.take_along_axis(margin, dropped, axis=3)
+    centres = np.broadcast_to(gi.center[:, 0][None, None], (B, h, gi.n_groups))
+    return np.concatenate([centres, kept_rows], axis=2), drop_rows
+
+
+def coreset_unpool(y: np.ndarray, gi: GroupInfo, kept: np.ndarray, dropped: np.ndarray) -> np.ndarray:
+    """Scatter packed rows back; every dropped margin receives its centre's row; tokens outside any
+    whole window stay zero.  coreset_select.py:127-185."""
+    B, h, _, D = y.shape
+    G, g = gi.n_groups, gi.group_size
+    out = np.zeros((B, h, G * g, D), dtype=y.dtype)
+    keep_rows, drop_rows = coreset_row_lists(gi, kept, dropped)
+    centres = y[:, :, :G, :]
+    for b in range(B):
+        for hh in range(h):
+            out[b, hh, keep_rows[b, hh], :] = y[b, hh]
+            out[b, hh, drop_rows[b, hh].reshape(-1), :] = np.repeat(centres[b, hh], drop_rows.shape[-1], axis=0)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- A9
+def tile_major_order(latent: Triple, tile: Triple, sp: int = 1) -> np.ndarray:
+    """perm[i] = raster index of the token at tile-major position i.  vorta/attention/tile.py:7-41.
+
+    For sp>1 the reference first regroups '(sp t h w) -> (t sp h w)' (tile.py:21-25), which interleaves
+    frames; restated here so the quirk is documented by a fixture (g4)."""
+    t, h, w = latent
+    tt, th, tw = tile
+    src = np.arange(t * h * w, dtype=np.int64)
+    if sp > 1:
+        src = src.reshape(sp, t // sp, h, w).transpose(1, 0, 2, 3).reshape(-1)
+    nt, nh, nw = t // tt, h // th, w // tw
+    return src.reshape(nt, tt, nh, th, nw, tw).transpose(0, 2, 4, 1, 3, 5).reshape(-1)
+
+
+# ----------------------------------------------------------------------------------------------- A8
+def sta_window_tiles(latent: Triple, tile: Triple, window: Triple) -> np.ndarray:
+    """Boolean (n_tiles, n_tiles): may q-tile i see kv-tile j?  sliding_attn_flex.py:93-127.
+
+    Per dim the window centre is clamp(q_tile, w//2, n-1-w//2) with torch.clamp semantics
+    (min applied first, then max: when min>max the result is max)."""
+    n = [latent[i] // tile[i] for i in range(3)]
+    coords = np.stack(np.meshgrid(*[np.arange(x) for x in n], indexing="ij"), -1).reshape(-1, 3)
+    ok = np.ones((coords.shape[0], coords.shape[0]), dtype=bool)
+    for d in range(3):
+        half = window[d] // 2
+        centre = np.minimum(np.maximum(coords[:, d], half), (n[d] - 1) - half)
+        ok &= np.abs(centre[:, None] - coords[None, :, d]) <= half
+    return ok
+
+
+def sta_mask(latent: Triple, tile: Triple, window: Triple, t_text: int, t_eff: int) -> np.ndarray:
+    """Dense boolean (S+T, S+T) mask in TILE-MAJOR token order.  sliding_attn_flex.py:101-128."""
+    S = latent[0] * latent[1] * latent[2]
+    tok = tile[0] * tile[1] * tile[2]
+    n = S + t_text
+    m = np.zeros((n, n), dtype=bool)
+    tiles = sta_window_tiles(latent, tile, window)
+    tid = np.arange(S) // tok
+    m[:S, :S] = tiles[tid][:, tid]
+    m[:S, S:S + t_eff] = True  # video -> valid text
+    m[S:S + t_eff, :S + t_eff] = True  # valid text -> everything valid
+    return m
+
+
+# ----------------------------------------------------------------------------------------------- A3
+def _softmax_attend(q: np.ndarray, k: np.ndarray, v: np.ndarray, mask: Optional[np.ndarray] = None,
+                    scale: Optional[float] = None) -> np.ndarray:
+    """softmax(q k^T * scale [masked]) v over the last two dims; fully-masked rows -> 0."""
+    q, k, v = (np.asarray(a, dtype=np.float64) for a in (q, k, v))
+    scale = 1.0 / np.sqrt(q.shape[-1]) if scale is None else scale
+    s = np.einsum("...qd,...kd->...qk", q, k) * scale
+    if mask is not None:
+        s = np.where(mask, s, -np.inf)
+    mx = s.max(-1, keepdims=True)
+    mx = np.where(np.isfinite(mx), mx, 0.0)
+    p = np.exp(s - mx)
+    den = p.sum(-1, keepdims=True)
+    p = np.divide(p, den, out=np.zeros_like(p), where=den > 0)
+    return np.einsum("...qk,...kd->...qd", p, v)
+
+
+def dense_attention(q, k, v, kv_valid: Optional[int] = None, q_valid: Optional[int] = None) -> np.ndarray:
+    """Full attention on the first `kv_valid` keys; query rows >= q_valid are zero.
+
+    Hunyuan: hunyuan.py:167-176 (L = mask.sum(); SDPA on [:L]; zero-pad the rest).
+    Wan:     wan.py:142-145 (no mask), incl. cross attention with Sq != Skv."""
+    Sq, Skv = q.shape[-2], k.shape[-2]
+    kv_valid = Skv if kv_valid is None else kv_valid
+    q_valid = Sq if q_valid is None else q_valid
+    out = np.zeros(q.shape[:-1] + (v.shape[-1],), dtype=np.float64)
+    out[..., :q_valid, :] = _softmax_attend(q[..., :q_valid, :], k[..., :kv_valid, :], v[..., :kv_valid, :])
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- A10
+def sliding_tile_attention(q, k, v, latent: Triple, tile: Triple, window: Triple,
+                           eq=None, ek=None, ev=None, t_eff: int = 0):
+    """Sliding-tile expert on RASTER-ordered q,k,v (B,h,S,D) [+ text (B,h,T,D)].
+
+    Restates tile -> concat text -> masked attention -> split -> untile
+    (sliding_attn_flex.py:137-211 with the mask of :101-128).  Returns video out (raster order) and, if
+    text is given, the text out."""
+    S = q.shape[-2]
+    perm = tile_major_order(latent, tile)
+    has_text = eq is not None
+    T = eq.shape[-2] if has_text else 0
+    qq, kk, vv = q[..., perm, :], k[..., perm, :], v[..., perm, :]
+    if has_text:
+        qq = np.concatenate([qq, eq], -2)
+        kk = np.concatenate([kk, ek], -2)
+        vv = np.concatenate([vv, ev], -2)
+    m = sta_mask(latent, tile, window, T, t_eff)
+    o = _softmax_attend(qq, kk, vv, mask=m)
+    out = np.empty_like(o[..., :S, :])
+    out[..., perm, :] = o[..., :S, :]
+    return (out, o[..., S:, :]) if has_text else out
+
+
+# ----------------------------------------------------------------------------------------------- A6
+def lowres_attention(q, k, v, gi: GroupInfo, model: str, eq=None, ek=None, ev=None, t_eff: int = 0,
+                     matches=None):
+    """Coreset ("low-res") expert.
+
+    hunyuan (hunyuan.py:410-457): Q and K matched independently, V reuses K's; text appended after the
+      packed video tokens; keys limited to S_low + t_eff; padded text query rows are zero.
+    wan (wan.py:243-270): K and V reuse Q's matching; no text.
+    `matches` optionally supplies ((q_kept,q_drop),(k_kept,k_drop)) to make index choices external."""
+    if matches is None:
+        mq = coreset_match(q, gi)
+        mk = coreset_match(k, gi) if model == "hunyuan" else mq
+    else:
+        mq, mk = matches
+    ql = coreset_pool(q, gi, mq[0])
+    kl = coreset_pool(k, gi, mk[0])
+    vl = coreset_pool(v, gi, mk[0])
+    s_low = ql.shape[-2]
+    if eq is not None:
+        T = eq.shape[-2]
+        ql, kl, vl = (np.concatenate([a, b], -2) for a, b in ((ql, eq), (kl, ek), (vl, ev)))
+        o = dense_attention(ql, kl, vl, kv_valid=s_low + t_eff, q_valid=s_low + t_eff)
+        return coreset_unpool(o[..., :s_low, :], gi, *mq), o[..., s_low:s_low + T, :]
+    o = dense_attention(ql, kl, vl)
+    return coreset_unpool(o, gi, *mq)
+
+
+# ----------------------------------------------------------------------------------------------- A1 / A2
+def router_scores(temb: np.ndarray, weight: np.ndarray, bias: np.ndarray, heads: int) -> np.ndarray:
+    """softmax((W silu(temb) + b).view(B,H,3)).  vorta/patch/router.py:33-43."""
+    x = np.asarray(temb, dtype=np.float64)
+    x = x / (1.0 + np.exp(-x))
+    y = (x @ np.asarray(weight, dtype=np.float64).T + np.asarray(bias, dtype=np.float64)).reshape(x.shape[0], heads, -1)
+    y = y - y.max(-1, keepdims=True)
+    e = np.exp(y)
+    return e / e.sum(-1, keepdims=True)
+
+
+def route_heads(scores: np.ndarray, tau: float) -> np.ndarray:
+    """expert id per head from batch item 0: top-1, falling back to expert 0 when its score < tau.
+    hunyuan.py:620-624 == wan.py:396-400.  (torch.topk returns the FIRST maximal index on ties.)"""
+    s = np.asarray(scores)[0]
+    idx = s.argmax(-1)
+    top = s.max(-1)
+    return np.where(top < tau, 0, idx).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------------- A11 / A12
+def routed_attention(q, k, v, expert_of_head: np.ndarray, *, model: str, latent: Triple, tile: Triple,
+                     window: Triple, gi: GroupInfo, t_text: int = 0, t_eff: int = 0):
+    """The whole routed op on post-RoPE q,k,v (B,H,S+T,D): dispatch by head, three experts, combine.
+
+    hunyuan.py:556-605 / wan.py:351-383.  Returns (B,H,S+T,D) with text rows at the end (hunyuan) or
+    (B,H,S,D) (wan)."""
+    B, H, N, D = q.shape
+    S = latent[0] * latent[1] * latent[2]
+    out = np.zeros((B, H, N, D), dtype=np.float64)
+    hy = model == "hunyuan"
+    for e in range(3):
+        hs = np.nonzero(expert_of_head == e)[0]
+        if hs.size == 0:
+            continue
+        qe, ke, ve = q[:, hs], k[:, hs], v[:, hs]
+        if e == 0:
+            out[:, hs] = dense_attention(qe, ke, ve, kv_valid=S + t_eff, q_valid=S + t_eff) if hy else \
+                dense_attention(qe, ke, ve)
+        elif e == 1:
+            if hy:
+                o, eo = lowres_attention(qe[..., :S, :], ke[..., :S, :], ve[..., :S, :], gi, "hunyuan",
+                                         qe[..., S:, :], ke[..., S:, :], ve[..., S:, :], t_eff)
+                out[:, hs, :S], out[:, hs, S:] = o, eo
+            else:
+                out[:, hs] = lowres_attention(qe, ke, ve, gi, "wan")
+        else:
+            if hy:
+                o, eo = sliding_tile_attention(qe[..., :S, :], ke[..., :S, :], ve[..., :S, :], latent, tile, window,
+                                               qe[..., S:, :], ke[..., S:, :], ve[..., S:, :], t_eff)
+                out[:, hs, :S], out[:, hs, S:] = o, eo
+            else:
+                out[:, hs] = sliding_tile_attention(qe, ke, ve, latent, tile, window)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- A13
+def ulysses_seq_to_head(shards: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """all_to_all_4D(x, scatter_idx=1, gather_idx=2) for every rank at once.
+
+    shards[r] = (B,H,S/P,D) held by rank r.  Rank r ends with heads [r*H/P,(r+1)*H/P) and the
+    rank-major concatenation of the sequence shards.  vorta/ulysses/utils.py:61-91."""
+    P = len(shards)
+    hl = shards[0].shape[1] // P
+    return [np.concatenate([shards[src][:, r * hl:(r + 1) * hl] for src in range(P)], axis=2) for r in range(P)]
+
+
+def ulysses_head_to_seq(shards: Sequence[np.ndarray]) -> List[np.ndarray]:
+    """all_to_all_4D(x, scatter_idx=2, gather_idx=1): exact inverse.  vorta/ulysses/utils.py:33-59."""
+    P = len(shards)
+    sl = shards[0].shape[2] // P
+    return [np.concatenate([shards[src][:, :, r * sl:(r + 1) * sl] for src in range(P)], axis=1) for r in range(P)]
+
+
+def shrink_dim(x: np.ndarray, dim: int, rank: int, P: int) -> np.ndarray:
+    """x.narrow(dim, rank*n/P, n/P).  vorta/ulysses/utils.py:218-223."""
+    n = x.shape[dim] // P
+    return np.take(x, np.arange(rank * n, (rank + 1) * n), axis=dim)
+
+
+def all_gather_cat(parts: Sequence[np.ndarray], dim: int) -> np.ndarray:
+    """rank-ordered concat.  vorta/ulysses/utils.py:135-146."""
+    return np.concatenate(list(parts), axis=dim)
+
+
+# ----------------------------------------------------------------------------------------------- misc
+def pixel_to_token(n_pixel: int, ratio: int) -> int:
+    """vorta/patch/utils.py:84-92."""
+    n, mod = divmod(n_pixel, ratio)
+    if mod == 0:
+        return n
+    if mod == 1:
+        return n + 1
+    raise ValueError(f"Number of pixel {n_pixel} is not a multiple of pixel2token {ratio}.")
+
+
+def video_to_latent(video: Triple, temporal: int = 4, spatial: int = 16) -> Triple:
+    """hunyuan_pixel2token == wan_pixel2token: /4 temporal, /(8*2) spatial.  vorta/patch/utils.py:59-95."""
+    return (pixel_to_token(video[0], temporal), pixel_to_token(video[1], spatial), pixel_to_token(video[2], spatial))
+
+
+# ----------------------------------------------------------------------------------------------- algorithmic work
+def flops_full(S: int, t_eff: int, D: int = 128) -> float:
+    return 4.0 * (S + t_eff) ** 2 * D
+
+
+def flops_lowres(S_low: int, t_eff: int, D: int = 128) -> float:
+    return 4.0 * (S_low + t_eff) ** 2 * D
+
+
+def flops_sliding(S: int, tok: int, n_kv_tiles: int, t_eff: int, D: int = 128) -> float:
+    return 4.0 * D * (S * (n_kv_tiles * tok + t_eff) + t_eff * (S + t_eff))
