@@ -1,0 +1,197 @@
+/*
+ * vorta_hip.h -- C ABI of libvorta_hip.so: the MI355X (gfx950) implementation of VORTA's routed
+ * sparse-attention denoising hot path.
+ *
+ * The reference (wenhao728/VORTA) is pure Python and has no FFI of its own: the boundary it exposes is
+ * the diffusers attention-processor protocol (vorta/attention/__init__.py:1-16).  Each entry point below
+ * names the reference code it replaces (paths relative to the reference root).  The Python host side
+ * (vorta_amd/) binds these with ctypes and mirrors the reference's processor classes one to one; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (VORTA_OK) or a negative VORTA_E* code; nothing throws across the ABI;
+ *   - the caller owns every buffer (inputs, outputs, index tables, workspaces); the library allocates
+ *     nothing and keeps no state; all pointers are DEVICE pointers unless a field says "host";
+ *   - work is enqueued on the given hipStream_t (passed as void*); no call synchronises the device;
+ *   - a "head slot" y in [0,n_heads) addresses head  head_list ? head_list[y] : y  of the (H,S,D) tensors;
+ *     a batch is folded into the head axis by the caller (head = b*H + h with stride_h the same);
+ *   - rows of D contiguous elements; strides in ELEMENTS; 16-byte aligned rows.
+ */
+#ifndef VORTA_HIP_H
+#define VORTA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VORTA_OK 0
+#define VORTA_EINVAL (-1)       /* bad argument (null pointer, size, alignment, struct_size)          */
+#define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
+#define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
+
+#define VORTA_ABI_VERSION 1
+
+typedef enum vorta_dtype { VORTA_BF16 = 0, VORTA_FP16 = 1 } vorta_dtype;
+
+/* One (H,S,D) operand: element (h,s,d) lives at ptr + h*stride_h + s*stride_s + d. */
+typedef struct vorta_tensor {
+  void* ptr;
+  int64_t stride_h;
+  int64_t stride_s;
+} vorta_tensor;
+
+/*
+ * vorta_attn_fwd -- softmax(Q K^T * scale) V for a list of heads, with row indirection.
+ *
+ * One generic gather flash-attention kernel serves all three experts:
+ *   dense   (hunyuan.py:136-189 `_step_attention`, wan.py:103-149 `_attn`): no tables, n_kv = valid
+ *           keys (Hunyuan L = attention_mask.sum(), hunyuan.py:169), q_valid = L so padded text rows
+ *           come out exactly zero (hunyuan.py:176);
+ *   coreset (hunyuan.py:410-457, wan.py:243-270 + coreset_select.py:68-185): q_rows / kv_rows are the
+ *           keep-lists written by vorta_coreset_select, dup_rows its drop-lists: pool-gather and
+ *           unpool-scatter are fused into the loads and the epilogue, no pooled copy exists;
+ *   sliding tile (sliding_attn_flex.py:72-211 + tile.py:7-78): q_rows is the tile-major permutation,
+ *           kv_rows the per-q-tile key list from vorta_sta_build_tables (q_group_len = tokens/tile);
+ *           tile/untile are address arithmetic, no BlockMask and no permuted copy exists.
+ * Each head writes straight into its slice of the final (H,S,D) output, which replaces the per-expert
+ * head gathers and the boolean index-put of `_get_routed_qkv` / `_combine_attn_outputs`
+ * (hunyuan.py:612-661, wan.py:388-437).
+ *
+ * Query side: positions p in [0,n_q) are cut into groups of q_group_len (0 = one group); a workgroup
+ * never straddles a group.  Position p reads/writes row  q_rows ? q_rows[y*q_rows_stride_h + p]
+ * : q_row_offset + p.  Positions p >= q_valid are written as zeros.
+ * Key side: group g attends positions j in [0,n_kv) -> row  kv_rows ? kv_rows[y*kv_rows_stride_h +
+ * g*kv_rows_stride_g + j] : kv_row_offset + j.
+ * Duplicates: if dup_rows, every position p < n_dup_pos additionally writes its output row to rows
+ * dup_rows[y*dup_rows_stride_h + p*n_dup + i], i < n_dup (coreset: centre -> dropped margins).
+ * Split keys: n_splits > 1 cuts the key range into n_splits chunks computed by separate workgroups into
+ * ws_o / ws_ml (float, sizes from vorta_attn_workspace_bytes) and merged by a second kernel; used for the
+ * few text-query rows of the sliding expert that attend every key.
+ */
+typedef struct vorta_attn_args {
+  uint32_t struct_size; /* = sizeof(vorta_attn_args) */
+  int32_t dtype;        /* vorta_dtype */
+  int32_t head_dim;     /* 128 */
+  int32_t n_heads;      /* head slots in this launch (upper bound when n_heads_dev is set) */
+  vorta_tensor q, k, v, o;
+  const int32_t* head_list;   /* [n_heads] or NULL */
+  const int32_t* n_heads_dev; /* optional device count: slots >= *n_heads_dev exit at once (sync-free routing) */
+  int32_t n_q, q_group_len, q_row_offset, q_valid;
+  const int32_t* q_rows;
+  int64_t q_rows_stride_h;
+  int32_t n_kv, kv_row_offset;
+  const int32_t* kv_rows;
+  int64_t kv_rows_stride_h, kv_rows_stride_g;
+  const int32_t* dup_rows;
+  int64_t dup_rows_stride_h;
+  int32_t n_dup_pos, n_dup;
+  float scale;        /* softmax scale, 1/sqrt(D) in the reference */
+  int32_t block_rows; /* query rows per workgroup: 0 = auto, 128 or 256 */
+  int32_t n_splits;   /* >= 1 */
+  float* ws_o;        /* [n_heads][n_splits][n_q][D]   when n_splits > 1 */
+  float* ws_ml;       /* [n_heads][n_splits][n_q][2]   when n_splits > 1 */
+} vorta_attn_args;
+
+int vorta_attn_fwd(const vorta_attn_args* args, void* hip_stream);
+/* bytes of ws_o and ws_ml for a given launch (0,0 when n_splits <= 1) */
+int vorta_attn_workspace_bytes(const vorta_attn_args* args, uint64_t* ws_o_bytes, uint64_t* ws_ml_bytes);
+
+/*
+ * vorta_coreset_select -- coreset_select.py:68-124 (ranking part) + :159-166 (scatter destinations).
+ *
+ * For every head slot and every window group of g = gw[0]*gw[1]*gw[2] tokens of the (t,h,w) latent:
+ * cosine similarity (F.normalize eps 1e-12, fp32 arithmetic) between the centre token and each of the
+ * g-1 margin tokens, ascending stable rank; the n_keep least similar margins are kept.
+ * Writes   keep_rows[y][G*(1+n_keep) (+ n_tail)] : token ids of the packed sequence
+ *                    [G centres | G x n_keep kept margins (group-major, least similar first) | tail]
+ *          drop_rows[y][G][g-1-n_keep]           : token ids of the dropped margins of each group
+ * (tail = n_tail consecutive ids starting at tail_first: the text tokens appended by hunyuan.py:441-444).
+ * If row_map is given, every emitted id i is replaced by row_map[i] (physical row of token i: the
+ * zero-copy Ulysses layout), while x is still read at row_map[i].
+ */
+typedef struct vorta_coreset_args {
+  uint32_t struct_size;
+  int32_t dtype, head_dim, n_heads;
+  vorta_tensor x; /* (H,S,D): Q or K */
+  const int32_t* head_list;
+  const int32_t* n_heads_dev;
+  int32_t latent[3], group[3];
+  int32_t n_keep; /* kept margins per group = int(g*(1-rate)) - 1 */
+  int32_t tail_first, n_tail;
+  const int32_t* row_map; /* optional [t*h*w + ...] */
+  int32_t* keep_rows;
+  int64_t keep_rows_stride_h;
+  int32_t* drop_rows; /* may be NULL (K side needs no drop list) */
+  int64_t drop_rows_stride_h;
+} vorta_coreset_args;
+
+int vorta_coreset_select(const vorta_coreset_args* args, void* hip_stream);
+
+/*
+ * vorta_sta_build_tables -- sliding_attn_flex.py:72-134 (mask_mod) + tile.py:7-78 (tile/untile) as tables.
+ *
+ *   q_rows [S]                 tile-major position -> raster token id (tile.py:26-29, sp = 1)
+ *   kv_rows[n_tiles][n_kv]     keys visible to each q tile: the clamped window of tiles
+ *                              (sliding_attn_flex.py:118-127) in tile-major order, then the t_eff valid
+ *                              text tokens S..S+t_eff-1 (:112);  n_kv = prod(min(n_d, ...)) * tok + t_eff
+ * n_kv is returned through *n_kv_out (host).  row_map as in vorta_coreset_select.
+ */
+typedef struct vorta_sta_args {
+  uint32_t struct_size;
+  int32_t latent[3], tile[3], window[3];
+  int32_t t_eff;
+  const int32_t* row_map;
+  int32_t* q_rows;
+  int32_t* kv_rows;
+} vorta_sta_args;
+
+int vorta_sta_table_sizes(const vorta_sta_args* args, int32_t* n_tiles, int32_t* tok_per_tile, int32_t* n_kv);
+int vorta_sta_build_tables(const vorta_sta_args* args, void* hip_stream);
+
+/*
+ * vorta_router_route -- vorta/patch/router.py:33-43 (Router.forward) + the top-1 / tau rule of
+ * `_get_routed_qkv` (hunyuan.py:620-624, wan.py:396-400), without the host sync of torch.nonzero.
+ *
+ *   scores[b][h][e] = softmax_e( W[3h+e,:] . silu(temb[b,:]) + bias[3h+e] )           (dtype of temb)
+ *   expert_of_head[h] = argmax_e scores[0][h][e]  (first max), 0 if that score < tau   (batch item 0)
+ *   head_lists[e][..] / head_counts[e] : ascending heads of expert e (device; feed n_heads_dev)
+ */
+typedef struct vorta_router_args {
+  uint32_t struct_size;
+  int32_t dtype;
+  int32_t batch, embed_dim, heads, n_experts; /* n_experts = 3 */
+  const void* temb;   /* [batch][embed_dim] */
+  const void* weight; /* [heads*n_experts][embed_dim] */
+  const void* bias;   /* [heads*n_experts] */
+  float tau;
+  void* scores;            /* [batch][heads][n_experts], may be NULL */
+  int32_t* expert_of_head; /* [heads] */
+  int32_t* head_lists;     /* [n_experts][heads] */
+  int32_t* head_counts;    /* [n_experts] */
+  float* ws_logits;        /* workspace [batch][heads][n_experts] floats (caller-owned) */
+} vorta_router_args;
+
+int vorta_router_route(const vorta_router_args* args, void* hip_stream);
+
+/*
+ * vorta_seq_row_map -- physical row of every token for the zero-copy Ulysses layout.
+ * After all_to_all_single of a sequence-sharded (H, S/P, D) tensor (vorta/ulysses/utils.py:61-91) rank r
+ * holds P chunks of (H/P, S/P, D); the reference re-packs them into (H/P, S, D) with two
+ * transpose+contiguous passes (:84-89).  Instead the kernels read the received buffer in place:
+ * token s of local head hl is row  (s / Sl) * (Hl*Sl) + hl*Sl + s % Sl  ->  row_map[s] holds the part
+ * that does not depend on the head, the head term is stride_h = Sl rows.
+ */
+int vorta_seq_row_map(int32_t* row_map, int32_t n_tokens, int32_t seg_len, int32_t seg_stride_rows, void* hip_stream);
+
+/* Introspection */
+int vorta_abi_version(void);
+const char* vorta_build_info(void); /* static string: arch, compiler */
+int vorta_last_hip_error(void);     /* last hipError_t seen by a failed launch in this thread */
+int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VORTA_HIP_H */

@@ -1,0 +1,215 @@
+"""GPU parity: the HIP gather flash-attention kernel (through the C ABI) vs the CPU oracle and the golden
+vectors.  Run with `-m gpu` on an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vorta_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# Stated tolerances: bf16/fp16 I/O, fp32 accumulation.
+#   vs the oracle evaluated on the SAME rounded inputs: only P/O rounding remains
+ATOL_SAME = {torch.bfloat16: 1.2e-2, torch.float16: 2.5e-3}
+RELF_SAME = {torch.bfloat16: 6e-3, torch.float16: 1.2e-3}
+#   vs golden vectors computed by the reference in fp32 from unrounded inputs
+ATOL_GOLD = 2e-2
+RELF_GOLD = 1e-2
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_fro(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def to_dev(x, dtype):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dtype).to(dev())
+
+
+def rounded(x, dtype):
+    """fp64 numpy copy of x after rounding to `dtype` (what the kernel actually sees)."""
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dtype).to(torch.float64).numpy()
+
+
+def pad128(x):
+    """zero-pad the last dim to 128: q.k and cosines are unchanged, extra output columns are zero."""
+    x = np.asarray(x)
+    out = np.zeros(x.shape[:-1] + (128,), dtype=x.dtype)
+    out[..., : x.shape[-1]] = x
+    return out
+
+
+def check(out, ref, dtype, gold=False):
+    out = out.float().cpu().numpy()
+    atol = ATOL_GOLD if gold else ATOL_SAME[dtype]
+    relf = RELF_GOLD if gold else RELF_SAME[dtype]
+    err = np.abs(out - ref).max()
+    rf = rel_fro(out, ref)
+    assert err <= atol and rf <= relf, f"max|d|={err:.3e} (tol {atol}), relF={rf:.3e} (tol {relf})"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("block_rows", [128, 256])
+def test_dense_ragged(dtype, block_rows):
+    from vorta_amd import ops
+    rng = np.random.default_rng(1)
+    H, Sq, Skv = 3, 333, 417
+    q, k, v = rng.standard_normal((H, Sq, 128)), rng.standard_normal((H, Skv, 128)), rng.standard_normal((H, Skv, 128))
+    n_kv, q_valid = 401, 300  # keys 401.. are padding; query rows 300.. must come out zero
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    out = torch.full((H, Sq, 128), 7.0, dtype=dtype, device=dev())
+    ops.attn_fwd(qd, kd, vd, out, n_q=Sq, n_kv=n_kv, q_valid=q_valid, block_rows=block_rows)
+    torch.cuda.synchronize()
+    ref = O.dense_attention(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), kv_valid=n_kv, q_valid=q_valid)
+    check(out, ref, dtype)
+    assert torch.all(out[:, q_valid:] == 0)
+
+
+def test_dense_golden_hunyuan_and_wan(golden):
+    from vorta_amd import ops
+    g = golden("g6_dense_out")
+    S = 384
+    t, te = (int(x) for x in g["hy_text"])
+    dtype = torch.bfloat16
+    q, k, v = (to_dev(pad128(g[n][0]), dtype) for n in ("hy_q", "hy_k", "hy_v"))
+    out = torch.empty_like(q)
+    ops.attn_fwd(q, k, v, out, n_q=S + t, n_kv=S + te, q_valid=S + te, scale=1 / math.sqrt(16))
+    ref = np.concatenate([g["hy_out"][0], g["hy_eout"][0]], axis=1)
+    check(out[..., :16], ref, dtype, gold=True)
+    assert torch.all(out[..., 16:] == 0) and torch.all(out[:, S + te:] == 0)
+    # Wan self attention and cross attention (Sq != Skv)
+    q, k, v = (to_dev(pad128(g[n][0]), dtype) for n in ("wan_q", "wan_k", "wan_v"))
+    out = torch.empty_like(q)
+    ops.attn_fwd(q, k, v, out, n_q=S, n_kv=S, scale=0.25)
+    check(out[..., :16], g["wan_out"][0], dtype, gold=True)
+    kc, vc = to_dev(pad128(g["wan_kc"][0]), dtype), to_dev(pad128(g["wan_vc"][0]), dtype)
+    ops.attn_fwd(q, kc, vc, out, n_q=S, n_kv=kc.shape[1], scale=0.25)
+    check(out[..., :16], g["wan_cross_out"][0], dtype, gold=True)
+
+
+def test_head_list_offsets_and_strides():
+    """head-slot indirection, device-side head count, row offsets, non-contiguous (B,S,H,D)-style strides."""
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(2)
+    H, S = 5, 200
+    base = rng.standard_normal((3, S, H, 128))  # (qkv, S, H, D) storage, heads interleaved per token
+    qkv = to_dev(base, dtype)
+    q, k, v = (qkv[i].permute(1, 0, 2) for i in range(3))  # (H,S,D) views with stride_s = H*128
+    out = torch.zeros((H, S, 128), dtype=dtype, device=dev())
+    heads = torch.tensor([4, 1, 3], dtype=torch.int32, device=dev())
+    count = torch.tensor([2], dtype=torch.int32, device=dev())  # only the first two slots are live
+    ops.attn_fwd(q, k, v, out, head_list=heads, n_heads_dev=count, n_q=50, q_row_offset=120, n_kv=70,
+                 kv_row_offset=30)
+    torch.cuda.synchronize()
+    r = [rounded(base[i].transpose(1, 0, 2), dtype) for i in range(3)]
+    for h in (4, 1):
+        ref = O.dense_attention(r[0][h, 120:170], r[1][h, 30:100], r[2][h, 30:100])
+        check(out[h, 120:170], ref, dtype)
+    assert torch.all(out[3] == 0) and torch.all(out[0] == 0) and torch.all(out[4, :120] == 0)
+
+
+@pytest.mark.parametrize("n_splits", [3, 8])
+def test_split_keys(n_splits):
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(3)
+    H, Sq, Skv = 2, 40, 1000
+    q, k, v = rng.standard_normal((H, Sq, 128)), rng.standard_normal((H, Skv, 128)), rng.standard_normal((H, Skv, 128))
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    out = torch.empty_like(qd)
+    ops.attn_fwd(qd, kd, vd, out, n_q=Sq, n_kv=Skv - 7, q_valid=33, n_splits=n_splits)
+    ref = O.dense_attention(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), kv_valid=Skv - 7, q_valid=33)
+    check(out, ref, dtype)
+    assert torch.all(out[:, 33:] == 0)
+
+
+def test_row_tables_groups_and_duplicates():
+    """q_rows / kv_rows indirection with query groups (each group its own key list) and duplicate rows."""
+    from vorta_amd import ops
+    dtype = torch.float16
+    rng = np.random.default_rng(4)
+    H, S = 2, 600
+    q, k, v = (rng.standard_normal((H, S, 128)) for _ in range(3))
+    n_groups, glen, n_kv = 3, 100, 150
+    q_rows = rng.permutation(S)[: n_groups * glen].astype(np.int32)  # distinct rows, shared by heads
+    kv_rows = np.stack([rng.permutation(S)[:n_kv] for _ in range(n_groups)]).astype(np.int32)
+    rest = np.setdiff1d(np.arange(S), q_rows)
+    n_dup_pos, n_dup = 40, 3
+    dup = rest[: n_dup_pos * n_dup].reshape(n_dup_pos, n_dup).astype(np.int32)
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    out = torch.zeros_like(qd)
+    ops.attn_fwd(qd, kd, vd, out, n_q=n_groups * glen, q_group_len=glen, n_kv=n_kv,
+                 q_rows=torch.as_tensor(q_rows, device=dev()), kv_rows=torch.as_tensor(kv_rows, device=dev()),
+                 kv_rows_stride_g=n_kv, dup_rows=torch.as_tensor(dup, device=dev()), n_dup_pos=n_dup_pos)
+    torch.cuda.synchronize()
+    rq, rk, rv = rounded(q, dtype), rounded(k, dtype), rounded(v, dtype)
+    ref = np.zeros((H, S, 128))
+    for g in range(n_groups):
+        rows = q_rows[g * glen:(g + 1) * glen]
+        ref[:, rows] = O.dense_attention(rq[:, rows], rk[:, kv_rows[g]], rv[:, kv_rows[g]])
+    for p in range(n_dup_pos):
+        ref[:, dup[p]] = ref[:, q_rows[p]][:, None]
+    check(out, ref, dtype)
+    untouched = np.setdiff1d(rest, dup.reshape(-1))
+    assert torch.all(out[:, torch.as_tensor(untouched, device=dev())] == 0)
+
+
+def test_online_softmax_rescale_branch():
+    """A late key that dwarfs every earlier score forces the running-max rescale (guide rule 26)."""
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(5)
+    H, Sq, Skv = 1, 64, 512
+    q, k, v = rng.standard_normal((H, Sq, 128)), rng.standard_normal((H, Skv, 128)), rng.standard_normal((H, Skv, 128))
+    for row, key in ((3, 200), (17, 450), (40, 70)):
+        k[0, key] = q[0, row] * 4.0  # score ~ 4*|q|^2/sqrt(128) >> the rest, first seen in a late block
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    out = torch.empty_like(qd)
+    ops.attn_fwd(qd, kd, vd, out, n_q=Sq, n_kv=Skv)
+    ref = O.dense_attention(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype))
+    check(out, ref, dtype)
+
+
+def test_bad_arguments_raise():
+    from vorta_amd import ops
+    q = torch.zeros((1, 64, 128), dtype=torch.bfloat16, device=dev())
+    with pytest.raises(ValueError):
+        ops.attn_fwd(q, q, q, q.clone(), n_q=64, n_kv=0)
+    with pytest.raises(Exception):
+        ops.attn_fwd(q[..., :64], q[..., :64], q[..., :64], q[..., :64].clone(), n_q=64, n_kv=64)  # head_dim 64
+    with pytest.raises(ValueError):
+        ops.attn_fwd(q, q, q, q.clone(), n_q=64, n_kv=64, block_rows=100)
+
+
+@pytest.mark.parametrize("S", [32760, 118800])
+def test_full_size_properties(S):
+    """Size-independent properties at BASELINE.json's full sequence lengths (one head, dense):
+       * a value matrix that is constant along the sequence must be reproduced exactly (rows of P sum to 1);
+       * the result does not depend on the order of the keys (kv_rows = a permutation)."""
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    gen = torch.Generator(device="cpu").manual_seed(S)
+    q = torch.randn((1, S, 128), generator=gen).to(dtype).to(dev())
+    k = torch.randn((1, S, 128), generator=gen).to(dtype).to(dev())
+    const = torch.randn((1, 1, 128), generator=gen).to(dtype).to(dev())
+    out = torch.empty_like(q)
+    ops.attn_fwd(q, k, const.expand(1, S, 128).contiguous(), out, n_q=S, n_kv=S)
+    assert (out.float() - const.float()).abs().max().item() <= 2e-2
+    v = torch.randn((1, S, 128), generator=gen).to(dtype).to(dev())
+    ops.attn_fwd(q, k, v, out, n_q=S, n_kv=S)
+    perm = torch.randperm(S, generator=gen).to(torch.int32).to(dev())
+    out2 = torch.empty_like(q)
+    ops.attn_fwd(q, k, v, out2, n_q=S, n_kv=S, kv_rows=perm)
+    assert (out.float() - out2.float()).abs().max().item() <= 1e-2
+    # spot check 64 rows against the oracle
+    rows = torch.randint(0, S, (64,), generator=gen)
+    ref = O.dense_attention(q[0, rows].double().cpu().numpy(), k[0].double().cpu().numpy(), v[0].double().cpu().numpy())
+    got = out[0, rows.to(dev())].float().cpu().numpy()
+    assert np.abs(got - ref).max() <= ATOL_SAME[dtype]

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""Quick kernel timing on the GPU box: dense attention TFLOP/s of vorta_attn_fwd vs torch SDPA."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from vorta_amd import ops
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--S", type=int, default=32760)
+    ap.add_argument("--H", type=int, default=12)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--block_rows", type=int, default=0)
+    ap.add_argument("--sdpa", action="store_true")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    dev = torch.device("cuda:0")
+    q, k, v = (torch.randn((a.H, a.S, 128), device=dev, dtype=dt) for _ in range(3))
+    o = torch.empty_like(q)
+    flops = 4.0 * a.S * a.S * 128 * a.H
+    for br in ([a.block_rows] if a.block_rows else [256, 128]):
+        ms = timeit(lambda: ops.attn_fwd(q, k, v, o, n_q=a.S, n_kv=a.S, block_rows=br), a.iters)
+        print(f"vorta_attn_fwd S={a.S} H={a.H} {a.dtype} block_rows={br}: {ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s", flush=True)
+    if a.sdpa:
+        import torch.nn.functional as F
+        q4, k4, v4 = q[None], k[None], v[None]
+        ms = timeit(lambda: F.scaled_dot_product_attention(q4, k4, v4), a.iters)
+        print(f"torch SDPA: {ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s")
+        ref = F.scaled_dot_product_attention(q4, k4, v4)[0]
+        print("max|vorta - sdpa| =", (o.float() - ref.float()).abs().max().item())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""Build libvorta_hip.so (hand-written HIP kernels + C ABI) for gfx950, in tree.
+
+    python -m vorta_amd.build          # or  __graft_entry__.build()
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(CSRC, "libvorta_hip.so")
+SOURCES = ["api.hip", "attn_fwd.hip", "coreset.hip", "sta_tables.hip", "router.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
+         "-Wno-unused-result"]
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "vorta_hip.h")]
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print("[vorta_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or any(_newer(o, LIB) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[vorta_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

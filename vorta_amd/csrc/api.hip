@@ -1,0 +1,28 @@
+// Introspection entry points and the error slot of libvorta_hip.
+#include <hip/hip_runtime.h>
+
+#include "vorta_hip.h"
+#include "common.h"
+
+static thread_local int g_last_hip_error = 0;
+
+int vorta_set_hip_error(hipError_t e) {
+  g_last_hip_error = (int)e;
+  return VORTA_ELAUNCH;
+}
+
+extern "C" int vorta_abi_version(void) { return VORTA_ABI_VERSION; }
+extern "C" const char* vorta_build_info(void) { return "libvorta_hip gfx950 (CDNA4) hipcc " __VERSION__; }
+extern "C" int vorta_last_hip_error(void) { return g_last_hip_error; }
+
+// struct sizes, so a binding can verify its layout before the first call
+extern "C" int vorta_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(vorta_tensor);
+    case 1: return (int)sizeof(vorta_attn_args);
+    case 2: return (int)sizeof(vorta_coreset_args);
+    case 3: return (int)sizeof(vorta_sta_args);
+    case 4: return (int)sizeof(vorta_router_args);
+    default: return -1;
+  }
+}

@@ -1,0 +1,447 @@
+// Gather flash-attention forward for gfx950 (MI355X, CDNA4).  One kernel serves the dense, coreset and
+// sliding-tile experts of VORTA's routed attention (include/vorta_hip.h: vorta_attn_fwd).
+//
+// Structure (per workgroup = NW waves, each wave owns 32 query rows; keys in blocks of 64):
+//   * swapped QK^T: S^T[kv][q] = K . Q^T with v_mfma_f32_32x32x16 -> a lane owns ONE query (lane&31) and
+//     16+16 of the 64 scores of the block, so the row max/sum are in-lane plus one half-wave exchange;
+//   * the S^T accumulator is used directly as the B operand of the PV product O^T[d][q] = V^T . P^T
+//     (rows of the 32x32 accumulator are the k index of the next MFMA; no lane movement);
+//   * K tile in LDS with a 16-way XOR swizzle (ds_read_b128 conflict free), V tile row-major with a
+//     64-byte-quadrant swizzle read through ds_read_b64_tr_b16 (hardware transpose);
+//   * K/V blocks are fetched global -> registers one block ahead (issue early, write to LDS late),
+//     LDS double buffered, one barrier per block; every row goes through an optional int32 row table,
+//     which is how pool/unpool (coreset) and tile/untile (sliding tile) are fused into the kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vorta_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int KVB = 64;            // keys per block
+constexpr int D = 128;             // head dim
+constexpr int ROWB = D * 2;        // bytes per row
+constexpr int TILE_BYTES = KVB * ROWB;  // 16 KiB
+constexpr int BUF_BYTES = 2 * TILE_BYTES;
+
+struct Params {
+  const char* q; const char* k; const char* v; char* o;
+  int64_t q_sh, k_sh, v_sh, o_sh;  // head strides in bytes
+  int64_t q_ss, k_ss, v_ss, o_ss;  // row strides in bytes
+  const int32_t* head_list; const int32_t* n_heads_dev;
+  int n_heads;
+  int n_q, q_group_len, q_row_offset, q_valid;
+  int n_groups, blocks_per_group;
+  const int32_t* q_rows; int64_t q_rows_sh;
+  int n_kv, kv_row_offset;
+  const int32_t* kv_rows; int64_t kv_rows_sh, kv_rows_sg;
+  const int32_t* dup_rows; int64_t dup_rows_sh; int n_dup_pos, n_dup;
+  float scale_log2;  // scale * log2(e)
+  int n_splits, blocks_per_split;
+  float* ws_o; float* ws_ml;
+};
+
+template <typename T> struct MF;
+template <> struct MF<__bf16> {
+  using v8 = bf16x8; using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ v4 tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS v4*)p);
+  }
+};
+template <> struct MF<_Float16> {
+  using v8 = f16x8; using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ v4 tr(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) __fp16 h4;
+    h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS h4*)p);
+    return *(v4*)&r;
+  }
+};
+
+// v_permlane32_swap(vdst, src) exchanges lanes 32-63 of vdst with lanes 0-31 of src.  Fed the same value
+// twice it returns {low half, low half} and {high half, high half}: combining the two results gives every
+// lane the reduction over itself and its partner lane ^ 32 (the two lanes that share one query row).
+__device__ __forceinline__ float half_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
+  using V8 = typename MF<T>::v8;
+  using V4 = typename MF<T>::v4;
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
+  constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+
+  // ---- work decomposition (XCD-aware: consecutive logical ids share an XCD's L2) ----
+  const int nwg = gridDim.x;
+  int wg;
+  {
+    const int b = blockIdx.x, xcd = b & 7, qd = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
+  }
+  const int sp = wg % p.n_splits;
+  const int rest = wg / p.n_splits;
+  const int n_qb = p.n_groups * p.blocks_per_group;
+  const int qb = rest % n_qb;
+  const int y = rest / n_qb;
+  if (p.n_heads_dev && y >= *p.n_heads_dev) return;
+  const int head = p.head_list ? p.head_list[y] : y;
+  const int grp = qb / p.blocks_per_group;
+  const int bi = qb - grp * p.blocks_per_group;
+  const int p0 = grp * p.q_group_len + bi * QB;
+  const int pend = min((grp + 1) * p.q_group_len, p.n_q);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31;
+  const int hh = lane >> 5;
+
+  // ---- key block range of this split ----
+  const int nblk_total = (p.n_kv + KVB - 1) / KVB;
+  const int blk0 = sp * p.blocks_per_split;
+  const int blk1 = min(blk0 + p.blocks_per_split, nblk_total);
+
+  // ---- query rows ----
+  const int wrow0 = p0 + wave * 32;
+  const bool wave_active = wrow0 < pend;  // wave-uniform
+  const int my_p = wrow0 + r32;
+  const bool row_ok = my_p < pend;
+  const int ld_p = min(my_p, pend - 1);
+  const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
+  const int64_t my_row = q_rows ? (int64_t)q_rows[ld_p] : (int64_t)(p.q_row_offset + ld_p);
+
+  V8 qf[8];
+  {
+    const char* qp = p.q + (int64_t)head * p.q_sh + my_row * p.q_ss + hh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const V8*)(qp + ks * 32);
+  }
+
+  // ---- loader setup ----
+  const int32_t* kv_rows =
+      p.kv_rows ? p.kv_rows + (int64_t)y * p.kv_rows_sh + (int64_t)grp * p.kv_rows_sg : nullptr;
+  const char* kbase = p.k + (int64_t)head * p.k_sh + (tid & 15) * 16;
+  const char* vbase = p.v + (int64_t)head * p.v_sh + (tid & 15) * 16;
+  const int lrow0 = tid >> 4;
+  const int lcc = tid & 15;
+  int k_wr[CH], v_wr[CH];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int row = lrow0 + i * ROWSTEP;
+    k_wr[i] = row * ROWB + ((lcc ^ (row & 15)) << 4);
+    v_wr[i] = TILE_BYTES + row * ROWB + ((lcc ^ ((row & 3) << 2)) << 4);
+  }
+  u32x4 kreg[CH], vreg[CH];
+  int64_t nrow[CH];  // row ids of the NEXT block to fetch (index prefetch)
+#define FETCH_ROWS(blk_)                                                          \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
+    const int pos_ = min((blk_) * KVB + lrow0 + i_ * ROWSTEP, p.n_kv - 1);        \
+    nrow[i_] = kv_rows ? (int64_t)kv_rows[pos_] : (int64_t)(p.kv_row_offset + pos_); \
+  }
+#define ISSUE_LOADS()                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
+    kreg[i_] = *(const u32x4*)(kbase + nrow[i_] * p.k_ss);                        \
+    vreg[i_] = *(const u32x4*)(vbase + nrow[i_] * p.v_ss);                        \
+  }
+#define WRITE_LDS(buf_)                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
+    *(u32x4*)(smem + (buf_) * BUF_BYTES + k_wr[i_]) = kreg[i_];                   \
+    *(u32x4*)(smem + (buf_) * BUF_BYTES + v_wr[i_]) = vreg[i_];                   \
+  }
+
+  // ---- LDS read addresses ----
+  int k_rd[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_rd[ks] = r32 * ROWB + (((2 * ks + hh) ^ (r32 & 15)) << 4);
+  int v_rd[4];
+  {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      v_rd[dt] = TILE_BYTES + (4 * (g >> 1) + q4) * ROWB + ((dt ^ q4) << 6) + 32 * (g & 1) + 8 * pp;
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale_log2;
+
+  if (blk0 < blk1) {
+    FETCH_ROWS(blk0);
+    ISSUE_LOADS();
+    if (blk0 + 1 < blk1) { FETCH_ROWS(blk0 + 1); }
+    WRITE_LDS(0);
+    if (blk0 + 1 < blk1) { ISSUE_LOADS(); }
+    if (blk0 + 2 < blk1) { FETCH_ROWS(blk0 + 2); }
+    __syncthreads();
+  }
+
+  for (int blk = blk0; blk < blk1; ++blk) {
+    const int buf = (blk - blk0) & 1;
+    const char* sb = smem + buf * BUF_BYTES;
+    V8 pb[4];
+    if (wave_active) {
+      // ---------------- S^T = K . Q^T ----------------
+      f32x16 s0, s1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const V8 k0 = *(const V8*)(sb + k_rd[ks]);
+        const V8 k1 = *(const V8*)(sb + k_rd[ks] + 32 * ROWB);
+        s0 = MF<T>::mfma(k0, qf[ks], s0);
+        s1 = MF<T>::mfma(k1, qf[ks], s1);
+      }
+      // ---------------- mask the tail of the key list ----------------
+      const int kv0 = blk * KVB;
+      if (kv0 + KVB > p.n_kv) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (kv0 + row >= p.n_kv) s0[i] = -INFINITY;
+          if (kv0 + 32 + row >= p.n_kv) s1[i] = -INFINITY;
+        }
+      }
+      // ---------------- online softmax (one query per lane) ----------------
+      float mx = s0[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s0[i]);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s1[i]);
+      mx = half_max(mx);
+      const float m_new = fmaxf(m_run, mx);
+      if (!__all(m_new == m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        l_run *= alpha;
+        m_run = m_new;
+      }
+      const float mc = m_run * c;
+      float lsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s0[i] = __builtin_amdgcn_exp2f(fmaf(s0[i], c, -mc));
+        s1[i] = __builtin_amdgcn_exp2f(fmaf(s1[i], c, -mc));
+        lsum += s0[i] + s1[i];
+      }
+      l_run += lsum;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pb[0][j] = (T)s0[j];
+        pb[1][j] = (T)s0[8 + j];
+        pb[2][j] = (T)s1[j];
+        pb[3][j] = (T)s1[8 + j];
+      }
+    }
+    // ---------------- stage the next key block (loads were issued one block ago) ----------------
+    if (blk + 1 < blk1) {
+      WRITE_LDS(buf ^ 1);
+      if (blk + 2 < blk1) { ISSUE_LOADS(); }
+      if (blk + 3 < blk1) { FETCH_ROWS(blk + 3); }
+    }
+    if (wave_active) {
+      // ---------------- O^T += V^T . P^T ----------------
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+          const V4 lo = MF<T>::tr(sb + v_rd[dt] + (16 * kg) * ROWB);
+          const V4 hi = MF<T>::tr(sb + v_rd[dt] + (16 * kg + 8) * ROWB);
+          V8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+          o[dt] = MF<T>::mfma(vf, pb[kg], o[dt]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (!wave_active) return;
+  // ---------------- epilogue ----------------
+  const float l_tot = half_sum(l_run);
+  if (p.n_splits > 1) {
+    // unnormalised partials: ws_o[y][sp][pos][d], ws_ml[y][sp][pos][2]
+    if (row_ok) {
+      const int64_t slot = ((int64_t)y * p.n_splits + sp) * p.n_q + my_p;
+      float* wo = p.ws_o + slot * D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          f32x4 v = {o[dt][4 * rg], o[dt][4 * rg + 1], o[dt][4 * rg + 2], o[dt][4 * rg + 3]};
+          *(f32x4*)(wo + 32 * dt + 8 * rg + 4 * hh) = v;
+        }
+      if (hh == 0) {
+        p.ws_ml[slot * 2] = m_run;
+        p.ws_ml[slot * 2 + 1] = l_tot;
+      }
+    }
+    return;
+  }
+  if (!row_ok) return;
+  const float inv = (my_p < p.q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
+  uint2 packed[16];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      V4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (T)(o[dt][4 * rg + j] * inv);
+      packed[dt * 4 + rg] = *(uint2*)&t;
+    }
+  char* obase = p.o + (int64_t)head * p.o_sh + hh * 8;
+  auto store_row = [&](int64_t row) {
+    char* op = obase + row * p.o_ss;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) *(uint2*)(op + (32 * dt + 8 * rg) * 2) = packed[dt * 4 + rg];
+  };
+  store_row(my_row);
+  if (p.dup_rows && my_p < p.n_dup_pos) {
+    const int32_t* dr = p.dup_rows + (int64_t)y * p.dup_rows_sh + (int64_t)my_p * p.n_dup;
+    for (int i = 0; i < p.n_dup; ++i) store_row((int64_t)dr[i]);
+  }
+}
+
+// Merge the split-key partials: one wave per (head slot, query position).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const Params p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)p.n_heads * p.n_q) return;
+  const int y = (int)(item / p.n_q);
+  const int pos = (int)(item - (int64_t)y * p.n_q);
+  if (p.n_heads_dev && y >= *p.n_heads_dev) return;
+  const int head = p.head_list ? p.head_list[y] : y;
+  float m = -1e30f;
+  for (int s = 0; s < p.n_splits; ++s) m = fmaxf(m, p.ws_ml[(((int64_t)y * p.n_splits + s) * p.n_q + pos) * 2]);
+  float acc0 = 0.f, acc1 = 0.f, l = 0.f;
+  for (int s = 0; s < p.n_splits; ++s) {
+    const int64_t slot = ((int64_t)y * p.n_splits + s) * p.n_q + pos;
+    const float w = __builtin_amdgcn_exp2f((p.ws_ml[slot * 2] - m) * p.scale_log2);
+    l += w * p.ws_ml[slot * 2 + 1];
+    const float2 v = *(const float2*)(p.ws_o + slot * D + lane * 2);
+    acc0 += w * v.x;
+    acc1 += w * v.y;
+  }
+  const float inv = (pos < p.q_valid && l > 0.f) ? 1.f / l : 0.f;
+  const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
+  const int64_t row = q_rows ? (int64_t)q_rows[pos] : (int64_t)(p.q_row_offset + pos);
+  T pair[2] = {(T)(acc0 * inv), (T)(acc1 * inv)};
+  char* ob = p.o + (int64_t)head * p.o_sh + lane * 4;
+  *(uint32_t*)(ob + row * p.o_ss) = *(uint32_t*)pair;
+  if (p.dup_rows && pos < p.n_dup_pos) {
+    const int32_t* dr = p.dup_rows + (int64_t)y * p.dup_rows_sh + (int64_t)pos * p.n_dup;
+    for (int i = 0; i < p.n_dup; ++i) *(uint32_t*)(ob + (int64_t)dr[i] * p.o_ss) = *(uint32_t*)pair;
+  }
+}
+
+template <typename T, int NW>
+int launch(const Params& p, hipStream_t st) {
+  const int64_t n_qb = (int64_t)p.n_groups * p.blocks_per_group;
+  const int64_t total = n_qb * p.n_heads * p.n_splits;
+  if (total <= 0) return VORTA_OK;
+  if (total > 0x7fffffff) return VORTA_EINVAL;
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NW>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vorta_set_hip_error(e);
+  if (p.n_splits > 1) {
+    const int64_t items = (int64_t)p.n_heads * p.n_q;
+    hipLaunchKernelGGL((attn_combine_kernel<T>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return vorta_set_hip_error(e);
+  }
+  return VORTA_OK;
+}
+
+int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
+  if (!a || a->struct_size != sizeof(vorta_attn_args)) return VORTA_EINVAL;
+  if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
+  if (a->head_dim != D) return VORTA_EUNSUPPORTED;
+  if (a->n_heads < 0 || a->n_q < 0 || a->n_kv < 0) return VORTA_EINVAL;
+  if (a->n_heads == 0 || a->n_q == 0) { block_rows = 0; p.n_groups = 0; p.blocks_per_group = 0; p.n_heads = 0; return VORTA_OK; }
+  if (a->n_kv == 0) return VORTA_EINVAL;  // softmax over nothing is undefined in the reference too
+  if (!a->q.ptr || !a->k.ptr || !a->v.ptr || !a->o.ptr) return VORTA_EINVAL;
+  const vorta_tensor* ts[4] = {&a->q, &a->k, &a->v, &a->o};
+  for (auto t : ts) {
+    if (((uintptr_t)t->ptr & 15) || (t->stride_s % 8) || (t->stride_h % 8) || t->stride_s < D) return VORTA_EINVAL;
+  }
+  if (a->n_splits < 1 || a->n_splits > 1024) return VORTA_EINVAL;
+  if (a->n_splits > 1 && (!a->ws_o || !a->ws_ml)) return VORTA_EINVAL;
+  if (a->q_group_len < 0 || a->q_valid < 0) return VORTA_EINVAL;
+  if (a->dup_rows && (a->n_dup < 0 || a->n_dup_pos < 0 || a->n_dup_pos > a->n_q)) return VORTA_EINVAL;
+  if (a->block_rows != 0 && a->block_rows != 128 && a->block_rows != 256) return VORTA_EINVAL;
+  p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr; p.o = (char*)a->o.ptr;
+  p.q_sh = a->q.stride_h * 2; p.k_sh = a->k.stride_h * 2; p.v_sh = a->v.stride_h * 2; p.o_sh = a->o.stride_h * 2;
+  p.q_ss = a->q.stride_s * 2; p.k_ss = a->k.stride_s * 2; p.v_ss = a->v.stride_s * 2; p.o_ss = a->o.stride_s * 2;
+  p.head_list = a->head_list; p.n_heads_dev = a->n_heads_dev; p.n_heads = a->n_heads;
+  p.n_q = a->n_q; p.q_group_len = a->q_group_len > 0 ? a->q_group_len : a->n_q;
+  p.q_row_offset = a->q_row_offset; p.q_valid = a->q_valid;
+  p.q_rows = a->q_rows; p.q_rows_sh = a->q_rows_stride_h;
+  p.n_kv = a->n_kv; p.kv_row_offset = a->kv_row_offset;
+  p.kv_rows = a->kv_rows; p.kv_rows_sh = a->kv_rows_stride_h; p.kv_rows_sg = a->kv_rows_stride_g;
+  p.dup_rows = a->dup_rows; p.dup_rows_sh = a->dup_rows_stride_h; p.n_dup_pos = a->n_dup_pos; p.n_dup = a->n_dup;
+  p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.n_splits = a->n_splits; p.ws_o = a->ws_o; p.ws_ml = a->ws_ml;
+  p.n_groups = (p.n_q + p.q_group_len - 1) / p.q_group_len;
+  block_rows = a->block_rows;
+  if (block_rows == 0) {
+    // 256-row workgroups halve the L2->LDS key traffic; 128-row ones waste less on short groups
+    const int g = p.q_group_len;
+    const int waste256 = ((g + 255) / 256) * 256 - g, waste128 = ((g + 127) / 128) * 128 - g;
+    block_rows = (waste256 * 8 > g && waste128 < waste256) ? 128 : 256;
+    if (g <= 128) block_rows = 128;
+  }
+  p.blocks_per_group = (p.q_group_len + block_rows - 1) / block_rows;
+  const int nblk = (p.n_kv + KVB - 1) / KVB;
+  p.blocks_per_split = (nblk + p.n_splits - 1) / p.n_splits;
+  return VORTA_OK;
+}
+
+}  // namespace
+
+extern "C" int vorta_attn_workspace_bytes(const vorta_attn_args* a, uint64_t* ws_o_bytes, uint64_t* ws_ml_bytes) {
+  if (!a || a->struct_size != sizeof(vorta_attn_args) || !ws_o_bytes || !ws_ml_bytes) return VORTA_EINVAL;
+  if (a->n_splits <= 1) { *ws_o_bytes = 0; *ws_ml_bytes = 0; return VORTA_OK; }
+  const uint64_t slots = (uint64_t)a->n_heads * (uint64_t)a->n_splits * (uint64_t)a->n_q;
+  *ws_o_bytes = slots * D * sizeof(float);
+  *ws_ml_bytes = slots * 2 * sizeof(float);
+  return VORTA_OK;
+}
+
+extern "C" int vorta_attn_fwd(const vorta_attn_args* a, void* hip_stream) {
+  Params p{};
+  int block_rows = 0;
+  int rc = fill_params(a, p, block_rows);
+  if (rc != VORTA_OK) return rc;
+  if (p.n_heads == 0 || p.n_groups == 0) return VORTA_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (a->dtype == VORTA_BF16)
+    return block_rows == 256 ? launch<__bf16, 8>(p, st) : launch<__bf16, 4>(p, st);
+  return block_rows == 256 ? launch<_Float16, 8>(p, st) : launch<_Float16, 4>(p, st);
+}

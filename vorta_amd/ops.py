@@ -1,0 +1,200 @@
+"""Tensor-level launchers over the C ABI (vorta_amd/_C.py).  PyTorch supplies device memory and the current
+stream; all arithmetic happens inside libvorta_hip.so.
+
+Tensors are (H, S, D) views ("head-major"): a (B, H, S, D) batch is folded with `fold_heads`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _C
+
+_DT = {torch.bfloat16: _C.VORTA_BF16, torch.float16: _C.VORTA_FP16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(*ts: torch.Tensor):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _C.VortaHipError("vorta_amd ops need tensors on an MI355X (cuda) device; there is no CPU path")
+
+
+def _tensor(t: torch.Tensor) -> _C.Tensor:
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError(f"expected a (H,S,D) view with contiguous D, got shape {tuple(t.shape)} strides {t.stride()}")
+    return _C.Tensor(t.data_ptr(), t.stride(0), t.stride(1))
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=torch.int32):
+    if t is None:
+        return None
+    if t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"index tables must be contiguous {dtype}")
+    return t.data_ptr()
+
+
+def fold_heads(x: torch.Tensor) -> torch.Tensor:
+    """(B,H,S,D) -> (B*H,S,D) view without copying (requires stride_b == H*stride_h)."""
+    if x.dim() == 3:
+        return x
+    B, H, S, D = x.shape
+    if B == 1:
+        return x[0]
+    if x.stride(0) != H * x.stride(1):
+        raise ValueError("batch cannot be folded into the head axis without a copy")
+    return x.as_strided((B * H, S, D), (x.stride(1), x.stride(2), x.stride(3)), x.storage_offset())
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *,
+             n_q: int, n_kv: int,
+             head_list: Optional[torch.Tensor] = None, n_heads: Optional[int] = None,
+             n_heads_dev: Optional[torch.Tensor] = None,
+             q_group_len: int = 0, q_row_offset: int = 0, q_valid: Optional[int] = None,
+             q_rows: Optional[torch.Tensor] = None,
+             kv_row_offset: int = 0, kv_rows: Optional[torch.Tensor] = None, kv_rows_stride_g: int = 0,
+             dup_rows: Optional[torch.Tensor] = None, n_dup_pos: int = 0,
+             scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1) -> None:
+    """vorta_attn_fwd (include/vorta_hip.h).  q_rows/kv_rows/dup_rows: int32; a leading head-slot axis is
+    optional (2-D q_rows = per head slot, 1-D = shared)."""
+    _require_gpu(q, k, v, out)
+    if q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype == out.dtype):
+        raise ValueError("q,k,v,out must share dtype bf16 or fp16")
+    a = _C.AttnArgs()
+    a.struct_size = C.sizeof(_C.AttnArgs)
+    a.dtype = _DT[q.dtype]
+    a.head_dim = q.shape[-1]
+    a.q, a.k, a.v, a.o = _tensor(q), _tensor(k), _tensor(v), _tensor(out)
+    if n_heads is None:
+        n_heads = head_list.numel() if head_list is not None else q.shape[0]
+    a.n_heads = n_heads
+    a.head_list = _ptr(head_list)
+    a.n_heads_dev = _ptr(n_heads_dev)
+    a.n_q, a.q_group_len, a.q_row_offset = n_q, q_group_len, q_row_offset
+    a.q_valid = n_q if q_valid is None else q_valid
+    a.q_rows = _ptr(q_rows)
+    a.q_rows_stride_h = q_rows.stride(0) if (q_rows is not None and q_rows.dim() == 2) else 0
+    a.n_kv, a.kv_row_offset = n_kv, kv_row_offset
+    a.kv_rows = _ptr(kv_rows)
+    if kv_rows is not None and kv_rows_stride_g == 0 and kv_rows.dim() == 2:
+        a.kv_rows_stride_h = kv_rows.stride(0)  # (slots, n_kv): per head slot, one group
+    a.kv_rows_stride_g = kv_rows_stride_g
+    a.dup_rows = _ptr(dup_rows)
+    if dup_rows is not None:
+        if dup_rows.dim() == 3:  # (slots, n_dup_pos, n_dup)
+            a.dup_rows_stride_h = dup_rows.stride(0)
+        a.n_dup = dup_rows.shape[-1]
+        a.n_dup_pos = n_dup_pos if n_dup_pos else dup_rows.shape[-2]
+    a.scale = (1.0 / math.sqrt(q.shape[-1])) if scale is None else scale
+    a.block_rows = block_rows
+    a.n_splits = n_splits
+    ws = None
+    if n_splits > 1:
+        so, sm = C.c_uint64(), C.c_uint64()
+        _C.check(_C.lib().vorta_attn_workspace_bytes(C.byref(a), C.byref(so), C.byref(sm)), "vorta_attn_workspace_bytes")
+        ws = (torch.empty(so.value // 4, dtype=torch.float32, device=q.device),
+              torch.empty(sm.value // 4, dtype=torch.float32, device=q.device))
+        a.ws_o, a.ws_ml = ws[0].data_ptr(), ws[1].data_ptr()
+    _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+    # `ws` may be released now: the caching allocator is stream ordered and the launch is on this stream
+
+
+def coreset_select(x: torch.Tensor, latent: Sequence[int], group: Sequence[int], n_keep: int, *,
+                   head_list: Optional[torch.Tensor] = None, n_heads: Optional[int] = None,
+                   n_heads_dev: Optional[torch.Tensor] = None, tail_first: int = 0, n_tail: int = 0,
+                   row_map: Optional[torch.Tensor] = None, want_drop: bool = True
+                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """vorta_coreset_select: returns keep_rows (slots, G*(1+n_keep)+n_tail) and drop_rows (slots, G, g-1-n_keep)."""
+    _require_gpu(x)
+    if n_heads is None:
+        n_heads = head_list.numel() if head_list is not None else x.shape[0]
+    g = group[0] * group[1] * group[2]
+    G = (latent[0] // group[0]) * (latent[1] // group[1]) * (latent[2] // group[2])
+    keep = torch.empty((n_heads, G * (1 + n_keep) + n_tail), dtype=torch.int32, device=x.device)
+    drop = torch.empty((n_heads, G, g - 1 - n_keep), dtype=torch.int32, device=x.device) if want_drop else None
+    a = _C.CoresetArgs()
+    a.struct_size = C.sizeof(_C.CoresetArgs)
+    a.dtype, a.head_dim, a.n_heads = _DT[x.dtype], x.shape[-1], n_heads
+    a.x = _tensor(x)
+    a.head_list, a.n_heads_dev = _ptr(head_list), _ptr(n_heads_dev)
+    a.latent = (C.c_int32 * 3)(*latent)
+    a.group = (C.c_int32 * 3)(*group)
+    a.n_keep, a.tail_first, a.n_tail = n_keep, tail_first, n_tail
+    a.row_map = _ptr(row_map)
+    a.keep_rows, a.keep_rows_stride_h = keep.data_ptr(), keep.stride(0)
+    if drop is not None:
+        a.drop_rows, a.drop_rows_stride_h = drop.data_ptr(), drop.stride(0)
+    _C.check(_C.lib().vorta_coreset_select(C.byref(a), _stream()), "vorta_coreset_select")
+    return keep, drop
+
+
+def sta_table_sizes(latent, tile, window, t_eff: int = 0) -> Tuple[int, int, int]:
+    """(n_tiles, tokens_per_tile, n_kv) -- host-only geometry query (works without a GPU)."""
+    a = _C.StaArgs()
+    a.struct_size = C.sizeof(_C.StaArgs)
+    a.latent, a.tile, a.window = (C.c_int32 * 3)(*latent), (C.c_int32 * 3)(*tile), (C.c_int32 * 3)(*window)
+    a.t_eff = t_eff
+    nt, tok, nkv = C.c_int32(), C.c_int32(), C.c_int32()
+    _C.check(_C.lib().vorta_sta_table_sizes(C.byref(a), C.byref(nt), C.byref(tok), C.byref(nkv)), "vorta_sta_table_sizes")
+    return nt.value, tok.value, nkv.value
+
+
+def sta_build_tables(latent, tile, window, t_eff: int, device, row_map: Optional[torch.Tensor] = None
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """vorta_sta_build_tables: q_rows (S,) and kv_rows (n_tiles, n_kv) int32 on `device`."""
+    n_tiles, tok, n_kv = sta_table_sizes(latent, tile, window, t_eff)
+    S = latent[0] * latent[1] * latent[2]
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _C.VortaHipError("sta_build_tables needs a cuda device")
+    q_rows = torch.empty(S, dtype=torch.int32, device=dev)
+    kv_rows = torch.empty((n_tiles, n_kv), dtype=torch.int32, device=dev)
+    a = _C.StaArgs()
+    a.struct_size = C.sizeof(_C.StaArgs)
+    a.latent, a.tile, a.window = (C.c_int32 * 3)(*latent), (C.c_int32 * 3)(*tile), (C.c_int32 * 3)(*window)
+    a.t_eff = t_eff
+    a.row_map = _ptr(row_map)
+    a.q_rows, a.kv_rows = q_rows.data_ptr(), kv_rows.data_ptr()
+    with torch.cuda.device(dev):
+        _C.check(_C.lib().vorta_sta_build_tables(C.byref(a), _stream()), "vorta_sta_build_tables")
+    return q_rows, kv_rows
+
+
+def router_route(temb: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, heads: int, tau: float,
+                 n_experts: int = 3):
+    """vorta_router_route: returns (scores (B,H,E) in temb.dtype, expert_of_head (H,), head_lists (E,H), head_counts (E,))
+    -- all on device; nothing is synchronised."""
+    _require_gpu(temb, weight, bias)
+    B, E = temb.shape
+    dev = temb.device
+    temb, weight, bias = temb.contiguous(), weight.contiguous(), bias.contiguous()
+    scores = torch.empty((B, heads, n_experts), dtype=temb.dtype, device=dev)
+    expert = torch.empty(heads, dtype=torch.int32, device=dev)
+    lists = torch.zeros((n_experts, heads), dtype=torch.int32, device=dev)
+    counts = torch.empty(n_experts, dtype=torch.int32, device=dev)
+    ws = torch.empty(B * heads * n_experts, dtype=torch.float32, device=dev)
+    a = _C.RouterArgs()
+    a.struct_size = C.sizeof(_C.RouterArgs)
+    a.dtype = _DT[temb.dtype]
+    a.batch, a.embed_dim, a.heads, a.n_experts = B, E, heads, n_experts
+    a.temb, a.weight, a.bias = temb.data_ptr(), weight.data_ptr(), bias.data_ptr()
+    a.tau = tau
+    a.scores, a.expert_of_head = scores.data_ptr(), expert.data_ptr()
+    a.head_lists, a.head_counts, a.ws_logits = lists.data_ptr(), counts.data_ptr(), ws.data_ptr()
+    _C.check(_C.lib().vorta_router_route(C.byref(a), _stream()), "vorta_router_route")
+    return scores, expert, lists, counts
+
+
+def seq_row_map(n_tokens: int, seg_len: int, seg_stride_rows: int, device) -> torch.Tensor:
+    """vorta_seq_row_map (zero-copy Ulysses layout)."""
+    out = torch.empty(n_tokens, dtype=torch.int32, device=device)
+    with torch.cuda.device(out.device):
+        _C.check(_C.lib().vorta_seq_row_map(out.data_ptr(), n_tokens, seg_len, seg_stride_rows, _stream()),
+                 "vorta_seq_row_map")
+    return out
