@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- denoising-step attention time of VORTA's routed sparse attention on MI355X.
+
+One "step" = one denoising step of the named model = every attention layer of the transformer once
+(x forwards per step), each layer being ONE routed-attention op (router dispatch is given, experts:
+full / coreset / sliding tile) on synthetic post-RoPE Q/K/V already resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W] [--config hunyuan-129f] [--mix uniform]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1: Ulysses over RCCL)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and, at N=1,
+`cpu_baseline`.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# ------------------------------------------------------------------------------------------------ configs
+# latent = pixel2token(video) (vorta/patch/utils.py:76-92); H/layers/text from the public model configs
+# (SURVEY.md §8); tile/window/group: SURVEY.md §8(d) table ("proposed" = our stated choice where the
+# authors' geometry does not divide the latent grid; the authors' own shapes are listed too).
+CONFIGS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    "hunyuan-129f": dict(model="hunyuan", latent=(33, 45, 80), heads=24, layers=60, fwd_per_step=1, text=256,
+                         text_valid=96, tile=(11, 9, 8), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="fp16"),
+    # authors' own benchmark shape (vorta/constants.py:8-12, scripts/hunyuan/train.sh:10-18)
+    "hunyuan-117f": dict(model="hunyuan", latent=(30, 45, 80), heads=24, layers=60, fwd_per_step=1, text=256,
+                         text_valid=96, tile=(6, 9, 8), window=(3, 3, 3), group=(2, 3, 2), rate=0.5, dtype="bf16"),
+    # BASELINE.json configs[1]
+    "wan1.3b-81f": dict(model="wan", latent=(21, 30, 52), heads=12, layers=30, fwd_per_step=2, text=0, text_valid=0,
+                        tile=(7, 6, 4), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
+    # BASELINE.json configs[4] geometry in bf16 (the fp8 path is not built yet)
+    "wan14b-81f": dict(model="wan", latent=(21, 45, 80), heads=40, layers=40, fwd_per_step=2, text=0, text_valid=0,
+                       tile=(7, 9, 8), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
+    "wan14b-77f": dict(model="wan", latent=(20, 45, 80), heads=40, layers=40, fwd_per_step=2, text=0, text_valid=0,
+                       tile=(5, 9, 8), window=(3, 3, 3), group=(2, 3, 2), rate=0.5, dtype="bf16"),
+    # tiny, for rehearsals
+    "tiny": dict(model="hunyuan", latent=(9, 12, 16), heads=8, layers=4, fwd_per_step=1, text=64, text_valid=40,
+                 tile=(3, 6, 8), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
+}
+# routing mixes (fractions full / lowres / sliding), SURVEY.md §8(d): no router weights exist offline
+MIXES = {"all-full": (1, 0, 0), "all-lowres": (0, 1, 0), "all-sliding": (0, 0, 1), "uniform": (1 / 3, 1 / 3, 1 / 3),
+         "sparse-heavy": (1 / 6, 1 / 3, 1 / 2)}
+
+PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def layer_experts(cfg, mix, layer, heads=None):
+    """expert id per head for one layer: counts fixed by the mix, assignment drawn with rng(1234+layer)."""
+    H = cfg["heads"] if heads is None else heads
+    f = MIXES[mix]
+    n1 = int(round(H * f[1]))
+    n2 = int(round(H * f[2]))
+    n0 = H - n1 - n2
+    ids = np.array([0] * n0 + [1] * n1 + [2] * n2)
+    return np.random.default_rng(1234 + layer).permutation(ids)
+
+
+def algorithmic_flops(cfg, experts):
+    """SURVEY.md §8(d) / BASELINE.md §2 per-layer work for a given head->expert assignment."""
+    from vorta_amd import ops
+    S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
+    te, D = cfg["text_valid"], 128
+    g = cfg["group"][0] * cfg["group"][1] * cfg["group"][2]
+    s_low = (S // g) * (1 + int(g * (1 - cfg["rate"])) - 1)
+    _, tok, n_kv = ops.sta_table_sizes(cfg["latent"], cfg["tile"], cfg["window"], te)
+    f_full = 4.0 * (S + te) ** 2 * D
+    f_low = 4.0 * (s_low + te) ** 2 * D
+    f_sl = 4.0 * D * (S * n_kv + te * (S + te))
+    n = [int((experts == e).sum()) for e in range(3)]
+    return n[0] * f_full + n[1] * f_low + n[2] * f_sl, dict(full=f_full, lowres=f_low, sliding=f_sl)
+
+
+def cpu_baseline(cfg, mix, step_flops):
+    """The CPU oracle (oracle/vorta_oracle.py, numpy) timed on this host on a bounded sample of the same
+    workload: one query slab per expert at the full key length, extrapolated by algorithmic FLOPs."""
+    from oracle import vorta_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
+    te, D = cfg["text_valid"], 128
+    rng = np.random.default_rng(0)
+    k = rng.standard_normal((1, 1, S + te, D)).astype(np.float32)
+    v = rng.standard_normal((1, 1, S + te, D)).astype(np.float32)
+    rows = 2048
+    q = rng.standard_normal((1, 1, rows, D)).astype(np.float32)
+    t0 = time.perf_counter()
+    done_flops, n = 0.0, 0
+    while time.perf_counter() - t0 < 12.0:
+        O._softmax_attend(q, k, v, dtype=np.float32)
+        done_flops += 4.0 * rows * (S + te) * D
+        n += 1
+    dt = time.perf_counter() - t0
+    rate = done_flops / dt  # FLOP/s of the oracle's attention core on this host
+    step_s = step_flops / rate
+    tokens = S * cfg["fwd_per_step"]
+    return {"value": tokens / step_s, "unit": "video_tokens/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} x dense oracle attention of {rows} query rows against all {S + te} keys (1 head, fp32 numpy), "
+                      f"{dt:.1f}s = {rate / 1e9:.0f} GFLOP/s, extrapolated by algorithmic FLOPs to the whole routed step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="hunyuan-129f", choices=sorted(CONFIGS))
+    ap.add_argument("--mix", default="uniform", choices=sorted(MIXES))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"])
+    ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    if args.dtype:
+        cfg["dtype"] = args.dtype
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+
+    dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16
+    H, L, T, te = cfg["heads"], cfg["layers"], cfg["text"], cfg["text_valid"]
+    S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
+    hy = cfg["model"] == "hunyuan"
+    P = world
+
+    # ---- per-layer routing (and, for P>1, the head -> rank placement that balances expert cost) ----
+    layer_ids = [layer_experts(cfg, args.mix, l) for l in range(L)]
+    step_flops = 0.0
+    for e in layer_ids:
+        f, per_head = algorithmic_flops(cfg, e)
+        step_flops += f * cfg["fwd_per_step"]
+
+    if P == 1:
+        geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], dev)
+        routings = [HeadRouting.from_expert_ids(e, dev) for e in layer_ids]
+        sets = []
+        for i in range(args.qkv_sets):
+            gen = torch.Generator(device=dev).manual_seed(1234 + i)
+            sets.append(tuple(torch.randn((1, H, S + T, 128), generator=gen, device=dev, dtype=dt) for _ in range(3)))
+        out = torch.empty_like(sets[0][0])
+        if te:
+            geom.sta_tables(te)  # built once per prompt, outside the step (pipeline_hunyuan.py:378-392)
+
+        def one_step():
+            for _ in range(cfg["fwd_per_step"]):
+                for l in range(L):
+                    q, k, v = sets[l % len(sets)]
+                    routed_attention(q, k, v, routings[l], geom, model=cfg["model"], text_len=T, text_valid=te, out=out)
+    else:
+        from vorta_amd import ulysses
+        sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P)
+
+        def one_step():
+            for _ in range(cfg["fwd_per_step"]):
+                for l in range(L):
+                    sp.layer(l)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    tl = ops.Timeline()
+    ops.set_timeline(tl)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_timeline(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    tokens = S * cfg["fwd_per_step"]
+
+    # ---- roofline of the dominant kernel: attn_fwd_kernel<T,8> (256-row workgroups: full + coreset + text) ----
+    summ = tl.summary()
+    dom = {k: v for k, v in summ.items() if k[1] == 256}
+    dom_ms = sum(v["ms"] for v in dom.values())
+    dom_fl = sum(v["flops"] for v in dom.values())
+    dom_n = sum(v["launches"] for v in dom.values())
+    if P > 1:
+        dom_fl = dom_fl  # per-rank launches carry per-rank flops
+    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": f"attn_fwd_kernel<{'_Float16' if dt == torch.float16 else '__bf16'},8>",
+                "achieved": round(achieved, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": dom_n, "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
+                "flops_per_launch": dom_fl / max(dom_n, 1)}
+    per_tag = {f"{k[0]}@{k[1]}": {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0}
+               for k, v in sorted(summ.items())}
+
+    res = {
+        "metric": "video_tokens_per_sec (routed-attention denoising step, HunyuanVideo 720p 129f)"
+        if args.config == "hunyuan-129f" else f"video_tokens_per_sec (routed-attention denoising step, {args.config})",
+        "value": round(tokens / (ms_per_step * 1e-3), 1), "unit": "video_tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
+                               f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
+                               f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
+                   "parallelism": "single GPU" if P == 1 else f"ulysses sp{P} (RCCL send/recv over xGMI)",
+                   "step_algorithmic_pflop": round(step_flops / 1e15, 3),
+                   "step_tflops_per_gpu": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world, 1)},
+        "roofline": roofline,
+        "per_launch": per_tag,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, args.mix, step_flops)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

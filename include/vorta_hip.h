@@ -95,6 +95,9 @@ typedef struct vorta_attn_args {
 } vorta_attn_args;
 
 int vorta_attn_fwd(const vorta_attn_args* args, void* hip_stream);
+/* the launch shape vorta_attn_fwd would use: query rows per workgroup (128 -> kernel attn_fwd_kernel<T,4>,
+ * 256 -> attn_fwd_kernel<T,8>) and the number of workgroups; pure host computation */
+int vorta_attn_plan(const vorta_attn_args* args, int32_t* block_rows, int64_t* n_workgroups);
 /* bytes of ws_o and ws_ml for a given launch (0,0 when n_splits <= 1) */
 int vorta_attn_workspace_bytes(const vorta_attn_args* args, uint64_t* ws_o_bytes, uint64_t* ws_ml_bytes);
 

@@ -163,9 +163,10 @@ def sta_mask(latent: Triple, tile: Triple, window: Triple, t_text: int, t_eff: i
 
 # ----------------------------------------------------------------------------------------------- A3
 def _softmax_attend(q: np.ndarray, k: np.ndarray, v: np.ndarray, mask: Optional[np.ndarray] = None,
-                    scale: Optional[float] = None) -> np.ndarray:
-    """softmax(q k^T * scale [masked]) v over the last two dims; fully-masked rows -> 0."""
-    q, k, v = (np.asarray(a, dtype=np.float64) for a in (q, k, v))
+                    scale: Optional[float] = None, dtype=np.float64) -> np.ndarray:
+    """softmax(q k^T * scale [masked]) v over the last two dims; fully-masked rows -> 0.
+    (`dtype=np.float32` is used only by bench.py's cpu_baseline leg, to time the port at a fair precision.)"""
+    q, k, v = (np.asarray(a, dtype=dtype) for a in (q, k, v))
     scale = 1.0 / np.sqrt(q.shape[-1]) if scale is None else scale
     s = np.einsum("...qd,...kd->...qk", q, k) * scale
     if mask is not None:

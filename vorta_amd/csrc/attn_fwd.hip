@@ -434,6 +434,16 @@ extern "C" int vorta_attn_workspace_bytes(const vorta_attn_args* a, uint64_t* ws
   return VORTA_OK;
 }
 
+extern "C" int vorta_attn_plan(const vorta_attn_args* a, int32_t* block_rows_out, int64_t* n_workgroups_out) {
+  Params p{};
+  int block_rows = 0;
+  int rc = fill_params(a, p, block_rows);
+  if (rc != VORTA_OK) return rc;
+  if (block_rows_out) *block_rows_out = block_rows;
+  if (n_workgroups_out) *n_workgroups_out = (int64_t)p.n_groups * p.blocks_per_group * p.n_heads * (p.n_heads ? p.n_splits : 0);
+  return VORTA_OK;
+}
+
 extern "C" int vorta_attn_fwd(const vorta_attn_args* a, void* hip_stream) {
   Params p{};
   int block_rows = 0;

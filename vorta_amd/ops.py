@@ -16,6 +16,33 @@ from . import _C
 _DT = {torch.bfloat16: _C.VORTA_BF16, torch.float16: _C.VORTA_FP16}
 
 
+class Timeline:
+    """Optional per-launch HIP-event timing of vorta_attn_fwd (used by bench.py for the roofline figure).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (tag, block_rows, n_workgroups, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, br, nwg, flops, e0, e1 in self.records:
+            d = out.setdefault((tag, br), dict(launches=0, ms=0.0, flops=0.0, workgroups=0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["workgroups"] += nwg
+        return out
+
+
+_timeline: Optional[Timeline] = None
+
+
+def set_timeline(t: Optional[Timeline]):
+    global _timeline
+    _timeline = t
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -60,7 +87,8 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
              q_rows: Optional[torch.Tensor] = None,
              kv_row_offset: int = 0, kv_rows: Optional[torch.Tensor] = None, kv_rows_stride_g: int = 0,
              dup_rows: Optional[torch.Tensor] = None, n_dup_pos: int = 0,
-             scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1) -> None:
+             scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1,
+             tag: str = "", flops: float = 0.0) -> None:
     """vorta_attn_fwd (include/vorta_hip.h).  q_rows/kv_rows/dup_rows: int32; a leading head-slot axis is
     optional (2-D q_rows = per head slot, 1-D = shared)."""
     _require_gpu(q, k, v, out)
@@ -101,6 +129,15 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
         ws = (torch.empty(so.value // 4, dtype=torch.float32, device=q.device),
               torch.empty(sm.value // 4, dtype=torch.float32, device=q.device))
         a.ws_o, a.ws_ml = ws[0].data_ptr(), ws[1].data_ptr()
+    if _timeline is not None:
+        br, nwg = C.c_int32(), C.c_int64()
+        _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg)), "vorta_attn_plan")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+        e1.record()
+        _timeline.records.append((tag, br.value, nwg.value, flops, e0, e1))
+        return
     _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
     # `ws` may be released now: the caching allocator is stream ordered and the launch is on this stream
 

@@ -1,0 +1,176 @@
+"""Routed sparse attention: the per-layer operator behind the attention processors.
+
+Takes post-RoPE q,k,v (B,H,S[+T],D) and a head->expert assignment and enqueues, on the current stream,
+at most:  1 launch for the full-attention heads, 2 selects + 1 launch for the coreset heads, and 1 (+1 for
+Hunyuan's text queries) launch for the sliding-tile heads.  Every launch reads the original q,k,v through
+head lists and row tables and writes its heads directly into the final output: the reference's per-expert
+head gathers (hunyuan.py:612-640), pooled copies (coreset_select.py:68-124), tile/untile permutes
+(tile.py) and boolean index-put (hunyuan.py:642-661) have no counterpart here.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import ops
+
+Triple = Tuple[int, int, int]
+
+
+@dataclass
+class HeadRouting:
+    """head -> expert assignment.  Either host lists (counts known on the host) or the device tables written
+    by ops.router_route (no host sync; every expert launch is sized for H slots and trims itself)."""
+    lists: torch.Tensor                 # (3, H) int32 device, ascending heads per expert
+    counts_host: Optional[List[int]]    # [n0,n1,n2] or None when only the device knows
+    counts_dev: Optional[torch.Tensor]  # (3,) int32 device
+
+    @staticmethod
+    def from_expert_ids(expert_of_head: Sequence[int], device) -> "HeadRouting":
+        H = len(expert_of_head)
+        lists = torch.zeros((3, H), dtype=torch.int32)
+        counts = []
+        for e in range(3):
+            hs = [h for h, x in enumerate(expert_of_head) if int(x) == e]
+            counts.append(len(hs))
+            if hs:
+                lists[e, : len(hs)] = torch.tensor(hs, dtype=torch.int32)
+        return HeadRouting(lists.to(device), counts, None)
+
+    @staticmethod
+    def from_device(lists: torch.Tensor, counts: torch.Tensor) -> "HeadRouting":
+        return HeadRouting(lists, None, counts)
+
+    def slot_args(self, e: int, H: int):
+        if self.counts_host is not None:
+            return dict(head_list=self.lists[e], n_heads=self.counts_host[e], n_heads_dev=None)
+        return dict(head_list=self.lists[e], n_heads=H, n_heads_dev=self.counts_dev[e:e + 1])
+
+
+@dataclass
+class RoutedGeometry:
+    """Everything that depends only on (latent, tile, window, coreset window, rate, text length).
+    Built once per run / prompt, like the reference's LowresGroupInfo + BlockMask
+    (vorta/patch/utils.py:8-56, pipeline_hunyuan.py:378-392)."""
+    latent: Triple
+    tile: Triple
+    window: Triple
+    group: Triple
+    rate: float
+    device: torch.device
+    row_map: Optional[torch.Tensor] = None  # zero-copy Ulysses layout (ulysses.py); None = plain (H,S,D)
+    _sta: Dict[int, Tuple[torch.Tensor, torch.Tensor, int]] = field(default_factory=dict)
+
+    def __post_init__(self):
+        self.latent, self.tile, self.window, self.group = (tuple(int(v) for v in x) for x in
+                                                           (self.latent, self.tile, self.window, self.group))
+        self.S = self.latent[0] * self.latent[1] * self.latent[2]
+        self.g = self.group[0] * self.group[1] * self.group[2]
+        for l, t in zip(self.latent, self.tile):
+            if l % t:
+                # same condition and exception type as hunyuan.py:264-267
+                raise ValueError(f"Tile size {self.tile} (dim={t}) does not divide latent shape {self.latent} (dim={l}).")
+        self.G = 1
+        for l, w in zip(self.latent, self.group):
+            self.G *= l // w
+        if self.S != self.G * self.g:
+            raise ValueError(f"Input sequence length {self.S} does not match low-res info {self.G}x{self.g}.")
+        self.n_keep = int(self.g * (1 - self.rate)) - 1  # coreset_select.py:54
+        self.S_low = self.G * (1 + self.n_keep)
+        self.tok = self.tile[0] * self.tile[1] * self.tile[2]
+
+    def sta_tables(self, t_eff: int):
+        if t_eff not in self._sta:
+            q_rows, kv_rows = ops.sta_build_tables(self.latent, self.tile, self.window, t_eff, self.device,
+                                                   row_map=self.row_map)
+            self._sta[t_eff] = (q_rows, kv_rows, kv_rows.shape[1])
+        return self._sta[t_eff]
+
+
+def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
+    """Few query rows against a long key list: cut the keys so the launch fills the chip (256 CUs)."""
+    qblocks = max(1, (n_q + 255) // 256) * max(1, n_heads)
+    kv_blocks = (n_kv + 63) // 64
+    want = max(1, 512 // qblocks)
+    return max(1, min(want, kv_blocks // 8 if kv_blocks >= 16 else 1, 256))
+
+
+def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing: HeadRouting,
+                     geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
+                     out: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
+
+    hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383."""
+    if q.dim() != 4 or q.shape[0] != 1:
+        # hunyuan.py:168 asserts batch 1; Wan's CFG runs two batch-1 forwards (pipeline_wan.py:322-344)
+        raise AssertionError(f"Batch size {q.shape[0]} is not supported by routed_attention.")
+    hy = model == "hunyuan"
+    H, N, D = q.shape[1], q.shape[2], q.shape[3]
+    S, T = geom.S, (text_len if hy else 0)
+    if N != S + T:
+        raise ValueError(f"Input sequence length {N - T} does not match latent shape {geom.latent}.")
+    te = text_valid if hy else 0
+    if out is None:
+        out = torch.empty_like(q)
+    q3, k3, v3, o3 = q[0], k[0], v[0], out[0]
+
+    def live(e):
+        return routing.counts_host is None or routing.counts_host[e] > 0
+
+    def nheads(e):  # for the algorithmic-work tags only
+        return routing.counts_host[e] if routing.counts_host is not None else 0
+
+    # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
+    if live(0):
+        ops.attn_fwd(q3, k3, v3, o3, n_q=S + T, n_kv=S + te, q_valid=S + te, scale=scale, tag="full",
+                     flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H))
+
+    # ---- expert 1: coreset attention (hunyuan.py:410-457 / wan.py:243-270) ----
+    if live(1):
+        sl = routing.slot_args(1, H)
+        keep_q, drop_q = ops.coreset_select(q3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T,
+                                            row_map=geom.row_map, **sl)
+        if hy:  # K matched on its own, V follows K (hunyuan.py:433-438)
+            keep_k, _ = ops.coreset_select(k3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=te,
+                                           row_map=geom.row_map, want_drop=False, **sl)
+        else:   # K and V follow Q's matching (wan.py:250-255)
+            keep_k = keep_q
+        ops.attn_fwd(q3, k3, v3, o3, n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te,
+                     q_rows=keep_q, kv_rows=keep_k, dup_rows=drop_q, n_dup_pos=geom.G, scale=scale, tag="lowres",
+                     flops=nheads(1) * 4.0 * (geom.S_low + te) ** 2 * D, **sl)
+
+    # ---- expert 2: sliding-tile attention (hunyuan.py:459-507 / wan.py:272-294) ----
+    if live(2):
+        sl = routing.slot_args(2, H)
+        q_rows, kv_rows, n_kv = geom.sta_tables(te)
+        ops.attn_fwd(q3, k3, v3, o3, n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
+                     kv_rows_stride_g=n_kv, scale=scale, tag="sliding",
+                     flops=nheads(2) * 4.0 * D * S * n_kv, **sl)
+        if T > 0:
+            # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
+            nh = sl["n_heads"]
+            if geom.row_map is None:
+                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te, scale=scale,
+                             n_splits=_auto_splits(nh, T, S + te), tag="sliding_text",
+                             flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
+            else:
+                rm = geom.row_map
+                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_rows=rm[S:S + T].contiguous(), q_valid=te, n_kv=S + te,
+                             kv_rows=rm[:S + te].contiguous(), scale=scale,
+                             n_splits=_auto_splits(nh, T, S + te), tag="sliding_text",
+                             flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
+    return out
+
+
+def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, kv_valid: Optional[int] = None,
+                    q_valid: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                    scale: Optional[float] = None) -> torch.Tensor:
+    """The --native_attention path: every head dense (hunyuan.py:167-176, wan.py:134-145).  (B,H,Sq,D) x (B,H,Skv,D)."""
+    if out is None:
+        out = torch.empty_like(q)
+    Sq, Skv = q.shape[-2], k.shape[-2]
+    ops.attn_fwd(ops.fold_heads(q), ops.fold_heads(k), ops.fold_heads(v), ops.fold_heads(out), n_q=Sq,
+                 n_kv=Skv if kv_valid is None else kv_valid, q_valid=Sq if q_valid is None else q_valid, scale=scale)
+    return out
