@@ -168,7 +168,7 @@ def _softmax_attend(q: np.ndarray, k: np.ndarray, v: np.ndarray, mask: Optional[
     (`dtype=np.float32` is used only by bench.py's cpu_baseline leg, to time the port at a fair precision.)"""
     q, k, v = (np.asarray(a, dtype=dtype) for a in (q, k, v))
     scale = 1.0 / np.sqrt(q.shape[-1]) if scale is None else scale
-    s = np.einsum("...qd,...kd->...qk", q, k) * scale
+    s = np.matmul(q, np.swapaxes(k, -1, -2)) * scale  # BLAS-backed (einsum is not)
     if mask is not None:
         s = np.where(mask, s, -np.inf)
     mx = s.max(-1, keepdims=True)
@@ -176,7 +176,7 @@ def _softmax_attend(q: np.ndarray, k: np.ndarray, v: np.ndarray, mask: Optional[
     p = np.exp(s - mx)
     den = p.sum(-1, keepdims=True)
     p = np.divide(p, den, out=np.zeros_like(p), where=den > 0)
-    return np.einsum("...qk,...kd->...qd", p, v)
+    return np.matmul(p, v)
 
 
 def dense_attention(q, k, v, kv_valid: Optional[int] = None, q_valid: Optional[int] = None) -> np.ndarray:

@@ -98,6 +98,11 @@ def lib():
         raise VortaHipError(
             f"{LIB_PATH} not found: build it with `python -m vorta_amd.build` (hipcc --offload-arch=gfx950). "
             "The routed attention path has no CPU/PyTorch fallback.")
+    # Load order matters: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7) but links it by
+    # file name, so if this library pulled /opt/rocm's copy in first the process would end up with two HIP
+    # runtimes (launches then fail with hipErrorNoDevice).  Importing torch first makes our NEEDED entry
+    # resolve to the runtime torch already loaded -- one runtime, shared streams and allocations.
+    import torch  # noqa: F401
     try:
         h = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
