@@ -73,7 +73,9 @@ __global__ __launch_bounds__(64) void router_route_kernel(const RParams p) {
       if (sc > best_s) { best_s = sc; best = e; }  // first maximum wins (torch.topk on ties)
     }
     if (b == 0) {
-      if (best_s < p.tau) best = 0;  // hunyuan.py:623
+      // hunyuan.py:623 `top1_score < tau_sparse`: torch compares a tensor with a Python scalar in the tensor's
+      // dtype, i.e. tau is rounded to the score dtype first
+      if (best_s < rnd<T>(p.tau)) best = 0;
       p.expert[h] = best;
       s_expert[h] = best;
     }
