@@ -92,6 +92,10 @@ typedef struct vorta_attn_args {
   int32_t n_splits;   /* >= 1 */
   float* ws_o;        /* [n_heads][n_splits][n_q][D]   when n_splits > 1 */
   float* ws_ml;       /* [n_heads][n_splits][n_q][2]   when n_splits > 1 */
+  /* optional device-resident lengths (e.g. L = attention_mask.sum(), hunyuan.py:169, without the host sync):
+   * effective n_kv = clamp(*n_kv_dev, 1, n_kv), effective q_valid = min(*q_valid_dev, q_valid) */
+  const int32_t* n_kv_dev;
+  const int32_t* q_valid_dev;
 } vorta_attn_args;
 
 int vorta_attn_fwd(const vorta_attn_args* args, void* hip_stream);
@@ -177,6 +181,9 @@ typedef struct vorta_router_args {
 } vorta_router_args;
 
 int vorta_router_route(const vorta_router_args* args, void* hip_stream);
+/* Same dispatch rule applied to scores that already exist (the `routing_score` argument of the processors,
+ * hunyuan.py:528): uses temb/weight/bias = NULL, `scores` as INPUT [batch][heads][n_experts], no workspace. */
+int vorta_route_scores(const vorta_router_args* args, void* hip_stream);
 
 /*
  * vorta_seq_row_map -- physical row of every token for the zero-copy Ulysses layout.

@@ -248,3 +248,42 @@ def test_device_side_routing_is_sync_free_and_equal():
                                 model="hunyuan", text_len=T, text_valid=te)
     assert torch.equal(out_dev, out_host)
     assert len(set(expert.cpu().tolist())) >= 2  # the draw exercises more than one expert
+
+
+@pytest.mark.parametrize("model", ["hunyuan", "wan"])
+def test_zero_copy_ulysses_layout_on_one_gpu(model):
+    """The kernels read the Ulysses receive buffer in place through row_map.  Emulate what rank 1 of P=2
+    holds after scatter_heads (no communication needed to build it) and compare with the plain layout."""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    from vorta_amd.ulysses import UlyssesLayout
+    dtype = torch.bfloat16
+    torch.manual_seed(21)
+    H, P, rank = 6, 2, 1
+    T, te = (16, 11) if model == "hunyuan" else (0, 0)
+    q, k, v = (torch.randn((1, H, S + T, 128), device=dev()).to(dtype) for _ in range(3))
+    experts = [0, 1, 2, 2, 1, 0]
+    order = [0, 2, 4, 5, 3, 1]  # rank 1 owns heads 5,3,1 (in this slot order)
+    lay = UlyssesLayout(H, S, T, 128, P, rank, dev(), dtype)
+    Hl, Sl = lay.Hl, lay.Sl
+    bufs = []
+    for x in (q, k, v):
+        b = lay.new_buffer().zero_()
+        for src in range(P):
+            for i in range(Hl):
+                h = order[rank * Hl + i]
+                b[src * Hl * Sl + i * Sl: src * Hl * Sl + (i + 1) * Sl] = x[0, h, src * Sl:(src + 1) * Sl]
+        for i in range(Hl):
+            b[lay.rows_video + i * Sl: lay.rows_video + i * Sl + T] = x[0, order[rank * Hl + i], S:]
+        bufs.append(b)
+    obuf = lay.new_buffer().zero_()
+    geom_sp = RoutedGeometry(LATENT, TILE, WINDOW, GROUP, 0.5, dev(), row_map=lay.row_map)
+    local_heads = order[rank * Hl:(rank + 1) * Hl]
+    route_local = HeadRouting.from_expert_ids([experts[h] for h in local_heads], dev())
+    routed_attention(*(lay.head_view(b) for b in bufs), route_local, geom_sp, model=model, text_len=T, text_valid=te,
+                     out=lay.head_view(obuf))
+    ref = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), _geom(), model=model, text_len=T,
+                           text_valid=te)
+    ov = lay.head_view(obuf)
+    rm = lay.row_map.long()
+    for i, h in enumerate(local_heads):
+        assert torch.equal(ov[i][rm], ref[0, h]), (i, h)

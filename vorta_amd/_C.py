@@ -33,6 +33,7 @@ class AttnArgs(C.Structure):
         ("n_dup_pos", _i32), ("n_dup", _i32),
         ("scale", _f32), ("block_rows", _i32), ("n_splits", _i32),
         ("ws_o", _vp), ("ws_ml", _vp),
+        ("n_kv_dev", _vp), ("q_valid_dev", _vp),
     ]
 
 
@@ -75,6 +76,7 @@ SYMBOLS = {
     "vorta_sta_table_sizes": (C.c_int, [C.POINTER(StaArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "vorta_sta_build_tables": (C.c_int, [C.POINTER(StaArgs), _vp]),
     "vorta_router_route": (C.c_int, [C.POINTER(RouterArgs), _vp]),
+    "vorta_route_scores": (C.c_int, [C.POINTER(RouterArgs), _vp]),
     "vorta_seq_row_map": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "vorta_abi_version": (C.c_int, []),
     "vorta_build_info": (C.c_char_p, []),

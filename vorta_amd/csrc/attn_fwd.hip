@@ -35,6 +35,7 @@ struct Params {
   int n_groups, blocks_per_group;
   const int32_t* q_rows; int64_t q_rows_sh;
   int n_kv, kv_row_offset;
+  const int32_t* n_kv_dev; const int32_t* q_valid_dev;
   const int32_t* kv_rows; int64_t kv_rows_sh, kv_rows_sg;
   const int32_t* dup_rows; int64_t dup_rows_sh; int n_dup_pos, n_dup;
   float scale_log2;  // scale * log2(e)
@@ -112,8 +113,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
   const int r32 = lane & 31;
   const int hh = lane >> 5;
 
-  // ---- key block range of this split ----
-  const int nblk_total = (p.n_kv + KVB - 1) / KVB;
+  // ---- key block range of this split (n_kv / q_valid may live on the device: no host sync) ----
+  const int n_kv = p.n_kv_dev ? max(1, min(*p.n_kv_dev, p.n_kv)) : p.n_kv;
+  const int q_valid = p.q_valid_dev ? min(*p.q_valid_dev, p.q_valid) : p.q_valid;
+  const int nblk_total = (n_kv + KVB - 1) / KVB;
   const int blk0 = sp * p.blocks_per_split;
   const int blk1 = min(blk0 + p.blocks_per_split, nblk_total);
 
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
   int64_t nrow[CH];  // row ids of the NEXT block to fetch (index prefetch)
 #define FETCH_ROWS(blk_)                                                          \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
-    const int pos_ = min((blk_) * KVB + lrow0 + i_ * ROWSTEP, p.n_kv - 1);        \
+    const int pos_ = min((blk_) * KVB + lrow0 + i_ * ROWSTEP, n_kv - 1);          \
     nrow[i_] = kv_rows ? (int64_t)kv_rows[pos_] : (int64_t)(p.kv_row_offset + pos_); \
   }
 #define ISSUE_LOADS()                                                             \
@@ -213,12 +216,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
       }
       // ---------------- mask the tail of the key list ----------------
       const int kv0 = blk * KVB;
-      if (kv0 + KVB > p.n_kv) {
+      if (kv0 + KVB > n_kv) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (kv0 + row >= p.n_kv) s0[i] = -INFINITY;
-          if (kv0 + 32 + row >= p.n_kv) s1[i] = -INFINITY;
+          if (kv0 + row >= n_kv) s0[i] = -INFINITY;
+          if (kv0 + 32 + row >= n_kv) s1[i] = -INFINITY;
         }
       }
       // ---------------- online softmax (one query per lane) ----------------
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
     return;
   }
   if (!row_ok) return;
-  const float inv = (my_p < p.q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
+  const float inv = (my_p < q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
   uint2 packed[16];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
@@ -349,7 +352,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const Params p) {
     acc0 += w * v.x;
     acc1 += w * v.y;
   }
-  const float inv = (pos < p.q_valid && l > 0.f) ? 1.f / l : 0.f;
+  const int q_valid = p.q_valid_dev ? min(*p.q_valid_dev, p.q_valid) : p.q_valid;
+  const float inv = (pos < q_valid && l > 0.f) ? 1.f / l : 0.f;
   const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
   const int64_t row = q_rows ? (int64_t)q_rows[pos] : (int64_t)(p.q_row_offset + pos);
   T pair[2] = {(T)(acc0 * inv), (T)(acc1 * inv)};
@@ -404,6 +408,7 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   p.q_row_offset = a->q_row_offset; p.q_valid = a->q_valid;
   p.q_rows = a->q_rows; p.q_rows_sh = a->q_rows_stride_h;
   p.n_kv = a->n_kv; p.kv_row_offset = a->kv_row_offset;
+  p.n_kv_dev = a->n_kv_dev; p.q_valid_dev = a->q_valid_dev;
   p.kv_rows = a->kv_rows; p.kv_rows_sh = a->kv_rows_stride_h; p.kv_rows_sg = a->kv_rows_stride_g;
   p.dup_rows = a->dup_rows; p.dup_rows_sh = a->dup_rows_stride_h; p.n_dup_pos = a->n_dup_pos; p.n_dup = a->n_dup;
   p.scale_log2 = a->scale * 1.4426950408889634f;

@@ -89,7 +89,46 @@ __global__ __launch_bounds__(64) void router_route_kernel(const RParams p) {
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(64) void route_scores_kernel(const RParams p) {
+  const int lane = threadIdx.x;
+  __shared__ int s_expert[1024];
+  for (int h = lane; h < p.H; h += 64) {
+    const T* sc = (const T*)p.scores + (int64_t)h * p.NE;  // batch item 0 (hunyuan.py:622)
+    int best = 0;
+    float best_s = (float)sc[0];
+    for (int e = 1; e < p.NE; ++e) {
+      const float v = (float)sc[e];
+      if (v > best_s) { best_s = v; best = e; }
+    }
+    if (best_s < rnd<T>(p.tau)) best = 0;
+    p.expert[h] = best;
+    s_expert[h] = best;
+  }
+  __syncthreads();
+  if (lane < p.NE) {
+    int n = 0;
+    for (int h = 0; h < p.H; ++h)
+      if (s_expert[h] == lane) p.lists[lane * p.H + n++] = h;
+    p.counts[lane] = n;
+  }
+}
+
 }  // namespace
+
+extern "C" int vorta_route_scores(const vorta_router_args* a, void* hip_stream) {
+  if (!a || a->struct_size != sizeof(vorta_router_args)) return VORTA_EINVAL;
+  if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
+  if (a->batch <= 0 || a->heads <= 0 || a->heads > 1024 || a->n_experts <= 0 || a->n_experts > 64) return VORTA_EINVAL;
+  if (!a->scores || !a->expert_of_head || !a->head_lists || !a->head_counts) return VORTA_EINVAL;
+  RParams p{nullptr, nullptr, nullptr, a->batch, 0, a->heads, a->n_experts, a->tau,
+            a->scores, a->expert_of_head, a->head_lists, a->head_counts, nullptr};
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (a->dtype == VORTA_BF16) hipLaunchKernelGGL(route_scores_kernel<__bf16>, dim3(1), dim3(64), 0, st, p);
+  else hipLaunchKernelGGL(route_scores_kernel<_Float16>, dim3(1), dim3(64), 0, st, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
+}
 
 extern "C" int vorta_router_route(const vorta_router_args* a, void* hip_stream) {
   if (!a || a->struct_size != sizeof(vorta_router_args)) return VORTA_EINVAL;

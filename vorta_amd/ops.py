@@ -88,6 +88,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
              kv_row_offset: int = 0, kv_rows: Optional[torch.Tensor] = None, kv_rows_stride_g: int = 0,
              dup_rows: Optional[torch.Tensor] = None, n_dup_pos: int = 0,
              scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1,
+             n_kv_dev: Optional[torch.Tensor] = None, q_valid_dev: Optional[torch.Tensor] = None,
              tag: str = "", flops: float = 0.0) -> None:
     """vorta_attn_fwd (include/vorta_hip.h).  q_rows/kv_rows/dup_rows: int32; a leading head-slot axis is
     optional (2-D q_rows = per head slot, 1-D = shared)."""
@@ -122,6 +123,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     a.scale = (1.0 / math.sqrt(q.shape[-1])) if scale is None else scale
     a.block_rows = block_rows
     a.n_splits = n_splits
+    a.n_kv_dev, a.q_valid_dev = _ptr(n_kv_dev), _ptr(q_valid_dev)
     ws = None
     if n_splits > 1:
         so, sm = C.c_uint64(), C.c_uint64()
@@ -226,6 +228,29 @@ def router_route(temb: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, h
     a.head_lists, a.head_counts, a.ws_logits = lists.data_ptr(), counts.data_ptr(), ws.data_ptr()
     _C.check(_C.lib().vorta_router_route(C.byref(a), _stream()), "vorta_router_route")
     return scores, expert, lists, counts
+
+
+def route_scores(scores: torch.Tensor, tau: float):
+    """vorta_route_scores: top-1 / tau dispatch of an existing (B,H,E) score tensor (batch item 0 routes).
+    Returns (expert_of_head (H,), head_lists (E,H), head_counts (E,)) on device, no host sync."""
+    _require_gpu(scores)
+    if scores.dtype not in _DT:
+        scores = scores.to(torch.bfloat16)
+    scores = scores.contiguous()
+    B, H, E = scores.shape
+    dev = scores.device
+    expert = torch.empty(H, dtype=torch.int32, device=dev)
+    lists = torch.zeros((E, H), dtype=torch.int32, device=dev)
+    counts = torch.empty(E, dtype=torch.int32, device=dev)
+    a = _C.RouterArgs()
+    a.struct_size = C.sizeof(_C.RouterArgs)
+    a.dtype = _DT[scores.dtype]
+    a.batch, a.embed_dim, a.heads, a.n_experts = B, 0, H, E
+    a.tau = tau
+    a.scores, a.expert_of_head = scores.data_ptr(), expert.data_ptr()
+    a.head_lists, a.head_counts = lists.data_ptr(), counts.data_ptr()
+    _C.check(_C.lib().vorta_route_scores(C.byref(a), _stream()), "vorta_route_scores")
+    return expert, lists, counts
 
 
 def seq_row_map(n_tokens: int, seg_len: int, seg_stride_rows: int, device) -> torch.Tensor:

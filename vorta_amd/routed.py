@@ -103,18 +103,19 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
     hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383."""
-    if q.dim() != 4 or q.shape[0] != 1:
+    if q.dim() == 4 and q.shape[0] != 1:
         # hunyuan.py:168 asserts batch 1; Wan's CFG runs two batch-1 forwards (pipeline_wan.py:322-344)
         raise AssertionError(f"Batch size {q.shape[0]} is not supported by routed_attention.")
     hy = model == "hunyuan"
-    H, N, D = q.shape[1], q.shape[2], q.shape[3]
+    H, N, D = q.shape[-3], q.shape[-2], q.shape[-1]
     S, T = geom.S, (text_len if hy else 0)
-    if N != S + T:
+    rm = geom.row_map
+    if rm is None and N != S + T:
         raise ValueError(f"Input sequence length {N - T} does not match latent shape {geom.latent}.")
     te = text_valid if hy else 0
     if out is None:
         out = torch.empty_like(q)
-    q3, k3, v3, o3 = q[0], k[0], v[0], out[0]
+    q3, k3, v3, o3 = (x[0] if x.dim() == 4 else x for x in (q, k, v, out))
 
     def live(e):
         return routing.counts_host is None or routing.counts_host[e] > 0
@@ -125,6 +126,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     if live(0):
         ops.attn_fwd(q3, k3, v3, o3, n_q=S + T, n_kv=S + te, q_valid=S + te, scale=scale, tag="full",
+                     q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
                      flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H))
 
     # ---- expert 1: coreset attention (hunyuan.py:410-457 / wan.py:243-270) ----
@@ -151,14 +153,13 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         if T > 0:
             # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
             nh = sl["n_heads"]
-            if geom.row_map is None:
+            if rm is None:
                 ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te, scale=scale,
                              n_splits=_auto_splits(nh, T, S + te), tag="sliding_text",
                              flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
             else:
-                rm = geom.row_map
-                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_rows=rm[S:S + T].contiguous(), q_valid=te, n_kv=S + te,
-                             kv_rows=rm[:S + te].contiguous(), scale=scale,
+                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_rows=rm[S:S + T], q_valid=te, n_kv=S + te,
+                             kv_rows=rm[:S + te], scale=scale,
                              n_splits=_auto_splits(nh, T, S + te), tag="sliding_text",
                              flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
     return out

@@ -1,0 +1,52 @@
+"""Sequence-parallel process-group state (mirror of vorta/ulysses/parallel_states.py:7-75)."""
+import os
+
+import torch.distributed as dist
+
+
+class SequenceParallelState:
+    """Process-global singleton, same attribute surface as the reference's SP_STATE:
+    rank / local_rank / world_size from the torchrun environment, one SP group per `rank // sp_size`."""
+
+    def __init__(self):
+        self._reset(rank_as_group=False)
+
+    def _reset(self, rank_as_group: bool):
+        self._enabled = False
+        self._sp_size = 1
+        self._group_id = self.rank if rank_as_group else 0
+        self._group_local_rank = 0
+        self._group = None
+
+    rank = property(lambda self: int(os.getenv("RANK", "0")))
+    local_rank = property(lambda self: int(os.getenv("LOCAL_RANK", "0")))
+    world_size = property(lambda self: int(os.getenv("WORLD_SIZE", "1")))
+    enabled = property(lambda self: self._enabled)
+    sp_size = property(lambda self: self._sp_size)
+    group_id = property(lambda self: self._group_id)
+    group_local_rank = property(lambda self: self._group_local_rank)
+    group = property(lambda self: self._group)
+    num_sp_groups = property(lambda self: self.world_size // self.sp_size)
+
+    def setup_sp_group(self, sequence_parallel_size: int):
+        if self.world_size % sequence_parallel_size != 0:
+            raise ValueError(f"{self.world_size=} must be divisible by {sequence_parallel_size=}!")
+        if sequence_parallel_size <= 1:
+            self._reset(rank_as_group=True)
+            return
+        self._enabled = True
+        self._sp_size = sequence_parallel_size
+        self._group_id, self._group_local_rank = divmod(self.rank, sequence_parallel_size)
+        # every rank must create every group (torch.distributed contract); keep our own
+        for gid in range(self.num_sp_groups):
+            ranks = list(range(gid * sequence_parallel_size, (gid + 1) * sequence_parallel_size))
+            grp = dist.new_group(ranks)
+            if gid == self._group_id:
+                self._group = grp
+
+    def cleanup(self):
+        dist.destroy_process_group()
+        self._reset(rank_as_group=False)
+
+
+SP_STATE = SequenceParallelState()
