@@ -134,12 +134,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VORTA_BENCH_BACKEND=gloo: 1-GPU rehearsal of the N>1 code path (all ranks share cuda:0, host-staged
+    # messages); the driver's multi-GPU runs use RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("VORTA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from vorta_amd import ops
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
@@ -229,6 +236,7 @@ def main():
         "value": round(tokens / (ms_per_step * 1e-3), 1), "unit": "video_tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "backend": (backend if world > 1 else None),
         "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",

@@ -75,10 +75,27 @@ class UlyssesLayout:
     def _peer(self, j: int) -> int:
         return dist.get_global_rank(self.group, j) if self.group is not None else j
 
-    def _run(self, ops):
-        if ops:
+    def _staged(self) -> bool:
+        # rehearsal transport: gloo cannot send/recv device memory, so stage through the host.  Only used when
+        # the process group is gloo but the tensors live on a GPU (tests / 1-GPU rehearsals); RCCL is direct.
+        return self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
+
+    def _run(self, p2p):
+        """p2p: list of ("send"|"recv", tensor, peer)."""
+        if not p2p:
+            return
+        if not self._staged():
+            ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._peer(j), self.group) for k, t, j in p2p]
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
+            return
+        host = [(k, t, t.detach().to("cpu") if k == "send" else torch.empty(t.shape, dtype=t.dtype), j) for k, t, j in p2p]
+        ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, h, self._peer(j), self.group) for k, t, h, j in host]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        for k, t, h, j in host:
+            if k == "recv":
+                t.copy_(h)
 
     # ---- sequence shards -> head shards -------------------------------------------------------------
     def scatter_heads(self, shards: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor], head_order: Sequence[int],
@@ -94,13 +111,11 @@ class UlyssesLayout:
                     if j == me:
                         buf[me * Hl * Sl + i * Sl: me * Hl * Sl + (i + 1) * Sl].copy_(src)
                     else:
-                        p2p.append(dist.P2POp(dist.isend, src if src.is_contiguous() else src.contiguous(),
-                                              self._peer(j), self.group))
+                        p2p.append(("send", src if src.is_contiguous() else src.contiguous(), j))
             for j in range(self.P):
                 if j != me:
                     for i in range(Hl):
-                        p2p.append(dist.P2POp(dist.irecv, buf[j * Hl * Sl + i * Sl: j * Hl * Sl + (i + 1) * Sl],
-                                              self._peer(j), self.group))
+                        p2p.append(("recv", buf[j * Hl * Sl + i * Sl: j * Hl * Sl + (i + 1) * Sl], j))
         if texts is not None and self.T:
             for t, buf in zip(texts, bufs):  # t: (H, T, D) replicated
                 for i in range(Hl):
@@ -120,18 +135,22 @@ class UlyssesLayout:
                 if j == me:
                     out_shard[head_order[me * Hl + i]].copy_(src)
                 else:
-                    p2p.append(dist.P2POp(dist.isend, src, self._peer(j), self.group))
+                    p2p.append(("send", src, j))
         for j in range(self.P):
             if j != me:
                 for i in range(Hl):
                     dst = out_shard[head_order[j * Hl + i]]
                     assert dst.is_contiguous()
-                    p2p.append(dist.P2POp(dist.irecv, dst, self._peer(j), self.group))
+                    p2p.append(("recv", dst, j))
         self._run(p2p)
         if out_text is not None and self.T:
             local = torch.stack([buf[self.rows_video + i * Sl: self.rows_video + i * Sl + self.T] for i in range(Hl)])
             parts = [torch.empty_like(local) for _ in range(self.P)]
-            if self.P > 1:
+            if self.P > 1 and self._staged():
+                hp = [torch.empty(local.shape, dtype=local.dtype) for _ in range(self.P)]
+                dist.all_gather(hp, local.cpu(), group=self.group)
+                parts = [h.to(local.device) for h in hp]
+            elif self.P > 1:
                 dist.all_gather(parts, local, group=self.group)
             else:
                 parts = [local]
