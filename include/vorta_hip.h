@@ -33,7 +33,7 @@ extern "C" {
 
 #define VORTA_ABI_VERSION 1
 
-typedef enum vorta_dtype { VORTA_BF16 = 0, VORTA_FP16 = 1 } vorta_dtype;
+typedef enum vorta_dtype { VORTA_BF16 = 0, VORTA_FP16 = 1, VORTA_FP32 = 2 /* vorta_route_scores only */ } vorta_dtype;
 
 /* One (H,S,D) operand: element (h,s,d) lives at ptr + h*stride_h + s*stride_s + d. */
 typedef struct vorta_tensor {

@@ -1,0 +1,86 @@
+"""Sequence-parallel branch of the processors: zero-copy Ulysses (vorta_amd/ulysses/engine.py).
+
+Replaces the per-expert all_to_all_4D / shrink_dim / all_gather choreography of the reference
+(hunyuan.py:147-164,184-187,423-431,453-455,481-489,500-503; wan.py:110-117,138-139,146-147,245-248,267-268,
+280-283,291-292): ALL heads are resharded once per layer, before routing, with one contiguous message per
+(head, peer); routing then happens on the local heads, so any expert mix works under SP (the reference needs
+h_e % P == 0 for every expert).
+"""
+from typing import Optional
+
+import torch
+
+from .. import ops
+from ..routed import HeadRouting, geometry_for, routed_attention
+from ..ulysses import SP_STATE
+from ..ulysses.engine import UlyssesLayout, balanced_head_order
+
+_LAYOUTS = {}
+
+
+def _layout(H, S, T, D, device, dtype):
+    key = (H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, str(device), dtype)
+    if key not in _LAYOUTS:
+        lay = UlyssesLayout(H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, device, dtype, SP_STATE.group)
+        _LAYOUTS[key] = (lay, [lay.new_buffer() for _ in range(4)])
+    return _LAYOUTS[key]
+
+
+def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_sparse: Optional[float], *, model: str,
+                 text_valid: int = 0, attention_mask=None, lowres_group_info=None, window_size=(3, 3, 3),
+                 tile_size=(6, 8, 8), latent_shape=None) -> torch.Tensor:
+    """q,k,v: (1, H, S/P + T, D) local sequence shard with the replicated text at the end.
+    Returns the attention output as a (1, S/P + T, H, D) buffer (text rows: all heads, gathered)."""
+    B, H, N, D = q.shape
+    assert B == 1
+    P = SP_STATE.sp_size
+    Sl = N - T
+    S = Sl * P
+    lay, bufs = _layout(H, S, T, D, q.device, q.dtype)
+    if routing_score is None:  # dense for every head
+        experts = [0] * H
+        te = T if attention_mask is None else int(attention_mask.sum().item()) - S  # host read, as hunyuan.py:169
+    else:
+        # balanced placement needs the routes on the host: one small read per layer (the reference reads
+        # torch.nonzero per expert, hunyuan.py:633); routes depend only on the timestep
+        experts = ops.route_scores(routing_score, tau_sparse)[0].cpu().tolist()
+        te = text_valid
+    dense_only = lowres_group_info is None
+    if dense_only:
+        cost = [1.0, 1.0, 1.0]
+        geom = None
+    else:
+        geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
+                            lowres_group_info.reduction_rate, q.device, row_map=lay.row_map)
+        _, _, n_kv = geom.sta_tables(te)
+        cost = [float(S + te) ** 2, float(geom.S_low + te) ** 2, float(S) * n_kv]
+    order = balanced_head_order(experts, cost, P)
+    shards = [x[0, :, :Sl] for x in (q, k, v)]
+    texts = [x[0, :, Sl:] for x in (q, k, v)] if T else None
+    lay.scatter_heads(shards, bufs[:3], order, texts)
+    qv, kv, vv, ov = (lay.head_view(b) for b in bufs)
+    me = SP_STATE.group_local_rank
+    local = [experts[h] for h in order[me * lay.Hl:(me + 1) * lay.Hl]]
+    if dense_only:
+        rm = lay.row_map
+        ops.attn_fwd(qv, kv, vv, ov, n_q=S + T, n_kv=S + te, q_valid=S + te, q_rows=rm[:S + T], kv_rows=rm[:S + te])
+    else:
+        routed_attention(qv, kv, vv, HeadRouting.from_expert_ids(local, q.device), geom, model=model, text_len=T,
+                         text_valid=te, out=ov)
+    out_h = torch.empty((H, Sl, D), dtype=q.dtype, device=q.device)
+    out_t = torch.empty((H, T, D), dtype=q.dtype, device=q.device) if T else None
+    lay.gather_heads(bufs[3], out_h, order, out_t)
+    buf = torch.empty((1, N, H, D), dtype=q.dtype, device=q.device)
+    buf[0, :Sl] = out_h.transpose(0, 1)
+    if T:
+        buf[0, Sl:] = out_t.transpose(0, 1)
+    return buf
+
+
+def sp_wan_dense(proc, attn, q, k, v, enc_img, is_cross_attn: bool):
+    """Dense Wan attention under SP (wan.py:103-149).  Cross attention has replicated K/V (text / image
+    tokens): every rank already holds all heads of its query shard and every key, so it needs NO
+    communication at all (the reference does an all-to-all of Q and back, wan.py:111-114,147)."""
+    if is_cross_attn:
+        return proc._attn(attn, q, k, v, enc_img, True)
+    return sp_attention(q, k, v, 0, None, None, model="wan"), None

@@ -1,0 +1,169 @@
+"""HunyuanVideo (MMDiT: video + text tokens in one sequence) attention processors.
+
+Same classes, call protocol and keyword names as vorta/attention/hunyuan.py, so diffusers' `Attention.forward`
+and the patched block forwards (modeling_hunyuan.py:492-499,556-563) can call them unchanged.  Projections, qk
+RMSNorm and RoPE stay in torch (rocBLAS); everything between post-RoPE q,k,v and the output projection runs in
+libvorta_hip.so (vorta_amd/routed.py).
+"""
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention
+from ..ulysses import SP_STATE, shrink_dim
+from .coreset_select import LowresGroupInfo
+from .sliding_tile import SlidingTileDescriptor
+
+
+def apply_rotary_emb(x: torch.Tensor, freqs_cis: Tuple[torch.Tensor, torch.Tensor]) -> torch.Tensor:
+    """Rotary embedding on (B,H,S,D) with (cos, sin) of shape (S,D), interleaved real/imag pairs.
+    [ext] restates diffusers==0.33.1 `apply_rotary_emb(use_real=True, use_real_unbind_dim=-1)`, which the
+    reference imports (hunyuan.py:18,97-98); it sits before the attention boundary."""
+    cos, sin = freqs_cis
+    cos, sin = cos[None, None].to(x.device), sin[None, None].to(x.device)
+    x_real, x_imag = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
+    x_rot = torch.stack([-x_imag, x_real], dim=-1).flatten(3)
+    return (x.float() * cos + x_rot.float() * sin).to(x.dtype)
+
+
+class HunyuanVideoFlashAttnProcessor:
+    """Dense attention for every head: the --native_attention path (hunyuan.py:35-238)."""
+
+    def __init__(self):
+        ops._C.lib()  # fail loudly now if libvorta_hip.so is missing: there is no fallback path
+
+    # -- steps 1-4 of hunyuan.py:42-134: everything before the attention boundary ----------------------
+    def _project(self, attn, hidden_states, encoder_hidden_states, image_rotary_emb):
+        single_stream = attn.add_q_proj is None  # single blocks carry text inside hidden_states
+        if single_stream:
+            hidden_states = torch.cat([hidden_states, encoder_hidden_states], dim=1)
+        T = encoder_hidden_states.shape[1]
+        q = attn.to_q(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+        k = attn.to_k(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+        v = attn.to_v(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+        if attn.norm_q is not None:
+            q = attn.norm_q(q)
+        if attn.norm_k is not None:
+            k = attn.norm_k(k)
+        if image_rotary_emb is not None:
+            rope = (shrink_dim(image_rotary_emb[0], dim=0), shrink_dim(image_rotary_emb[1], dim=0))
+            if single_stream:
+                q = torch.cat([apply_rotary_emb(q[:, :, :-T], rope), q[:, :, -T:]], dim=2)
+                k = torch.cat([apply_rotary_emb(k[:, :, :-T], rope), k[:, :, -T:]], dim=2)
+            else:
+                q, k = apply_rotary_emb(q, rope), apply_rotary_emb(k, rope)
+        if not single_stream:
+            eq = attn.add_q_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+            ek = attn.add_k_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+            ev = attn.add_v_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+            if attn.norm_added_q is not None:
+                eq = attn.norm_added_q(eq)
+            if attn.norm_added_k is not None:
+                ek = attn.norm_added_k(ek)
+            q, k, v = torch.cat([q, eq], dim=2), torch.cat([k, ek], dim=2), torch.cat([v, ev], dim=2)
+        return q, k, v, T
+
+    # -- step 6 (hunyuan.py:191-208) ---------------------------------------------------------------------
+    @staticmethod
+    def _output(attn, out_bshd: torch.Tensor, T: int):
+        """out_bshd: (B, S+T, H, D) -- the kernels wrote it in this layout, so the head merge is a view."""
+        hidden = out_bshd[:, :-T].flatten(2, 3)
+        enc = out_bshd[:, -T:].flatten(2, 3)
+        if getattr(attn, "to_out", None) is not None:
+            hidden = attn.to_out[1](attn.to_out[0](hidden))
+        if getattr(attn, "to_add_out", None) is not None:
+            enc = attn.to_add_out(enc)
+        return hidden, enc
+
+    @staticmethod
+    def _new_out(q: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        B, H, N, D = q.shape
+        buf = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+        return buf, buf.permute(0, 2, 1, 3)  # (B,H,N,D) view for the kernels
+
+    @staticmethod
+    def _text_valid(attention_mask: torch.Tensor, n_video: int, descriptor=None) -> int:
+        if descriptor is not None:
+            return descriptor.text_seq_length_no_pad
+        # the reference reads this on the host as well (hunyuan.py:169 `attention_mask.squeeze().sum()`)
+        return int(attention_mask.sum().item()) - n_video * (SP_STATE.sp_size if SP_STATE.enabled else 1)
+
+    def _dense(self, q, k, v, attention_mask, T):
+        B = q.shape[0]
+        assert B == 1, f"Batch size {B} is not supported for {self.__class__.__name__}."  # hunyuan.py:168
+        if SP_STATE.enabled:
+            from ._sp import sp_attention
+            return sp_attention(q, k, v, T, None, None, model="hunyuan", attention_mask=attention_mask)
+        buf, out = self._new_out(q)
+        # L = attention_mask.sum() stays on the device: no host sync (the reference syncs at hunyuan.py:169)
+        L = attention_mask.sum(dtype=torch.int32).reshape(1)
+        N = q.shape[2]
+        ops.attn_fwd(q[0], k[0], v[0], out[0], n_q=N, n_kv=N, q_valid=N, n_kv_dev=L, q_valid_dev=L)
+        return buf
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb):
+        q, k, v, T = self._project(attn, hidden_states, encoder_hidden_states, image_rotary_emb)
+        return self._output(attn, self._dense(q, k, v, attention_mask, T), T)
+
+
+class HunyuanVideoFlashAttnProcessorTripleEval(HunyuanVideoFlashAttnProcessor):
+    """Inference-time routed attention: hard top-1 expert per head (hunyuan.py:516-661)."""
+
+    def __init__(self, check_input: bool = False):
+        super().__init__()
+        self.check_input = check_input
+
+    def _check_input(self, hidden_states, lowres_group_info, latent_shape, window_size, tile_size):
+        """hunyuan.py:247-272 (same conditions, same messages)."""
+        if not self.check_input:
+            return
+        seq_length = hidden_states.shape[1] * SP_STATE.sp_size
+        num_groups = lowres_group_info.center_indices.shape[0]
+        group_size = lowres_group_info.center_indices.shape[1] + lowres_group_info.margin_indices.shape[1]
+        if seq_length != latent_shape[0] * latent_shape[1] * latent_shape[2]:
+            raise ValueError(f"Input sequence length {seq_length} does not match latent shape {latent_shape}.")
+        for t_size, l_size in zip(tile_size, latent_shape):
+            if l_size % t_size != 0:
+                raise ValueError(
+                    f"Tile size {tile_size} (dim={t_size}) does not divide latent shape {latent_shape} (dim={l_size}).")
+        if seq_length != num_groups * group_size:
+            raise ValueError(f"Input sequence length {seq_length} does not match low-res info {num_groups}x{group_size}.")
+
+    @torch.no_grad()
+    def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb,
+                 routing_score: torch.Tensor, tau_sparse: float,
+                 lowres_group_info: Optional[LowresGroupInfo] = None,
+                 flex_attn_mask_func: Optional[SlidingTileDescriptor] = None,
+                 window_size: Tuple[int, int, int] = (3, 3, 3), tile_size: Tuple[int, int, int] = (6, 8, 8),
+                 latent_shape: Tuple[int, int, int] = (30, 48, 80)):
+        self._check_input(hidden_states, lowres_group_info, latent_shape, window_size, tile_size)
+        q, k, v, T = self._project(attn, hidden_states, encoder_hidden_states, image_rotary_emb)
+        assert q.shape[0] == 1, f"Batch size {q.shape[0]} is not supported for {self.__class__.__name__}."
+        te = self._text_valid(attention_mask, q.shape[2] - T, flex_attn_mask_func)
+        if SP_STATE.enabled:
+            from ._sp import sp_attention
+            buf = sp_attention(q, k, v, T, routing_score, tau_sparse, model="hunyuan", text_valid=te,
+                               lowres_group_info=lowres_group_info, window_size=window_size, tile_size=tile_size,
+                               latent_shape=latent_shape)
+            return self._output(attn, buf, T)
+        geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
+                            lowres_group_info.reduction_rate, q.device)
+        # top-1 / tau dispatch on the device: no torch.nonzero host sync (hunyuan.py:612-640)
+        _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+        buf, out = self._new_out(q)
+        routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,
+                         text_valid=te, out=out)
+        return self._output(attn, buf, T)
+
+
+class HunyuanVideoFlashAttnProcessorTripleTrain(HunyuanVideoFlashAttnProcessorTripleEval):
+    """Training-time soft mixture of the three experts (hunyuan.py:241-513): OUT OF SCOPE of this build
+    (training only).  `use_original_attn=True` (the dense teacher) is served."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb,
+                 use_original_attn: bool = False, **kwargs):
+        if use_original_attn:
+            return HunyuanVideoFlashAttnProcessor.__call__(self, attn, hidden_states, encoder_hidden_states,
+                                                           attention_mask, image_rotary_emb)
+        raise NotImplementedError("the soft-mixture training forward is outside the inference hot path of this build")

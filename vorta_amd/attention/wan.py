@@ -1,0 +1,146 @@
+"""Wan-2.1 attention processors (video-only self attention + separate cross attention).
+
+Same classes, call protocol and keyword names as vorta/attention/wan.py.  Only self attention is routed
+(modeling_wan.py:215-229); cross attention and `use_original_attn` go through the dense kernel.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from .. import ops
+from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention
+from ..ulysses import SP_STATE, shrink_dim
+from .coreset_select import LowresGroupInfo
+from .sliding_tile import SlidingTileDescriptor
+
+
+def apply_rotary_emb(hidden_states: torch.Tensor, freqs: torch.Tensor) -> torch.Tensor:
+    """complex rotation in float64, as the reference does it (wan.py:34-37); before the attention boundary."""
+    x = torch.view_as_complex(hidden_states.to(torch.float64).unflatten(3, (-1, 2)))
+    return torch.view_as_real(x * freqs).flatten(3, 4).type_as(hidden_states)
+
+
+class WanAttnProcessor2_0:
+    """Dense attention (wan.py:40-160): self, text cross (Sq != Skv) and the optional I2V image branch."""
+
+    def __init__(self):
+        ops._C.lib()  # no fallback: fail now if the HIP library is missing
+
+    def _input_proj(self, attn, hidden_states, encoder_hidden_states=None, rotary_emb=None):
+        """wan.py:64-101: q/k/v projections, RMSNorm across heads (before the head split), RoPE."""
+        enc_img = None
+        if attn.add_k_proj is not None:
+            enc_img = encoder_hidden_states[:, :257]
+            encoder_hidden_states = encoder_hidden_states[:, 257:]
+        if encoder_hidden_states is None:
+            encoder_hidden_states = hidden_states
+        q = attn.to_q(hidden_states)
+        k = attn.to_k(encoder_hidden_states)
+        v = attn.to_v(encoder_hidden_states)
+        if attn.norm_q is not None:
+            q = attn.norm_q(q)
+        if attn.norm_k is not None:
+            k = attn.norm_k(k)
+        q, k, v = (x.unflatten(2, (attn.heads, -1)).transpose(1, 2) for x in (q, k, v))
+        if rotary_emb is not None:
+            rotary_emb = shrink_dim(rotary_emb, dim=2)
+            q, k = apply_rotary_emb(q, rotary_emb), apply_rotary_emb(k, rotary_emb)
+        return q, k, v, enc_img
+
+    @staticmethod
+    def _new_out(q: torch.Tensor):
+        B, H, N, D = q.shape
+        buf = torch.empty((B, N, H, D), dtype=q.dtype, device=q.device)
+        return buf, buf.permute(0, 2, 1, 3)
+
+    def _attn(self, attn, q, k, v, enc_img, is_cross_attn: bool):
+        """wan.py:103-149 without SP (the SP branch lives in _sp.py). Returns (B,S,H,D) buffers."""
+        buf_img = None
+        if enc_img is not None:
+            k_img = attn.norm_added_k(attn.add_k_proj(enc_img)).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+            v_img = attn.add_v_proj(enc_img).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+            buf_img, out_img = self._new_out(q)
+            for b in range(q.shape[0]):
+                dense_attention(q[b:b + 1], k_img[b:b + 1], v_img[b:b + 1], out=out_img[b:b + 1])
+        buf, out = self._new_out(q)
+        for b in range(q.shape[0]):
+            dense_attention(q[b:b + 1], k[b:b + 1], v[b:b + 1], out=out[b:b + 1])
+        return buf, buf_img
+
+    @staticmethod
+    def _output_proj(attn, buf, buf_img=None):
+        hidden = buf.flatten(2, 3)
+        if buf_img is not None:
+            hidden = hidden + buf_img.flatten(2, 3)
+        return attn.to_out[1](attn.to_out[0](hidden))
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, rotary_emb=None):
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is always None on this path (wan.py:141)")
+        is_cross = encoder_hidden_states is not None
+        q, k, v, enc_img = self._input_proj(attn, hidden_states, encoder_hidden_states, rotary_emb)
+        if SP_STATE.enabled:
+            from ._sp import sp_wan_dense
+            return self._output_proj(attn, *sp_wan_dense(self, attn, q, k, v, enc_img, is_cross))
+        return self._output_proj(attn, *self._attn(attn, q, k, v, enc_img, is_cross))
+
+
+class WanAttnProcessorTripleEval(WanAttnProcessor2_0):
+    """Inference-time routed self attention (wan.py:303-437)."""
+
+    def __init__(self, check_input: bool = False):
+        super().__init__()
+        self.check_input = check_input
+
+    def _check_input(self, hidden_states, lowres_group_info, latent_shape, window_size, tile_size):
+        """wan.py:168-193."""
+        if not self.check_input:
+            return
+        seq_length = hidden_states.shape[1] * SP_STATE.sp_size
+        num_groups = lowres_group_info.center_indices.shape[0]
+        group_size = lowres_group_info.center_indices.shape[1] + lowres_group_info.margin_indices.shape[1]
+        if seq_length != latent_shape[0] * latent_shape[1] * latent_shape[2]:
+            raise ValueError(f"Input sequence length {seq_length} does not match latent shape {latent_shape}.")
+        for t_size, l_size in zip(tile_size, latent_shape):
+            if l_size % t_size != 0:
+                raise ValueError(
+                    f"Tile size {tile_size} (dim={t_size}) does not divide latent shape {latent_shape} (dim={l_size}).")
+        if seq_length != num_groups * group_size:
+            raise ValueError(f"Input sequence length {seq_length} does not match low-res info {num_groups}x{group_size}.")
+
+    @torch.no_grad()
+    def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask, rotary_emb,
+                 tau_sparse: float, routing_score: torch.Tensor,
+                 lowres_group_info: Optional[LowresGroupInfo] = None,
+                 flex_attn_mask_func: Optional[SlidingTileDescriptor] = None,
+                 window_size: Tuple[int, int, int] = (3, 3, 3), tile_size: Tuple[int, int, int] = (6, 8, 8),
+                 latent_shape: Tuple[int, int, int] = (20, 30, 52), use_original_attn: bool = False):
+        if encoder_hidden_states is not None or use_original_attn:
+            return WanAttnProcessor2_0.__call__(self, attn, hidden_states, encoder_hidden_states, attention_mask,
+                                                rotary_emb)
+        self._check_input(hidden_states, lowres_group_info, latent_shape, window_size, tile_size)
+        q, k, v, _ = self._input_proj(attn, hidden_states, None, rotary_emb)
+        assert q.shape[0] == 1, "routed attention runs one batch item per call (pipeline_wan.py:322-344 does CFG as two)"
+        if SP_STATE.enabled:
+            from ._sp import sp_attention
+            buf = sp_attention(q, k, v, 0, routing_score, tau_sparse, model="wan", lowres_group_info=lowres_group_info,
+                               window_size=window_size, tile_size=tile_size, latent_shape=latent_shape)
+            return self._output_proj(attn, buf)
+        geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
+                            lowres_group_info.reduction_rate, q.device)
+        _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+        buf, out = self._new_out(q)
+        routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="wan", out=out)
+        return self._output_proj(attn, buf)
+
+
+class WanAttnProcessorTripleTrain(WanAttnProcessorTripleEval):
+    """Soft-mixture training forward (wan.py:163-300): OUT OF SCOPE (training only); the dense teacher
+    (`use_original_attn=True`) and cross attention are served."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, rotary_emb=None,
+                 use_original_attn: bool = False, **kwargs):
+        if encoder_hidden_states is not None or use_original_attn:
+            return WanAttnProcessor2_0.__call__(self, attn, hidden_states, encoder_hidden_states, attention_mask,
+                                                rotary_emb)
+        raise NotImplementedError("the soft-mixture training forward is outside the inference hot path of this build")

@@ -118,14 +118,15 @@ __global__ __launch_bounds__(64) void route_scores_kernel(const RParams p) {
 
 extern "C" int vorta_route_scores(const vorta_router_args* a, void* hip_stream) {
   if (!a || a->struct_size != sizeof(vorta_router_args)) return VORTA_EINVAL;
-  if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
+  if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16 && a->dtype != VORTA_FP32) return VORTA_EUNSUPPORTED;
   if (a->batch <= 0 || a->heads <= 0 || a->heads > 1024 || a->n_experts <= 0 || a->n_experts > 64) return VORTA_EINVAL;
   if (!a->scores || !a->expert_of_head || !a->head_lists || !a->head_counts) return VORTA_EINVAL;
   RParams p{nullptr, nullptr, nullptr, a->batch, 0, a->heads, a->n_experts, a->tau,
             a->scores, a->expert_of_head, a->head_lists, a->head_counts, nullptr};
   hipStream_t st = (hipStream_t)hip_stream;
   if (a->dtype == VORTA_BF16) hipLaunchKernelGGL(route_scores_kernel<__bf16>, dim3(1), dim3(64), 0, st, p);
-  else hipLaunchKernelGGL(route_scores_kernel<_Float16>, dim3(1), dim3(64), 0, st, p);
+  else if (a->dtype == VORTA_FP16) hipLaunchKernelGGL(route_scores_kernel<_Float16>, dim3(1), dim3(64), 0, st, p);
+  else hipLaunchKernelGGL(route_scores_kernel<float>, dim3(1), dim3(64), 0, st, p);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
 }

@@ -234,8 +234,8 @@ def route_scores(scores: torch.Tensor, tau: float):
     """vorta_route_scores: top-1 / tau dispatch of an existing (B,H,E) score tensor (batch item 0 routes).
     Returns (expert_of_head (H,), head_lists (E,H), head_counts (E,)) on device, no host sync."""
     _require_gpu(scores)
-    if scores.dtype not in _DT:
-        scores = scores.to(torch.bfloat16)
+    if scores.dtype not in _DT and scores.dtype != torch.float32:
+        scores = scores.float()
     scores = scores.contiguous()
     B, H, E = scores.shape
     dev = scores.device
@@ -244,7 +244,7 @@ def route_scores(scores: torch.Tensor, tau: float):
     counts = torch.empty(E, dtype=torch.int32, device=dev)
     a = _C.RouterArgs()
     a.struct_size = C.sizeof(_C.RouterArgs)
-    a.dtype = _DT[scores.dtype]
+    a.dtype = _DT.get(scores.dtype, 2)  # 2 = VORTA_FP32 (accepted by vorta_route_scores only)
     a.batch, a.embed_dim, a.heads, a.n_experts = B, 0, H, E
     a.tau = tau
     a.scores, a.expert_of_head = scores.data_ptr(), expert.data_ptr()

@@ -175,3 +175,17 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, kv_val
     ops.attn_fwd(ops.fold_heads(q), ops.fold_heads(k), ops.fold_heads(v), ops.fold_heads(out), n_q=Sq,
                  n_kv=Skv if kv_valid is None else kv_valid, q_valid=Sq if q_valid is None else q_valid, scale=scale)
     return out
+
+
+_GEOMETRY_CACHE: Dict[tuple, RoutedGeometry] = {}
+
+
+def geometry_for(latent, tile, window, group, rate, device, row_map: Optional[torch.Tensor] = None) -> RoutedGeometry:
+    """Process-wide cache: the tables are built once per geometry, not once per layer call."""
+    key = (tuple(latent), tuple(tile), tuple(window), tuple(group), float(rate), str(device),
+           None if row_map is None else (row_map.data_ptr(), row_map.numel()))
+    g = _GEOMETRY_CACHE.get(key)
+    if g is None:
+        g = RoutedGeometry(latent, tile, window, group, rate, torch.device(device), row_map=row_map)
+        _GEOMETRY_CACHE[key] = g
+    return g
