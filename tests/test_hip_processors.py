@@ -108,10 +108,12 @@ def test_wan_check_input_and_cross_attention(golden):
     y1 = proc(attn, hidden, enc, None, None, tau_sparse=0.3, routing_score=None, **_wan_kwargs())
     y2 = WanAttnProcessor2_0()(attn, hidden, enc, None, None)
     assert torch.equal(y1, y2)
-    q, k, v, _ = proc._input_proj(attn, hidden, enc, None)
-    ref = O.dense_attention(q.double().cpu().numpy(), k.double().cpu().numpy(), v.double().cpu().numpy())
-    ref = torch.tensor(ref).permute(0, 2, 1, 3).flatten(2, 3).to(dtype).to(dev())
-    want = attn.to_out[0](ref)
+    with torch.no_grad():
+        q, k, v, _ = proc._input_proj(attn, hidden, enc, None)
+        ref = O.dense_attention(q.double().cpu().numpy(), k.double().cpu().numpy(), v.double().cpu().numpy())
+        ref = torch.tensor(ref).permute(0, 2, 1, 3).flatten(2, 3).to(dtype).to(dev())
+        want = attn.to_out[0](ref)
+    y2 = y2.detach()
     assert rel_fro(y2.float().cpu().numpy(), want.float().cpu().numpy()) < 1e-2
 
 
@@ -144,8 +146,10 @@ def _f64(t):
     return t.detach().double().cpu().numpy()
 
 
-def _hy_reference(attn, hidden, enc, rope, experts, T, te, dual):
-    """float64 restatement of hunyuan.py:544-608 with the oracle as the attention core."""
+def _hy_reference(attn, hidden, enc, rope, experts, T, te, dual, qkv=None):
+    """float64 restatement of hunyuan.py:544-608 with the oracle as the attention core.  With `qkv` given the
+    attention runs on exactly those (already rounded) q,k,v, so coreset rankings cannot differ by rounding; the
+    projections are then checked separately (returned as the third value)."""
     def lin(m, x):
         return x @ _f64(m.weight).T + _f64(m.bias)
 
@@ -176,13 +180,16 @@ def _hy_reference(attn, hidden, enc, rope, experts, T, te, dual):
         q = np.concatenate([rot(q[:, :, :S]), q[:, :, S:]], 2)
         k = np.concatenate([rot(k[:, :, :S]), k[:, :, S:]], 2)
     gi = O.group_info(LATENT, GROUP, 0.5)
+    projected = (q, k, v)
+    if qkv is not None:
+        q, k, v = (_f64(x) for x in qkv)
     o = O.routed_attention(q, k, v, np.asarray(experts), model="hunyuan", latent=LATENT, tile=TILE, window=WINDOW,
                            gi=gi, t_text=T, t_eff=te)
     o = o.transpose(0, 2, 1, 3).reshape(1, S + T, H * 128)
     hid, en = o[:, :S], o[:, S:]
     if dual:
         hid, en = lin(attn.to_out[0], hid), lin(attn.to_add_out, en)
-    return hid, en
+    return hid, en, projected
 
 
 @pytest.mark.parametrize("dual", [True, False])
@@ -208,9 +215,13 @@ def test_hunyuan_triple_eval_vs_oracle(dual):
               flex_attn_mask_func=create_sliding_tile_attn_mask_func(LATENT, WINDOW, TILE, T, te, dev()))
     proc = HunyuanVideoFlashAttnProcessorTripleEval(check_input=True)
     hid, en = proc(attn, hidden, enc, mask, rope, routing_score=score, tau_sparse=0.3, **kw)
-    ref_h, ref_e = _hy_reference(attn, hidden, enc, rope, experts, T, te, dual)
+    with torch.no_grad():
+        qkv = proc._project(attn, hidden, enc, rope)[:3]
+    ref_h, ref_e, projected = _hy_reference(attn, hidden, enc, rope, experts, T, te, dual, qkv=qkv)
+    for got, want in zip(qkv, projected):  # steps 1-4: projections, qk-norm, RoPE, text concat (bf16 vs float64)
+        assert rel_fro(got.float().cpu().numpy(), want) < 1e-2
     assert hid.shape == ref_h.shape and en.shape == ref_e.shape
-    assert rel_fro(hid.float().cpu().numpy(), ref_h) < 2.5e-2 and rel_fro(en.float().cpu().numpy(), ref_e) < 2.5e-2
+    assert rel_fro(hid.float().cpu().numpy(), ref_h) < 1.5e-2 and rel_fro(en.float().cpu().numpy(), ref_e) < 1.5e-2
     if not dual:  # no output projection: padded text rows are exactly zero (hunyuan.py:176)
         assert torch.all(en[:, te:] == 0)
     # without the descriptor the text length is read from the mask (like hunyuan.py:169) and nothing changes
@@ -221,8 +232,8 @@ def test_hunyuan_triple_eval_vs_oracle(dual):
     hid3, en3 = proc(attn, hidden, enc, mask, rope, routing_score=score, tau_sparse=0.95, **kw)
     hid4, en4 = HunyuanVideoFlashAttnProcessor()(attn, hidden, enc, mask, rope)
     assert torch.equal(hid3, hid4) and torch.equal(en3, en4)
-    ref_h, ref_e = _hy_reference(attn, hidden, enc, rope, [0] * H, T, te, dual)
-    assert rel_fro(hid4.float().cpu().numpy(), ref_h) < 2.5e-2
+    ref_h, ref_e, _ = _hy_reference(attn, hidden, enc, rope, [0] * H, T, te, dual, qkv=qkv)
+    assert rel_fro(hid4.float().cpu().numpy(), ref_h) < 1.5e-2
 
 
 # --------------------------------------------------------------------------------------------- SP rehearsal

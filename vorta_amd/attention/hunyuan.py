@@ -102,6 +102,7 @@ class HunyuanVideoFlashAttnProcessor:
         ops.attn_fwd(q[0], k[0], v[0], out[0], n_q=N, n_kv=N, q_valid=N, n_kv_dev=L, q_valid_dev=L)
         return buf
 
+    @torch.no_grad()  # forward only: the HIP ops have no backward (training is out of scope)
     def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb):
         q, k, v, T = self._project(attn, hidden_states, encoder_hidden_states, image_rotary_emb)
         return self._output(attn, self._dense(q, k, v, attention_mask, T), T)

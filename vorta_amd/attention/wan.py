@@ -74,6 +74,7 @@ class WanAttnProcessor2_0:
             hidden = hidden + buf_img.flatten(2, 3)
         return attn.to_out[1](attn.to_out[0](hidden))
 
+    @torch.no_grad()  # forward only: the HIP ops have no backward (training is out of scope)
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, rotary_emb=None):
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is always None on this path (wan.py:141)")
