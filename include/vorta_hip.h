@@ -96,6 +96,9 @@ typedef struct vorta_attn_args {
    * effective n_kv = clamp(*n_kv_dev, 1, n_kv), effective q_valid = min(*q_valid_dev, q_valid) */
   const int32_t* n_kv_dev;
   const int32_t* q_valid_dev;
+  int32_t variant; /* 256-row workgroups: 0/1 = 8 waves x 32 rows (attn_fwd_kernel<T,8>), 2 = 4 waves x 64 rows
+                      (attn_fwd_w64_kernel<T>); ignored for 128-row workgroups */
+  int32_t reserved;
 } vorta_attn_args;
 
 int vorta_attn_fwd(const vorta_attn_args* args, void* hip_stream);

@@ -34,6 +34,7 @@ class AttnArgs(C.Structure):
         ("scale", _f32), ("block_rows", _i32), ("n_splits", _i32),
         ("ws_o", _vp), ("ws_ml", _vp),
         ("n_kv_dev", _vp), ("q_valid_dev", _vp),
+        ("variant", _i32), ("reserved", _i32),
     ]
 
 

@@ -1,0 +1,72 @@
+// Shared pieces of the gather flash-attention kernels (attn_fwd.hip: 32 query rows per wave, two waves per
+// SIMD; attn_fwd_w64.hip: 64 query rows per wave, one wave per SIMD).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vorta_hip.h"
+#include "common.h"
+
+namespace vorta_attn {
+
+
+constexpr int KVB = 64;            // keys per block
+constexpr int D = 128;             // head dim
+constexpr int ROWB = D * 2;        // bytes per row
+constexpr int TILE_BYTES = KVB * ROWB;  // 16 KiB
+constexpr int BUF_BYTES = 2 * TILE_BYTES;
+
+struct Params {
+  const char* q; const char* k; const char* v; char* o;
+  int64_t q_sh, k_sh, v_sh, o_sh;  // head strides in bytes
+  int64_t q_ss, k_ss, v_ss, o_ss;  // row strides in bytes
+  const int32_t* head_list; const int32_t* n_heads_dev;
+  int n_heads;
+  int n_q, q_group_len, q_row_offset, q_valid;
+  int n_groups, blocks_per_group;
+  const int32_t* q_rows; int64_t q_rows_sh;
+  int n_kv, kv_row_offset;
+  const int32_t* n_kv_dev; const int32_t* q_valid_dev;
+  const int32_t* kv_rows; int64_t kv_rows_sh, kv_rows_sg;
+  const int32_t* dup_rows; int64_t dup_rows_sh; int n_dup_pos, n_dup;
+  float scale_log2;  // scale * log2(e)
+  int n_splits, blocks_per_split;
+  float* ws_o; float* ws_ml;
+};
+
+template <typename T> struct MF;
+template <> struct MF<__bf16> {
+  using v8 = bf16x8; using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ v4 tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS v4*)p);
+  }
+};
+template <> struct MF<_Float16> {
+  using v8 = f16x8; using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ v4 tr(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) __fp16 h4;
+    h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS h4*)p);
+    return *(v4*)&r;
+  }
+};
+
+// v_permlane32_swap(vdst, src) exchanges lanes 32-63 of vdst with lanes 0-31 of src.  Fed the same value
+// twice it returns {low half, low half} and {high half, high half}: combining the two results gives every
+// lane the reduction over itself and its partner lane ^ 32 (the two lanes that share one query row).
+__device__ __forceinline__ float half_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+
+}  // namespace vorta_attn

@@ -36,6 +36,7 @@ class Timeline:
 
 
 _timeline: Optional[Timeline] = None
+DEFAULT_VARIANT = int(__import__("os").environ.get("VORTA_ATTN_VARIANT", "0"))
 
 
 def set_timeline(t: Optional[Timeline]):
@@ -89,7 +90,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
              dup_rows: Optional[torch.Tensor] = None, n_dup_pos: int = 0,
              scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1,
              n_kv_dev: Optional[torch.Tensor] = None, q_valid_dev: Optional[torch.Tensor] = None,
-             tag: str = "", flops: float = 0.0) -> None:
+             variant: int = 0, tag: str = "", flops: float = 0.0) -> None:
     """vorta_attn_fwd (include/vorta_hip.h).  q_rows/kv_rows/dup_rows: int32; a leading head-slot axis is
     optional (2-D q_rows = per head slot, 1-D = shared)."""
     _require_gpu(q, k, v, out)
@@ -124,6 +125,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     a.block_rows = block_rows
     a.n_splits = n_splits
     a.n_kv_dev, a.q_valid_dev = _ptr(n_kv_dev), _ptr(q_valid_dev)
+    a.variant = variant or DEFAULT_VARIANT
     ws = None
     if n_splits > 1:
         so, sm = C.c_uint64(), C.c_uint64()
