@@ -403,20 +403,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
       d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
     }                                                                             \
   }
-#define STAGE(par_, j_)                                                           \
-  /* K(j+2) into the slot K(j) left, V(j+1) into the slot V(j-1) left; then fetch K(j+3), V(j+2) */ \
+#define STAGE_WRITE(par_)                                                         \
+  /* K(j+2) into the slot K(j) left, V(j+1) into the slot V(j-1) left (loaded during the previous step) */ \
   WRITE_K(par_)                                                                   \
   WRITE_V((par_) ^ 1)                                                             \
+  __builtin_amdgcn_sched_barrier(0);
+#define STAGE_LOAD(j_)                                                            \
+  /* fetch K(j+3), V(j+2): issued between the two MFMA phases, landed by the next step's STAGE_WRITE */ \
+  __builtin_amdgcn_sched_barrier(0);                                              \
   LOAD_K()                                                                        \
   LOAD_V()                                                                        \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
-  ROWS_OF(rowK, (j_) + 4)
+  ROWS_OF(rowK, (j_) + 4)                                                         \
+  __builtin_amdgcn_sched_barrier(0);
 
   // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
   // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
   // all visible to the scheduler together.
 #define STEP(c0_, c1_, n0_, n1_, par_, j_)                                        \
   {                                                                               \
+    STAGE_WRITE(par_)                                                             \
     if (wave_active) {                                                            \
       if ((j_) * KVB + KVB > n_kv) {                                              \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
         pb_[2][e_] = (T)c1_[e_];                                                  \
         pb_[3][e_] = (T)c1_[8 + e_];                                              \
       }                                                                           \
-      STAGE(par_, j_)                                                             \
+      STAGE_LOAD(j_)                                                              \
       _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
         _Pragma("unroll") for (int kg_ = 0; kg_ < 4; ++kg_) {                     \
           const V4 lo_ = MF<T>::tr(smem + (par_) * TILE_BYTES + v_rd[dt_] + (16 * kg_) * ROWB); \
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
         }                                                                         \
       }                                                                           \
     } else {                                                                      \
-      STAGE(par_, j_)                                                             \
+      STAGE_LOAD(j_)                                                              \
     }                                                                             \
     __syncthreads();                                                              \
   }
@@ -497,7 +503,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   }
 #undef QK
 #undef STEP
-#undef STAGE
+#undef STAGE_LOAD
+#undef STAGE_WRITE
 #undef ROWS_OF
 #undef LOAD_K
 #undef LOAD_V
