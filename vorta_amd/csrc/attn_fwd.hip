@@ -359,15 +359,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   // K(b) is staged one block ahead of V(b): block b's keys are needed by iteration b-1 (scores are computed
   // one block ahead of the PV product), its values by iteration b.  Rings: K tiles at [0,32K), V at [32K,64K).
   u32x4 kreg[CH], vreg[CH];
-  int64_t rowK[CH], rowV[CH];  // rows of the next K block / next V block to fetch
+  // K / V rows are fetched with buffer loads: wave-uniform descriptor on the head's base, 32-bit byte offset
+  // per lane (row * stride via the full-rate 24-bit multiply) -- no 64-bit address arithmetic in the loop.
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.k + (int64_t)head * p.k_sh), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.v + (int64_t)head * p.v_sh), 0, 0x7fffffff, 0x00020000);
+  const int k_ss32 = (int)p.k_ss, v_ss32 = (int)p.v_ss, lane_col = (tid & 15) * 16;
+  int rowK[CH], rowV[CH];  // rows of the next K block / next V block to fetch
 #define ROWS_OF(dst_, blk_)                                                       \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
     const int pos_ = min((blk_) * KVB + lrow0 + i_ * ROWSTEP, n_kv - 1);          \
-    if constexpr (KVTAB) dst_[i_] = (int64_t)kv_rows[pos_];                       \
-    else dst_[i_] = (int64_t)(p.kv_row_offset + pos_);                            \
+    if constexpr (KVTAB) dst_[i_] = kv_rows[pos_];                                \
+    else dst_[i_] = p.kv_row_offset + pos_;                                       \
   }
-#define LOAD_K() _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) kreg[i_] = *(const u32x4*)(kbase + rowK[i_] * p.k_ss);
-#define LOAD_V() _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) vreg[i_] = *(const u32x4*)(vbase + rowV[i_] * p.v_ss);
+#define LOAD_K() _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) kreg[i_] = __builtin_amdgcn_raw_buffer_load_b128( \
+      k_rsrc, (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + lane_col, 0, 0);
+#define LOAD_V() _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) vreg[i_] = __builtin_amdgcn_raw_buffer_load_b128( \
+      v_rsrc, (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + lane_col, 0, 0);
 #define WRITE_K(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) *(u32x4*)(smem + (par_) * TILE_BYTES + k_wr[i_]) = kreg[i_];
 #define WRITE_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) *(u32x4*)(smem + (par_) * TILE_BYTES + v_wr[i_]) = vreg[i_];
 
@@ -642,6 +651,7 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   if (a->dup_rows && (a->n_dup < 0 || a->n_dup_pos < 0 || a->n_dup_pos > a->n_q)) return VORTA_EINVAL;
   if (a->block_rows != 0 && a->block_rows != 128 && a->block_rows != 256) return VORTA_EINVAL;
   if (a->variant < 0 || a->variant > 3) return VORTA_EINVAL;
+  if (a->variant == 3 && (a->k.stride_s * 2 >= (1 << 24) || a->v.stride_s * 2 >= (1 << 24))) return VORTA_EUNSUPPORTED;
   p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr; p.o = (char*)a->o.ptr;
   p.q_sh = a->q.stride_h * 2; p.k_sh = a->k.stride_h * 2; p.v_sh = a->v.stride_h * 2; p.o_sh = a->o.stride_h * 2;
   p.q_ss = a->q.stride_s * 2; p.k_ss = a->k.stride_s * 2; p.v_ss = a->v.stride_s * 2; p.o_ss = a->o.stride_s * 2;
