@@ -212,23 +212,24 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     tokens = S * cfg["fwd_per_step"]
 
-    # ---- roofline of the dominant kernel: attn_fwd_kernel<T,8> (256-row workgroups: full + coreset + text) ----
-    summ = tl.summary()
-    dom = {k: v for k, v in summ.items() if k[1] == 256}
-    dom_ms = sum(v["ms"] for v in dom.values())
-    dom_fl = sum(v["flops"] for v in dom.values())
-    dom_n = sum(v["launches"] for v in dom.values())
-    if P > 1:
-        dom_fl = dom_fl  # per-rank launches carry per-rank flops
-    achieved = dom_fl / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": f"attn_fwd_kernel<{'_Float16' if dt == torch.float16 else '__bf16'},8>",
+    # ---- roofline of the dominant kernel symbol (largest share of the timed region) ----
+    summ = tl.summary()  # keyed by (expert tag, kernel symbol)
+    by_kernel = {}
+    for (tag, sym), v in summ.items():
+        d = by_kernel.setdefault(sym, dict(ms=0.0, flops=0.0, launches=0))
+        d["ms"] += v["ms"]; d["flops"] += v["flops"]; d["launches"] += v["launches"]
+    dom_sym = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+    dom = by_kernel[dom_sym]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": dom_sym,
                 "achieved": round(achieved, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
-                "launches": dom_n, "avg_launch_ms": round(dom_ms / max(dom_n, 1), 4),
-                "flops_per_launch": dom_fl / max(dom_n, 1)}
-    per_tag = {f"{k[0]}@{k[1]}": {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
-                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0}
-               for k, v in sorted(summ.items())}
+                "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
+                "share_of_step": round(dom["ms"] / (ms_per_step * args.steps), 3)}
+    per_tag = {f"{tag}: {sym}": {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
+                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0}
+               for (tag, sym), v in sorted(summ.items())}
 
     res = {
         "metric": "video_tokens_per_sec (routed-attention denoising step, HunyuanVideo 720p 129f)"

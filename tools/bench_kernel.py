@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--block_rows", type=int, default=0)
     ap.add_argument("--sdpa", action="store_true")
-    ap.add_argument("--variants", default="1,2")
+    ap.add_argument("--variants", default="1,2")  # 1 plain, 2 pipelined
     ap.add_argument("--rounds", type=int, default=1)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -41,7 +41,7 @@ def main():
     flops = 4.0 * a.S * a.S * 128 * a.H
     for rnd in range(a.rounds):
         for br in ([a.block_rows] if a.block_rows else [256, 128]):
-            for var in ([int(x) for x in a.variants.split(",")] if br == 256 else [1]):
+            for var in [int(x) for x in a.variants.split(",")]:
                 ms = timeit(lambda: ops.attn_fwd(q, k, v, o, n_q=a.S, n_kv=a.S, block_rows=br, variant=var), a.iters)
                 print(f"vorta_attn_fwd S={a.S} H={a.H} {a.dtype} block_rows={br} variant={var}: {ms:.3f} ms  "
                       f"{flops/ms/1e9:.1f} TFLOP/s", flush=True)

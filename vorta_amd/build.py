@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libvorta_hip.so")
-SOURCES = ["api.hip", "attn_fwd.hip", "attn_fwd_w64.hip", "coreset.hip", "sta_tables.hip", "router.hip"]
+SOURCES = ["api.hip", "attn_fwd.hip", "coreset.hip", "sta_tables.hip", "router.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
          "-Wno-unused-result"]
 
@@ -23,13 +23,15 @@ def _newer(src, dst):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = os.environ.get("VORTA_EXTRA_FLAGS", "").split()  # experiments only (e.g. -DVORTA_SCHED=1)
+    force = force or bool(extra)
     deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(INCLUDE, "vorta_hip.h")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print("[vorta_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

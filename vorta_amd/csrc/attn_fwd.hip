@@ -19,10 +19,6 @@
 
 #include "attn_common.h"
 
-namespace vorta_attn {
-template <typename T> int launch_w64(const Params& p, hipStream_t st);  // attn_fwd_w64.hip
-}
-
 namespace {
 using namespace vorta_attn;
 
@@ -426,6 +422,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   ROWS_OF(rowK, (j_) + 4)                                                         \
   __builtin_amdgcn_sched_barrier(0);
 
+#ifndef VORTA_SCHED
+#define VORTA_SCHED 0
+#endif
+#if VORTA_SCHED == 1
+  // QK phase: per MFMA gap 2 exp + 4 plain VALU + 2 LDS reads; PV phase: per gap 2 VALU + 2 LDS reads
+#define SCHED_RECIPE()                                                            \
+  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
+  }
+#else
+#define SCHED_RECIPE()
+#endif
+
   // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
   // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
   // all visible to the scheduler together.
@@ -478,6 +490,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
           o[dt_] = MF<T>::mfma(vf_, pb_[kg_], o[dt_]);                            \
         }                                                                         \
       }                                                                           \
+      SCHED_RECIPE()                                                              \
     } else {                                                                      \
       STAGE_LOAD(j_)                                                              \
     }                                                                             \
@@ -605,16 +618,13 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const Params p) {
 }
 
 template <typename T, int NW>
-int launch(const Params& p, hipStream_t st, bool w64 = false, bool pipe = false) {
+int launch(const Params& p, hipStream_t st, bool pipe) {
   const int64_t n_qb = (int64_t)p.n_groups * p.blocks_per_group;
   const int64_t total = n_qb * p.n_heads * p.n_splits;
   if (total <= 0) return VORTA_OK;
   if (total > 0x7fffffff) return VORTA_EINVAL;
   hipError_t e;
-  if (w64) {
-    int rc = vorta_attn::launch_w64<T>(p, st);
-    if (rc != VORTA_OK) return rc;
-  } else if (pipe) {
+  if (pipe) {
     if (p.kv_rows) hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, true>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
     else hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, false>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
     e = hipGetLastError();
@@ -650,8 +660,8 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   if (a->q_group_len < 0 || a->q_valid < 0) return VORTA_EINVAL;
   if (a->dup_rows && (a->n_dup < 0 || a->n_dup_pos < 0 || a->n_dup_pos > a->n_q)) return VORTA_EINVAL;
   if (a->block_rows != 0 && a->block_rows != 128 && a->block_rows != 256) return VORTA_EINVAL;
-  if (a->variant < 0 || a->variant > 3) return VORTA_EINVAL;
-  if (a->variant == 3 && (a->k.stride_s * 2 >= (1 << 24) || a->v.stride_s * 2 >= (1 << 24))) return VORTA_EUNSUPPORTED;
+  if (a->variant < 0 || a->variant > 2) return VORTA_EINVAL;
+  if (a->variant != 1 && (a->k.stride_s * 2 >= (1 << 24) || a->v.stride_s * 2 >= (1 << 24))) return VORTA_EUNSUPPORTED;
   p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr; p.o = (char*)a->o.ptr;
   p.q_sh = a->q.stride_h * 2; p.k_sh = a->k.stride_h * 2; p.v_sh = a->v.stride_h * 2; p.o_sh = a->o.stride_h * 2;
   p.q_ss = a->q.stride_s * 2; p.k_ss = a->k.stride_s * 2; p.v_ss = a->v.stride_s * 2; p.o_ss = a->o.stride_s * 2;
@@ -691,12 +701,17 @@ extern "C" int vorta_attn_workspace_bytes(const vorta_attn_args* a, uint64_t* ws
   return VORTA_OK;
 }
 
-extern "C" int vorta_attn_plan(const vorta_attn_args* a, int32_t* block_rows_out, int64_t* n_workgroups_out) {
+extern "C" int vorta_attn_plan(const vorta_attn_args* a, int32_t* block_rows_out, int64_t* n_workgroups_out,
+                               int32_t* kernel_id_out) {
   Params p{};
   int block_rows = 0;
   int rc = fill_params(a, p, block_rows);
   if (rc != VORTA_OK) return rc;
   if (block_rows_out) *block_rows_out = block_rows;
+  if (kernel_id_out) {
+    const bool pipe = block_rows == 256 ? (a->variant != 1) : (a->variant == 2);
+    *kernel_id_out = (block_rows == 256 ? 8 : 4) * 16 + (pipe ? 1 : 0) + ((pipe && a->kv_rows) ? 2 : 0);
+  }
   if (n_workgroups_out) *n_workgroups_out = (int64_t)p.n_groups * p.blocks_per_group * p.n_heads * (p.n_heads ? p.n_splits : 0);
   return VORTA_OK;
 }
@@ -708,9 +723,10 @@ extern "C" int vorta_attn_fwd(const vorta_attn_args* a, void* hip_stream) {
   if (rc != VORTA_OK) return rc;
   if (p.n_heads == 0 || p.n_groups == 0) return VORTA_OK;
   hipStream_t st = (hipStream_t)hip_stream;
-  const bool w64 = block_rows == 256 && a->variant == 2;
-  const bool pipe = a->variant == 3;
+  // variant 0 (auto): 256-row workgroups run the software-pipelined kernel, 128-row ones the plain kernel
+  // (the pipelined body needs 4 more staging registers per thread at 4 waves and spills there)
+  const bool pipe = block_rows == 256 ? (a->variant != 1) : (a->variant == 2);
   if (a->dtype == VORTA_BF16)
-    return block_rows == 256 ? launch<__bf16, 8>(p, st, w64, pipe) : launch<__bf16, 4>(p, st, false, pipe);
-  return block_rows == 256 ? launch<_Float16, 8>(p, st, w64, pipe) : launch<_Float16, 4>(p, st, false, pipe);
+    return block_rows == 256 ? launch<__bf16, 8>(p, st, pipe) : launch<__bf16, 4>(p, st, pipe);
+  return block_rows == 256 ? launch<_Float16, 8>(p, st, pipe) : launch<_Float16, 4>(p, st, pipe);
 }

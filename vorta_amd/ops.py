@@ -21,7 +21,7 @@ class Timeline:
     Events are recorded on the stream the kernels are launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []  # (tag, block_rows, n_workgroups, flops, start_event, end_event)
+        self.records = []  # (tag, kernel symbol, n_workgroups, flops, start_event, end_event)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -134,13 +134,17 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
               torch.empty(sm.value // 4, dtype=torch.float32, device=q.device))
         a.ws_o, a.ws_ml = ws[0].data_ptr(), ws[1].data_ptr()
     if _timeline is not None:
-        br, nwg = C.c_int32(), C.c_int64()
-        _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg)), "vorta_attn_plan")
+        br, nwg, kid = C.c_int32(), C.c_int64(), C.c_int32()
+        _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg), C.byref(kid)), "vorta_attn_plan")
+        tname = "_Float16" if q.dtype == torch.float16 else "__bf16"
+        nw, kk = kid.value // 16, kid.value % 16
+        sym = (f"attn_fwd_pipe_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>" if kk & 1
+               else f"attn_fwd_kernel<{tname},{nw}>")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
         e1.record()
-        _timeline.records.append((tag, br.value, nwg.value, flops, e0, e1))
+        _timeline.records.append((tag, sym, nwg.value, flops, e0, e1))
         return
     _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
     # `ws` may be released now: the caching allocator is stream ordered and the launch is on this stream
