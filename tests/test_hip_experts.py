@@ -287,3 +287,93 @@ def test_zero_copy_ulysses_layout_on_one_gpu(model):
     rm = lay.row_map.long()
     for i, h in enumerate(local_heads):
         assert torch.equal(ov[i][rm], ref[0, h]), (i, h)
+
+
+def test_concurrent_expert_streams_give_identical_output():
+    """The three experts on forked HIP streams write disjoint heads: bit-identical to the serial order."""
+    from vorta_amd.routed import HeadRouting, routed_attention
+    dtype = torch.float16
+    torch.manual_seed(31)
+    H, T, te = 6, 16, 11
+    q, k, v = (torch.randn((1, H, S + T, 128), device=dev()).to(dtype) for _ in range(3))
+    route = HeadRouting.from_expert_ids([2, 0, 1, 1, 2, 0], dev())
+    geom = _geom()
+    a = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=T, text_valid=te)
+    b = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=T, text_valid=te, concurrent=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------- full-size properties
+HY_LATENT, HY_TILE, HY_GROUP = (33, 45, 80), (11, 9, 8), (3, 3, 2)
+
+
+def test_full_size_sliding_properties():
+    """BASELINE config 3 geometry (S = 118 800, T = 256/96), one head: size-independent properties of the
+    sliding-tile expert -- constant V is reproduced, padded text rows are zero, keys outside a query tile's
+    window cannot influence it (bitwise), and sampled rows match the oracle on the kernel's own key lists."""
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.float16
+    Sf, T, te = 33 * 45 * 80, 256, 96
+    gen = torch.Generator().manual_seed(7)
+    q = torch.randn((1, 1, Sf + T, 128), generator=gen).to(dtype).to(dev())
+    k = torch.randn((1, 1, Sf + T, 128), generator=gen).to(dtype).to(dev())
+    v = torch.randn((1, 1, Sf + T, 128), generator=gen).to(dtype).to(dev())
+    geom = RoutedGeometry(HY_LATENT, HY_TILE, WINDOW, HY_GROUP, 0.5, dev())
+    route = HeadRouting.from_expert_ids([2], dev())
+    const = torch.randn((1, 1, 1, 128), generator=gen).to(dtype).to(dev())
+    out = routed_attention(q, k, const.expand(1, 1, Sf + T, 128).contiguous(), route, geom, model="hunyuan",
+                           text_len=T, text_valid=te)
+    assert (out[0, 0, :Sf + te].float() - const[0, 0].float()).abs().max().item() <= 4e-3
+    assert torch.all(out[0, 0, Sf + te:] == 0)
+    out = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=T, text_valid=te)
+    # tokens of the last h-tile (h >= 36) are outside the window of query tiles with h < 9
+    hh = (torch.arange(Sf, device=dev()) // 80) % 45
+    far, near = hh >= 36, hh < 9
+    k2, v2 = k.clone(), v.clone()
+    k2[0, 0, :Sf][far] = 3.0
+    v2[0, 0, :Sf][far] = -5.0
+    out2 = routed_attention(q, k2, v2, route, geom, model="hunyuan", text_len=T, text_valid=te)
+    assert torch.equal(out[0, 0, :Sf][near], out2[0, 0, :Sf][near])
+    assert not torch.equal(out[0, 0, :Sf][far], out2[0, 0, :Sf][far])
+    # sampled queries vs the oracle, keys taken from the table the kernel used (bit-exact vs the reference mask
+    # at small sizes: test_sta_tables_match_reference_mask)
+    q_rows, kv_rows, n_kv = geom.sta_tables(te)
+    pos = torch.randint(0, Sf, (48,), generator=gen)
+    qr = q_rows.cpu()[pos].long()
+    for i in range(0, 48, 8):
+        tile_id = int(pos[i]) // geom.tok
+        keys = kv_rows[tile_id].long()
+        ref = O.dense_attention(q[0, 0, qr[i]:qr[i] + 1].double().cpu().numpy(), k[0, 0, keys].double().cpu().numpy(),
+                                v[0, 0, keys].double().cpu().numpy())
+        got = out[0, 0, qr[i]].float().cpu().numpy()
+        assert np.abs(got - ref[0]).max() <= 2.5e-3
+
+
+def test_full_size_coreset_properties():
+    """Coreset expert at S = 118 800: constant V reproduced on every token, every dropped margin carries its
+    centre's output bit for bit, keep + drop lists partition the sequence, padded text rows are zero."""
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.float16
+    Sf, T, te = 33 * 45 * 80, 256, 96
+    gen = torch.Generator().manual_seed(8)
+    q = torch.randn((1, 1, Sf + T, 128), generator=gen).to(dtype).to(dev())
+    k = torch.randn((1, 1, Sf + T, 128), generator=gen).to(dtype).to(dev())
+    v = torch.randn((1, 1, Sf + T, 128), generator=gen).to(dtype).to(dev())
+    geom = RoutedGeometry(HY_LATENT, HY_TILE, WINDOW, HY_GROUP, 0.5, dev())
+    route = HeadRouting.from_expert_ids([1], dev())
+    const = torch.randn((1, 1, 1, 128), generator=gen).to(dtype).to(dev())
+    out = routed_attention(q, k, const.expand(1, 1, Sf + T, 128).contiguous(), route, geom, model="hunyuan",
+                           text_len=T, text_valid=te)
+    assert (out[0, 0, :Sf + te].float() - const[0, 0].float()).abs().max().item() <= 4e-3
+    assert torch.all(out[0, 0, Sf + te:] == 0)
+    out = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=T, text_valid=te)
+    keep, drop = ops.coreset_select(q[0], HY_LATENT, HY_GROUP, geom.n_keep, tail_first=Sf, n_tail=T)
+    G = geom.G
+    centres = keep[0, :G].long()
+    assert torch.equal(out[0, 0][drop[0].long()], out[0, 0][centres][:, None].expand(-1, drop.shape[-1], -1))
+    allrows = torch.cat([keep[0, :geom.S_low], drop[0].reshape(-1)]).long().sort().values
+    assert torch.equal(allrows, torch.arange(Sf, device=dev()))
+    assert geom.S_low == Sf // 2 and keep.shape[1] == Sf // 2 + T

@@ -40,11 +40,13 @@ def main():
     o = torch.empty_like(q)
     flops = 4.0 * a.S * a.S * 128 * a.H
     for rnd in range(a.rounds):
+      for remap in (0, 1):
+        ops.NO_XCD_REMAP = remap
         for br in ([a.block_rows] if a.block_rows else [256, 128]):
             for var in [int(x) for x in a.variants.split(",")]:
                 ms = timeit(lambda: ops.attn_fwd(q, k, v, o, n_q=a.S, n_kv=a.S, block_rows=br, variant=var), a.iters)
-                print(f"vorta_attn_fwd S={a.S} H={a.H} {a.dtype} block_rows={br} variant={var}: {ms:.3f} ms  "
-                      f"{flops/ms/1e9:.1f} TFLOP/s", flush=True)
+                print(f"vorta_attn_fwd S={a.S} H={a.H} {a.dtype} block_rows={br} variant={var} no_xcd_remap={remap}: "
+                      f"{ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s", flush=True)
     if a.sdpa:
         import torch.nn.functional as F
         q4, k4, v4 = q[None], k[None], v[None]

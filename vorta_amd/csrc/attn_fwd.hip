@@ -36,9 +36,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
   // ---- work decomposition (XCD-aware: consecutive logical ids share an XCD's L2) ----
   const int nwg = gridDim.x;
   int wg;
-  {
+  if (p.xcd_remap) {
     const int b = blockIdx.x, xcd = b & 7, qd = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
+  } else {
+    wg = blockIdx.x;
   }
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
@@ -293,9 +295,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   // ---- work decomposition (XCD-aware: consecutive logical ids share an XCD's L2) ----
   const int nwg = gridDim.x;
   int wg;
-  {
+  if (p.xcd_remap) {
     const int b = blockIdx.x, xcd = b & 7, qd = nwg >> 3, r = nwg & 7;
     wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
+  } else {
+    wg = blockIdx.x;
   }
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
@@ -675,14 +679,16 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   p.dup_rows = a->dup_rows; p.dup_rows_sh = a->dup_rows_stride_h; p.n_dup_pos = a->n_dup_pos; p.n_dup = a->n_dup;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.n_splits = a->n_splits; p.ws_o = a->ws_o; p.ws_ml = a->ws_ml;
+  p.xcd_remap = a->reserved == 0 ? 1 : 0;  // experiment knob (reserved = 1 disables the remap)
   p.n_groups = (p.n_q + p.q_group_len - 1) / p.q_group_len;
   block_rows = a->block_rows;
   if (block_rows == 0) {
-    // 256-row workgroups halve the L2->LDS key traffic; 128-row ones waste less on short groups
+    // 256-row workgroups run the pipelined kernel (measured ~1.24x the 128-row kernel per row); a group that
+    // does not fill its last workgroup wastes CU time in proportion to the padding, so compare
+    //   rate256 * g / roundup(g,256)   with   rate128 * g / roundup(g,128)
     const int g = p.q_group_len;
-    const int waste256 = ((g + 255) / 256) * 256 - g, waste128 = ((g + 127) / 128) * 128 - g;
-    block_rows = (waste256 * 8 > g && waste128 < waste256) ? 128 : 256;
-    if (g <= 128) block_rows = 128;
+    const int64_t pad256 = ((g + 255) / 256) * 256, pad128 = ((g + 127) / 128) * 128;
+    block_rows = (pad256 * 100 > pad128 * 124) ? 128 : 256;
   }
   p.blocks_per_group = (p.q_group_len + block_rows - 1) / block_rows;
   const int nblk = (p.n_kv + KVB - 1) / KVB;

@@ -37,6 +37,7 @@ class Timeline:
 
 _timeline: Optional[Timeline] = None
 DEFAULT_VARIANT = int(__import__("os").environ.get("VORTA_ATTN_VARIANT", "0"))
+NO_XCD_REMAP = int(__import__("os").environ.get("VORTA_NO_XCD_REMAP", "0"))
 
 
 def set_timeline(t: Optional[Timeline]):
@@ -126,6 +127,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     a.n_splits = n_splits
     a.n_kv_dev, a.q_valid_dev = _ptr(n_kv_dev), _ptr(q_valid_dev)
     a.variant = variant or DEFAULT_VARIANT
+    a.reserved = NO_XCD_REMAP
     ws = None
     if n_splits > 1:
         so, sm = C.c_uint64(), C.c_uint64()

@@ -97,12 +97,27 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
     return max(1, min(want, kv_blocks // 8 if kv_blocks >= 16 else 1, 256))
 
 
+_SIDE_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
+
+
+def _side_streams(device: torch.device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _SIDE_STREAMS[idx]
+
+
 def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing: HeadRouting,
                      geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
-                     out: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, scale: Optional[float] = None,
+                     concurrent: bool = False) -> torch.Tensor:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
-    hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383."""
+    hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383.
+
+    concurrent=True enqueues the coreset and sliding-tile experts on two side HIP streams (forked from and joined
+    back into the current stream with events): the experts are independent, so the tail of one launch (a few
+    hundred workgroups on 256 CUs when only H/P heads are local) is filled by the next expert's workgroups."""
     if q.dim() == 4 and q.shape[0] != 1:
         # hunyuan.py:168 asserts batch 1; Wan's CFG runs two batch-1 forwards (pipeline_wan.py:322-344)
         raise AssertionError(f"Batch size {q.shape[0]} is not supported by routed_attention.")
@@ -124,19 +139,19 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         return routing.counts_host[e] if routing.counts_host is not None else 0
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
-    if live(0):
+    def expert_full():
         ops.attn_fwd(q3, k3, v3, o3, n_q=S + T, n_kv=S + te, q_valid=S + te, scale=scale, tag="full",
                      q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
                      flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H))
 
     # ---- expert 1: coreset attention (hunyuan.py:410-457 / wan.py:243-270) ----
-    if live(1):
+    def expert_lowres():
         sl = routing.slot_args(1, H)
         keep_q, drop_q = ops.coreset_select(q3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T,
-                                            row_map=geom.row_map, **sl)
+                                            row_map=rm, **sl)
         if hy:  # K matched on its own, V follows K (hunyuan.py:433-438)
             keep_k, _ = ops.coreset_select(k3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=te,
-                                           row_map=geom.row_map, want_drop=False, **sl)
+                                           row_map=rm, want_drop=False, **sl)
         else:   # K and V follow Q's matching (wan.py:250-255)
             keep_k = keep_q
         ops.attn_fwd(q3, k3, v3, o3, n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te,
@@ -144,7 +159,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                      flops=nheads(1) * 4.0 * (geom.S_low + te) ** 2 * D, **sl)
 
     # ---- expert 2: sliding-tile attention (hunyuan.py:459-507 / wan.py:272-294) ----
-    if live(2):
+    def expert_sliding():
         sl = routing.slot_args(2, H)
         q_rows, kv_rows, n_kv = geom.sta_tables(te)
         ops.attn_fwd(q3, k3, v3, o3, n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
@@ -152,16 +167,39 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                      flops=nheads(2) * 4.0 * D * S * n_kv, **sl)
         if T > 0:
             # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
-            nh = sl["n_heads"]
+            nsp = _auto_splits(sl["n_heads"], T, S + te)
             if rm is None:
                 ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te, scale=scale,
-                             n_splits=_auto_splits(nh, T, S + te), tag="sliding_text",
-                             flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
+                             n_splits=nsp, tag="sliding_text", flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
             else:
-                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_rows=rm[S:S + T], q_valid=te, n_kv=S + te,
-                             kv_rows=rm[:S + te], scale=scale,
-                             n_splits=_auto_splits(nh, T, S + te), tag="sliding_text",
+                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_rows=rm[S:S + T], q_valid=te, n_kv=S + te, kv_rows=rm[:S + te],
+                             scale=scale, n_splits=nsp, tag="sliding_text",
                              flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
+
+    experts = [(expert_full, live(0)), (expert_lowres, live(1)), (expert_sliding, live(2))]
+    if not concurrent:
+        for fn, on in experts:
+            if on:
+                fn()
+        return out
+    # the experts are independent: fork them onto side streams, join before returning (so every later use of
+    # q,k,v,out on the current stream is ordered after them)
+    cur = torch.cuda.current_stream(q.device)
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    streams = (None,) + _side_streams(q.device)
+    for (fn, on), st in zip(experts, streams):
+        if not on:
+            continue
+        if st is None:
+            fn()
+            continue
+        st.wait_event(fork)
+        with torch.cuda.stream(st):
+            fn()
+            done = torch.cuda.Event()
+            done.record(st)
+        cur.wait_event(done)
     return out
 
 
