@@ -233,6 +233,15 @@ def main():
                 "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                 "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                 "share_of_step": round(dom["ms"] / (ms_per_step * args.steps), 3)}
+    # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself);
+    # only valid for the workload they were collected on
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        if pmc["workload"] == f"{args.config} {args.mix} {cfg['dtype']}" and world == 1:
+            roofline["traffic"] = round(pmc["kernels"][dom_sym]["hbm_bytes_per_launch"])
+            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)"
+    except Exception:
+        pass
     per_tag = {f"{tag}: {sym}": {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0}
                for (tag, sym), v in sorted(summ.items())}
