@@ -122,9 +122,9 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"])
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--experts", default="auto", choices=["auto", "serial", "concurrent"],
-                    help="one stream, or coreset/sliding experts on side HIP streams (auto: concurrent only for "
-                         ">= 4 GPUs, where a launch holds H/P heads and its tail is a large share)")
+    ap.add_argument("--experts", default="fused", choices=["fused", "serial", "concurrent"],
+                    help="fused: the experts of a layer as ONE grid (vorta_attn_fwd_batch); serial: one launch per "
+                         "expert on one stream; concurrent: experts on side HIP streams")
     args = ap.parse_args()
 
     cfg = dict(CONFIGS[args.config])
@@ -159,7 +159,7 @@ def main():
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
     P = world
-    concurrent = args.experts == "concurrent" or (args.experts == "auto" and world >= 4)
+    concurrent, fused = args.experts == "concurrent", args.experts == "fused"
 
     # ---- per-layer routing (and, for P>1, the head -> rank placement that balances expert cost) ----
     layer_ids = [layer_experts(cfg, args.mix, l) for l in range(L)]
@@ -184,11 +184,11 @@ def main():
                 for l in range(L):
                     q, k, v = sets[l % len(sets)]
                     routed_attention(q, k, v, routings[l], geom, model=cfg["model"], text_len=T, text_valid=te, out=out,
-                                     concurrent=concurrent)
+                                     concurrent=concurrent, fused=fused)
     else:
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
-                                            concurrent=concurrent)
+                                            concurrent=concurrent, fused=fused)
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):
@@ -257,7 +257,8 @@ def main():
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
                    "parallelism": "single GPU" if P == 1 else f"ulysses sp{P} (RCCL send/recv over xGMI)",
-                   "experts": "concurrent streams" if concurrent else "one stream",
+                   "experts": {"fused": "one fused grid per layer", "serial": "one launch per expert",
+                               "concurrent": "experts on side streams"}[args.experts],
                    "step_algorithmic_pflop": round(step_flops / 1e15, 3),
                    "step_tflops_per_gpu": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world, 1)},
         "roofline": roofline,

@@ -102,6 +102,11 @@ typedef struct vorta_attn_args {
 } vorta_attn_args;
 
 int vorta_attn_fwd(const vorta_attn_args* args, void* hip_stream);
+/* Up to 4 launches fused into ONE grid (the experts of a routed layer, hunyuan.py:564-591): workgroups are
+ * dispatched in argument order -- pass the longest key loops first -- so one expert's tail is filled by the next
+ * expert instead of idling until a kernel boundary.  Every entry must resolve to the 256-row pipelined kernel
+ * (VORTA_EUNSUPPORTED otherwise: launch those separately); split-key entries get their merge kernels after. */
+int vorta_attn_fwd_batch(const vorta_attn_args* args, int32_t n, void* hip_stream);
 /* the launch shape vorta_attn_fwd would use: query rows per workgroup (128 -> kernel attn_fwd_kernel<T,4>,
  * 256 -> attn_fwd_kernel<T,8>) and the number of workgroups; pure host computation */
 int vorta_attn_plan(const vorta_attn_args* args, int32_t* block_rows, int64_t* n_workgroups, int32_t* kernel_id);

@@ -377,3 +377,36 @@ def test_full_size_coreset_properties():
     allrows = torch.cat([keep[0, :geom.S_low], drop[0].reshape(-1)]).long().sort().values
     assert torch.equal(allrows, torch.arange(Sf, device=dev()))
     assert geom.S_low == Sf // 2 and keep.shape[1] == Sf // 2 + T
+
+
+def test_fused_layer_launch_matches_separate_launches():
+    """All experts of a layer as ONE grid (vorta_attn_fwd_batch) vs one launch per expert: bit-identical."""
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.bfloat16
+    torch.manual_seed(41)
+    latent, tile, group = (8, 12, 16), (4, 6, 8), (2, 3, 2)
+    Sx, H, T, te = 8 * 12 * 16, 6, 256, 200
+    q, k, v = (torch.randn((1, H, Sx + T, 128), device=dev()).to(dtype) for _ in range(3))
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
+    route = HeadRouting.from_expert_ids([0, 1, 2, 2, 0, 1], dev())
+    tl = ops.Timeline()
+    ops.set_timeline(tl)
+    try:
+        a = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=T, text_valid=te, fused=True)
+    finally:
+        ops.set_timeline(None)
+    assert [r[1] for r in tl.records] == ["attn_fwd_multi_kernel<__bf16>"]  # really one grid
+    b = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=T, text_valid=te, fused=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    gi = O.group_info(latent, group, 0.5)
+    ref = O.routed_attention(rounded(q.float().cpu().numpy(), dtype), rounded(k.float().cpu().numpy(), dtype),
+                             rounded(v.float().cpu().numpy(), dtype), np.array([0, 1, 2, 2, 0, 1]), model="hunyuan",
+                             latent=latent, tile=tile, window=WINDOW, gi=gi, t_text=T, t_eff=te)
+    check(a[0], ref[0], dtype)
+    # device-resident routing through the fused grid as well
+    _, lists, counts = ops.route_scores(torch.eye(3, device=dev())[torch.tensor([0, 1, 2, 2, 0, 1])][None], 0.3)
+    c = routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,
+                         text_valid=te)
+    assert torch.equal(a, c)

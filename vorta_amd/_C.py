@@ -71,6 +71,7 @@ class RouterArgs(C.Structure):
 # every symbol include/vorta_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "vorta_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "vorta_attn_fwd_batch": (C.c_int, [C.POINTER(AttnArgs), _i32, _vp]),
     "vorta_attn_plan": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),
     "vorta_attn_workspace_bytes": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vorta_coreset_select": (C.c_int, [C.POINTER(CoresetArgs), _vp]),

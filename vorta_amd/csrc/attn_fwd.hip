@@ -282,25 +282,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
 // QK(j+1) are independent of the softmax of block j, so the wave has matrix work to issue while its VALU
 // is busy, and the two waves of a SIMD no longer need to be in opposite phases to overlap.
 template <typename T, int NW, bool KVTAB>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params p) {
+__device__ __forceinline__ void attn_pipe_body(const Params& p, char* __restrict__ smem, const int wg) {
   using V8 = typename MF<T>::v8;
   using V4 = typename MF<T>::v4;
   constexpr int NT = NW * 64;
   constexpr int QB = NW * 32;
   constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
   constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
-
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
-
-  // ---- work decomposition (XCD-aware: consecutive logical ids share an XCD's L2) ----
-  const int nwg = gridDim.x;
-  int wg;
-  if (p.xcd_remap) {
-    const int b = blockIdx.x, xcd = b & 7, qd = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
-  } else {
-    wg = blockIdx.x;
-  }
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
@@ -587,6 +575,45 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
 }
 
 
+template <typename T, int NW, bool KVTAB>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+  // XCD-aware work order: consecutive logical ids (same head, neighbouring query blocks) share an XCD's L2
+  const int nwg = gridDim.x;
+  int wg;
+  if (p.xcd_remap) {
+    const int b = blockIdx.x, xcd = b & 7, qd = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
+  } else {
+    wg = blockIdx.x;
+  }
+  attn_pipe_body<T, NW, KVTAB>(p, smem, wg);
+}
+
+// Several launches of the pipelined kernel fused into ONE grid (the experts of a routed layer).  Workgroups
+// are dispatched in segment order, longest key loops first, so the tail of one expert (a launch holds only a
+// few waves of workgroups per CU-set, fewer still under sequence parallelism) is filled by the next expert's
+// workgroups instead of idling until a kernel boundary.  No XCD chunking here: with segments of different
+// cost, dealing consecutive workgroups round-robin over the XCDs keeps the chip balanced.
+constexpr int MAX_SEGMENTS = 4;
+struct MultiParams {
+  Params seg[MAX_SEGMENTS];
+  int start[MAX_SEGMENTS + 1];  // first workgroup of each segment; start[n] = grid size
+  int n;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParams mp) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+  const int b = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
+  const Params& p = mp.seg[s];
+  if (p.kv_rows) attn_pipe_body<T, 8, true>(p, smem, b - mp.start[s]);
+  else attn_pipe_body<T, 8, false>(p, smem, b - mp.start[s]);
+}
+
 // Merge the split-key partials: one wave per (head slot, query position).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const Params p) {
@@ -719,6 +746,54 @@ extern "C" int vorta_attn_plan(const vorta_attn_args* a, int32_t* block_rows_out
     *kernel_id_out = (block_rows == 256 ? 8 : 4) * 16 + (pipe ? 1 : 0) + ((pipe && a->kv_rows) ? 2 : 0);
   }
   if (n_workgroups_out) *n_workgroups_out = (int64_t)p.n_groups * p.blocks_per_group * p.n_heads * (p.n_heads ? p.n_splits : 0);
+  return VORTA_OK;
+}
+
+extern "C" int vorta_attn_fwd_batch(const vorta_attn_args* args, int32_t n, void* hip_stream) {
+  if (!args || n < 0 || n > MAX_SEGMENTS) return VORTA_EINVAL;
+  MultiParams mp{};
+  int64_t total = 0;
+  int dtype = -1, m = 0;
+  const vorta_attn_args* live[MAX_SEGMENTS];
+  for (int i = 0; i < n; ++i) {
+    Params p{};
+    int block_rows = 0;
+    int rc = fill_params(&args[i], p, block_rows);
+    if (rc != VORTA_OK) return rc;
+    if (p.n_heads == 0 || p.n_groups == 0) continue;
+    // only launches that resolve to the 256-row pipelined kernel can share a grid
+    if (block_rows != 256 || args[i].variant == 1) return VORTA_EUNSUPPORTED;
+    if (dtype >= 0 && dtype != args[i].dtype) return VORTA_EINVAL;
+    dtype = args[i].dtype;
+    p.xcd_remap = 0;
+    mp.seg[m] = p;
+    mp.start[m] = (int)total;
+    live[m] = &args[i];
+    total += (int64_t)p.n_groups * p.blocks_per_group * p.n_heads * p.n_splits;
+    if (total > 0x7fffffff) return VORTA_EINVAL;
+    ++m;
+  }
+  if (m == 0) return VORTA_OK;
+  for (int i = m; i <= MAX_SEGMENTS; ++i) mp.start[i] = (int)total;
+  mp.n = m;
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (dtype == VORTA_BF16) hipLaunchKernelGGL((attn_fwd_multi_kernel<__bf16>), dim3((unsigned)total), dim3(512), 0, st, mp);
+  else hipLaunchKernelGGL((attn_fwd_multi_kernel<_Float16>), dim3((unsigned)total), dim3(512), 0, st, mp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vorta_set_hip_error(e);
+  for (int i = 0; i < m; ++i) {
+    const Params& p = mp.seg[i];
+    if (p.n_splits > 1) {
+      const int64_t items = (int64_t)p.n_heads * p.n_q;
+      if (dtype == VORTA_BF16)
+        hipLaunchKernelGGL((attn_combine_kernel<__bf16>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
+      else
+        hipLaunchKernelGGL((attn_combine_kernel<_Float16>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, p);
+      e = hipGetLastError();
+      if (e != hipSuccess) return vorta_set_hip_error(e);
+    }
+  }
+  (void)live;
   return VORTA_OK;
 }
 

@@ -81,19 +81,18 @@ def fold_heads(x: torch.Tensor) -> torch.Tensor:
     return x.as_strided((B * H, S, D), (x.stride(1), x.stride(2), x.stride(3)), x.storage_offset())
 
 
-def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *,
-             n_q: int, n_kv: int,
-             head_list: Optional[torch.Tensor] = None, n_heads: Optional[int] = None,
-             n_heads_dev: Optional[torch.Tensor] = None,
-             q_group_len: int = 0, q_row_offset: int = 0, q_valid: Optional[int] = None,
-             q_rows: Optional[torch.Tensor] = None,
-             kv_row_offset: int = 0, kv_rows: Optional[torch.Tensor] = None, kv_rows_stride_g: int = 0,
-             dup_rows: Optional[torch.Tensor] = None, n_dup_pos: int = 0,
-             scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1,
-             n_kv_dev: Optional[torch.Tensor] = None, q_valid_dev: Optional[torch.Tensor] = None,
-             variant: int = 0, tag: str = "", flops: float = 0.0) -> None:
-    """vorta_attn_fwd (include/vorta_hip.h).  q_rows/kv_rows/dup_rows: int32; a leading head-slot axis is
-    optional (2-D q_rows = per head slot, 1-D = shared)."""
+def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *,
+               n_q: int, n_kv: int,
+               head_list: Optional[torch.Tensor] = None, n_heads: Optional[int] = None,
+               n_heads_dev: Optional[torch.Tensor] = None,
+               q_group_len: int = 0, q_row_offset: int = 0, q_valid: Optional[int] = None,
+               q_rows: Optional[torch.Tensor] = None,
+               kv_row_offset: int = 0, kv_rows: Optional[torch.Tensor] = None, kv_rows_stride_g: int = 0,
+               dup_rows: Optional[torch.Tensor] = None, n_dup_pos: int = 0,
+               scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1,
+               n_kv_dev: Optional[torch.Tensor] = None, q_valid_dev: Optional[torch.Tensor] = None,
+               variant: int = 0, tag: str = "", flops: float = 0.0):
+    """Fill a vorta_attn_args; returns (args, workspace tensors to keep alive until the launch is enqueued)."""
     _require_gpu(q, k, v, out)
     if q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype == out.dtype):
         raise ValueError("q,k,v,out must share dtype bf16 or fp16")
@@ -135,21 +134,73 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
         ws = (torch.empty(so.value // 4, dtype=torch.float32, device=q.device),
               torch.empty(sm.value // 4, dtype=torch.float32, device=q.device))
         a.ws_o, a.ws_ml = ws[0].data_ptr(), ws[1].data_ptr()
+    return a, ws
+
+
+def _plan(a) -> Tuple[int, int, str]:
+    br, nwg, kid = C.c_int32(), C.c_int64(), C.c_int32()
+    _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg), C.byref(kid)), "vorta_attn_plan")
+    tname = "_Float16" if a.dtype == _C.VORTA_FP16 else "__bf16"
+    nw, kk = kid.value // 16, kid.value % 16
+    sym = (f"attn_fwd_pipe_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>" if kk & 1
+           else f"attn_fwd_kernel<{tname},{nw}>")
+    return br.value, nwg.value, sym
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, tag: str = "",
+             flops: float = 0.0, **kw) -> None:
+    """vorta_attn_fwd (include/vorta_hip.h); keyword arguments as `_attn_args`.  q_rows/kv_rows/dup_rows: int32; a
+    leading head-slot axis is optional (2-D q_rows = per head slot, 1-D = shared)."""
+    a, ws = _attn_args(q, k, v, out, **kw)
     if _timeline is not None:
-        br, nwg, kid = C.c_int32(), C.c_int64(), C.c_int32()
-        _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg), C.byref(kid)), "vorta_attn_plan")
-        tname = "_Float16" if q.dtype == torch.float16 else "__bf16"
-        nw, kk = kid.value // 16, kid.value % 16
-        sym = (f"attn_fwd_pipe_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>" if kk & 1
-               else f"attn_fwd_kernel<{tname},{nw}>")
+        _, nwg, sym = _plan(a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
         e1.record()
-        _timeline.records.append((tag, sym, nwg.value, flops, e0, e1))
+        _timeline.records.append((tag, sym, nwg, flops, e0, e1))
         return
     _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
     # `ws` may be released now: the caching allocator is stream ordered and the launch is on this stream
+
+
+def attn_fwd_batch(calls) -> None:
+    """vorta_attn_fwd_batch: `calls` is a list of dicts of attn_fwd arguments (q,k,v,out + keywords, optional tag /
+    flops).  Launches that all resolve to the 256-row pipelined kernel are fused into one grid, in list order
+    (put the longest key loops first); otherwise they are launched one by one."""
+    built = []
+    for c in calls:
+        c = dict(c)
+        tag, flops = c.pop("tag", ""), c.pop("flops", 0.0)
+        q, k, v, out = c.pop("q"), c.pop("k"), c.pop("v"), c.pop("out")
+        a, ws = _attn_args(q, k, v, out, **c)
+        built.append((a, ws, tag, flops))
+    if not built:
+        return
+    fusable = 1 < len(built) <= 4 and all(_plan(a)[0] == 256 and a.variant != 1 for a, _, _, _ in built)
+    if not fusable:
+        for a, ws, tag, flops in built:
+            if _timeline is not None:
+                _, nwg, sym = _plan(a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+                e1.record()
+                _timeline.records.append((tag, sym, nwg, flops, e0, e1))
+            else:
+                _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+        return
+    arr = (_C.AttnArgs * len(built))(*[a for a, _, _, _ in built])
+    if _timeline is not None:
+        tname = "_Float16" if built[0][0].dtype == _C.VORTA_FP16 else "__bf16"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _C.check(_C.lib().vorta_attn_fwd_batch(arr, len(built), _stream()), "vorta_attn_fwd_batch")
+        e1.record()
+        _timeline.records.append(("+".join(t for _, _, t, _ in built), f"attn_fwd_multi_kernel<{tname}>",
+                                  sum(_plan(a)[1] for a, _, _, _ in built), sum(f for _, _, _, f in built), e0, e1))
+        return
+    _C.check(_C.lib().vorta_attn_fwd_batch(arr, len(built), _stream()), "vorta_attn_fwd_batch")
 
 
 def coreset_select(x: torch.Tensor, latent: Sequence[int], group: Sequence[int], n_keep: int, *,

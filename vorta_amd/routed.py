@@ -110,12 +110,14 @@ def _side_streams(device: torch.device):
 def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing: HeadRouting,
                      geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
                      out: Optional[torch.Tensor] = None, scale: Optional[float] = None,
-                     concurrent: bool = False) -> torch.Tensor:
+                     concurrent: bool = False, fused: bool = True) -> torch.Tensor:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
     hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383.
 
-    concurrent=True enqueues the coreset and sliding-tile experts on two side HIP streams (forked from and joined
+    fused=True (default) submits the experts' attention launches as ONE grid (vorta_attn_fwd_batch): workgroups of
+    the full expert first, then coreset, then sliding tile, so each expert's tail is filled by the next one.
+    concurrent=True instead enqueues the coreset and sliding-tile experts on two side HIP streams (forked from and joined
     back into the current stream with events): the experts are independent, so the tail of one launch (a few
     hundred workgroups on 256 CUs when only H/P heads are local) is filled by the next expert's workgroups."""
     if q.dim() == 4 and q.shape[0] != 1:
@@ -138,11 +140,13 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     def nheads(e):  # for the algorithmic-work tags only
         return routing.counts_host[e] if routing.counts_host is not None else 0
 
+    base = dict(q=q3, k=k3, v=v3, out=o3, scale=scale)
+
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     def expert_full():
-        ops.attn_fwd(q3, k3, v3, o3, n_q=S + T, n_kv=S + te, q_valid=S + te, scale=scale, tag="full",
+        return [dict(base, n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full",
                      q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
-                     flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H))
+                     flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H))]
 
     # ---- expert 1: coreset attention (hunyuan.py:410-457 / wan.py:243-270) ----
     def expert_lowres():
@@ -154,33 +158,39 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                                            row_map=rm, want_drop=False, **sl)
         else:   # K and V follow Q's matching (wan.py:250-255)
             keep_k = keep_q
-        ops.attn_fwd(q3, k3, v3, o3, n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te,
-                     q_rows=keep_q, kv_rows=keep_k, dup_rows=drop_q, n_dup_pos=geom.G, scale=scale, tag="lowres",
-                     flops=nheads(1) * 4.0 * (geom.S_low + te) ** 2 * D, **sl)
+        return [dict(base, n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te, q_rows=keep_q,
+                     kv_rows=keep_k, dup_rows=drop_q, n_dup_pos=geom.G, tag="lowres",
+                     flops=nheads(1) * 4.0 * (geom.S_low + te) ** 2 * D, **sl)]
 
     # ---- expert 2: sliding-tile attention (hunyuan.py:459-507 / wan.py:272-294) ----
     def expert_sliding():
         sl = routing.slot_args(2, H)
         q_rows, kv_rows, n_kv = geom.sta_tables(te)
-        ops.attn_fwd(q3, k3, v3, o3, n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
-                     kv_rows_stride_g=n_kv, scale=scale, tag="sliding",
-                     flops=nheads(2) * 4.0 * D * S * n_kv, **sl)
+        calls = [dict(base, n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
+                      kv_rows_stride_g=n_kv, tag="sliding", flops=nheads(2) * 4.0 * D * S * n_kv, **sl)]
         if T > 0:
             # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
-            nsp = _auto_splits(sl["n_heads"], T, S + te)
+            txt = dict(base, n_q=T, q_valid=te, n_kv=S + te, n_splits=_auto_splits(sl["n_heads"], T, S + te),
+                       tag="sliding_text", flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
             if rm is None:
-                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te, scale=scale,
-                             n_splits=nsp, tag="sliding_text", flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
+                txt.update(q_row_offset=S)
             else:
-                ops.attn_fwd(q3, k3, v3, o3, n_q=T, q_rows=rm[S:S + T], q_valid=te, n_kv=S + te, kv_rows=rm[:S + te],
-                             scale=scale, n_splits=nsp, tag="sliding_text",
-                             flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
+                txt.update(q_rows=rm[S:S + T], kv_rows=rm[:S + te])
+            calls.append(txt)
+        return calls
+
+    def launch(calls):
+        for c in calls:
+            c = dict(c)
+            ops.attn_fwd(c.pop("q"), c.pop("k"), c.pop("v"), c.pop("out"), **c)
 
     experts = [(expert_full, live(0)), (expert_lowres, live(1)), (expert_sliding, live(2))]
     if not concurrent:
-        for fn, on in experts:
-            if on:
-                fn()
+        calls = [c for fn, on in experts if on for c in fn()]
+        if fused:
+            ops.attn_fwd_batch(calls)
+        else:
+            launch(calls)
         return out
     # the experts are independent: fork them onto side streams, join before returning (so every later use of
     # q,k,v,out on the current stream is ordered after them)
@@ -192,11 +202,11 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         if not on:
             continue
         if st is None:
-            fn()
+            launch(fn())
             continue
         st.wait_event(fork)
         with torch.cuda.stream(st):
-            fn()
+            launch(fn())
             done = torch.cuda.Event()
             done.record(st)
         cur.wait_event(done)

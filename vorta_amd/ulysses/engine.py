@@ -163,12 +163,12 @@ class UlyssesRoutedAttention:
     heads (zero-copy layout) -> gather_heads.  Also the template for the attention processors under SP."""
 
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
-                 rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False):
+                 rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True):
         from ..routed import HeadRouting, RoutedGeometry
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
         self.cfg, self.P, self.rank = cfg, P, rank
-        self.concurrent = concurrent
+        self.concurrent, self.fused = concurrent, fused
         self.te = cfg["text_valid"]
         self.lay = UlyssesLayout(H, S, T, 128, P, rank, device, dtype, group)
         self.geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"],
@@ -200,5 +200,5 @@ class UlyssesRoutedAttention:
         self.lay.scatter_heads(shards, self.bufs[:3], order, texts)
         q, k, v, o = (self.lay.head_view(b) for b in self.bufs)
         routed_attention(q, k, v, self.routes[l], self.geom, model=self.cfg["model"], text_len=self.cfg["text"],
-                         text_valid=self.te, out=o, concurrent=self.concurrent)
+                         text_valid=self.te, out=o, concurrent=self.concurrent, fused=self.fused)
         self.lay.gather_heads(self.bufs[3], self.out_shard, order, self.out_text)
