@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"])
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sliding-block-rows", type=int, default=0, choices=[0, 128, 256],
+                    help="query rows per workgroup of the sliding-tile launch (0 = library heuristic; 256 lets it join "
+                         "the fused grid)")
     ap.add_argument("--experts", default="fused", choices=["fused", "serial", "concurrent"],
                     help="fused: the experts of a layer as ONE grid (vorta_attn_fwd_batch); serial: one launch per "
                          "expert on one stream; concurrent: experts on side HIP streams")
@@ -184,11 +187,11 @@ def main():
                 for l in range(L):
                     q, k, v = sets[l % len(sets)]
                     routed_attention(q, k, v, routings[l], geom, model=cfg["model"], text_len=T, text_valid=te, out=out,
-                                     concurrent=concurrent, fused=fused)
+                                     concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows)
     else:
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
-                                            concurrent=concurrent, fused=fused)
+                                            concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows)
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):

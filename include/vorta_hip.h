@@ -96,8 +96,8 @@ typedef struct vorta_attn_args {
    * effective n_kv = clamp(*n_kv_dev, 1, n_kv), effective q_valid = min(*q_valid_dev, q_valid) */
   const int32_t* n_kv_dev;
   const int32_t* q_valid_dev;
-  int32_t variant; /* kernel body: 0 = auto, 1 = plain (attn_fwd_kernel<T,NW>), 2 = software-pipelined, scores one
-                      key block ahead (attn_fwd_pipe_kernel<T,NW,KVTAB>); auto = 2 for 256-row workgroups */
+  int32_t variant; /* kernel body: 0 = auto = 2; 1 = plain (attn_fwd_kernel<T,NW>), 2 = software-pipelined, scores one
+                      key block ahead, K/V tiles by LDS-DMA (attn_fwd_pipe_kernel<T,NW,KVTAB,DMA>) */
   int32_t reserved;
 } vorta_attn_args;
 
@@ -111,7 +111,7 @@ int vorta_attn_fwd_batch(const vorta_attn_args* args, int32_t n, void* hip_strea
  * 256 -> attn_fwd_kernel<T,8>) and the number of workgroups; pure host computation */
 int vorta_attn_plan(const vorta_attn_args* args, int32_t* block_rows, int64_t* n_workgroups, int32_t* kernel_id);
 /* kernel_id = waves*16 + (pipelined ? 1 : 0) + (pipelined with kv table ? 2 : 0):
- *   attn_fwd_kernel<T,NW> (plain) or attn_fwd_pipe_kernel<T,NW,KVTAB> */
+ *   attn_fwd_kernel<T,NW> (plain) or attn_fwd_pipe_kernel<T,NW,KVTAB,DMA> */
 /* bytes of ws_o and ws_ml for a given launch (0,0 when n_splits <= 1) */
 int vorta_attn_workspace_bytes(const vorta_attn_args* args, uint64_t* ws_o_bytes, uint64_t* ws_ml_bytes);
 

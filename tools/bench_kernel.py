@@ -40,7 +40,7 @@ def main():
     o = torch.empty_like(q)
     flops = 4.0 * a.S * a.S * 128 * a.H
     for rnd in range(a.rounds):
-      for remap in (0, 1):
+      for remap in (0,):
         ops.NO_XCD_REMAP = remap
         for br in ([a.block_rows] if a.block_rows else [256, 128]):
             for var in [int(x) for x in a.variants.split(",")]:

@@ -576,6 +576,282 @@ __device__ __forceinline__ void attn_pipe_body(const Params& p, char* __restrict
 
 
 template <typename T, int NW, bool KVTAB>
+__device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __restrict__ smem, const int wg) {
+  using V8 = typename MF<T>::v8;
+  using V4 = typename MF<T>::v4;
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
+  constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
+  const int sp = wg % p.n_splits;
+  const int rest = wg / p.n_splits;
+  const int n_qb = p.n_groups * p.blocks_per_group;
+  const int qb = rest % n_qb;
+  const int y = rest / n_qb;
+  if (p.n_heads_dev && y >= *p.n_heads_dev) return;
+  const int head = p.head_list ? p.head_list[y] : y;
+  const int grp = qb / p.blocks_per_group;
+  const int bi = qb - grp * p.blocks_per_group;
+  const int p0 = grp * p.q_group_len + bi * QB;
+  const int pend = min((grp + 1) * p.q_group_len, p.n_q);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31;
+  const int hh = lane >> 5;
+
+  // ---- key block range of this split (n_kv / q_valid may live on the device: no host sync) ----
+  const int n_kv = p.n_kv_dev ? max(1, min(*p.n_kv_dev, p.n_kv)) : p.n_kv;
+  const int q_valid = p.q_valid_dev ? min(*p.q_valid_dev, p.q_valid) : p.q_valid;
+  const int nblk_total = (n_kv + KVB - 1) / KVB;
+  const int blk0 = sp * p.blocks_per_split;
+  const int blk1 = min(blk0 + p.blocks_per_split, nblk_total);
+
+  // ---- query rows ----
+  const int wrow0 = p0 + wave * 32;
+  const bool wave_active = wrow0 < pend;  // wave-uniform
+  const int my_p = wrow0 + r32;
+  const bool row_ok = my_p < pend;
+  const int ld_p = min(my_p, pend - 1);
+  const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
+  const int64_t my_row = q_rows ? (int64_t)q_rows[ld_p] : (int64_t)(p.q_row_offset + ld_p);
+
+  V8 qf[8];
+  {
+    const char* qp = p.q + (int64_t)head * p.q_sh + my_row * p.q_ss + hh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const V8*)(qp + ks * 32);
+  }
+
+  // ---- loader setup ----
+  const int32_t* kv_rows =
+      p.kv_rows ? p.kv_rows + (int64_t)y * p.kv_rows_sh + (int64_t)grp * p.kv_rows_sg : nullptr;
+  const char* kbase = p.k + (int64_t)head * p.k_sh + (tid & 15) * 16;
+  const char* vbase = p.v + (int64_t)head * p.v_sh + (tid & 15) * 16;
+  const int lrow0 = tid >> 4;
+  const int lcc = tid & 15;
+  // K / V tiles go global -> LDS directly (buffer_load ... lds): no staging registers, no ds_write.  One wave
+  // instruction fills 1 KiB = 4 tile rows (16 lanes x 16 B per row); the destination is lane-linear, so the
+  // bank swizzles of the tile images are applied on the SOURCE side: the lane that lands in chunk c' of row r
+  // fetches chunk c' ^ swz(r) of that row (same involution the fragment reads apply).
+  // K(b) is staged one block ahead of V(b); rings: K tiles at [0,32K), V at [32K,64K).
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.k + (int64_t)head * p.k_sh), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.v + (int64_t)head * p.v_sh), 0, 0x7fffffff, 0x00020000);
+  const int k_ss32 = (int)p.k_ss, v_ss32 = (int)p.v_ss;
+  int k_col[CH], v_col[CH];  // source byte offset inside the row for this lane's chunk
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int row = 4 * (CH * wave + i) + (lane >> 4);
+    k_col[i] = ((lane & 15) ^ (row & 15)) << 4;
+    v_col[i] = ((lane & 15) ^ ((row & 3) << 2)) << 4;
+  }
+  int rowK[CH], rowV[CH];  // rows of the next K block / next V block to fetch
+#define ROWS_OF(dst_, blk_)                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
+    const int pos_ = min((blk_) * KVB + 4 * (CH * wave + i_) + (lane >> 4), n_kv - 1); \
+    if constexpr (KVTAB) dst_[i_] = kv_rows[pos_];                                \
+    else dst_[i_] = p.kv_row_offset + pos_;                                       \
+  }
+#define DMA_K(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
+      k_rsrc, (LDS_AS void*)(smem + (par_) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                            \
+      (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + k_col[i_], 0, 0, 0);
+#define DMA_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
+      v_rsrc, (LDS_AS void*)(smem + (2 + (par_)) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                      \
+      (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
+
+  // ---- LDS read addresses ----
+  int k_rd[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_rd[ks] = r32 * ROWB + (((2 * ks + hh) ^ (r32 & 15)) << 4);
+  int v_rd[4];
+  {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      v_rd[dt] = 2 * TILE_BYTES + (4 * (g >> 1) + q4) * ROWB + ((dt ^ q4) << 6) + 32 * (g & 1) + 8 * pp;
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale_log2;
+  f32x16 sA0, sA1, sB0, sB1;  // scores of the current / next key block (roles swap every block)
+
+  // scores of a block from the K ring slot `par_` into (d0_, d1_); the tail mask is applied by the consumer
+#define QK(d0_, d1_, par_)                                                        \
+  {                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { d0_[i_] = 0.f; d1_[i_] = 0.f; } \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
+      const V8 k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);        \
+      const V8 k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
+      d0_ = MF<T>::mfma(k0_, qf[ks_], d0_);                                       \
+      d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
+    }                                                                             \
+  }
+  // top of step j: K(j+2) -> the slot K(j) left, V(j+1) -> the slot V(j-1) left; both land before the barrier
+  // that ends the step (the compiler's __syncthreads waits vmcnt(0) first), a whole step of latency cover
+#define STAGE_DMA(par_, j_)                                                       \
+  DMA_K(par_)                                                                     \
+  DMA_V((par_) ^ 1)                                                               \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
+  ROWS_OF(rowK, (j_) + 3)                                                         \
+  __builtin_amdgcn_sched_barrier(0);
+
+#ifndef VORTA_SCHED
+#define VORTA_SCHED 0
+#endif
+#if VORTA_SCHED == 1
+  // QK phase: per MFMA gap 2 exp + 4 plain VALU + 2 LDS reads; PV phase: per gap 2 VALU + 2 LDS reads
+#define SCHED_RECIPE()                                                            \
+  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
+  }
+#else
+#define SCHED_RECIPE()
+#endif
+
+  // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
+  // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
+  // all visible to the scheduler together.
+#define STEP(c0_, c1_, n0_, n1_, par_, j_)                                        \
+  {                                                                               \
+    STAGE_DMA(par_, j_)                                                           \
+    if (wave_active) {                                                            \
+      if ((j_) * KVB + KVB > n_kv) {                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
+          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
+          if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
+          if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
+        }                                                                         \
+      }                                                                           \
+      float mx_ = c0_[0];                                                         \
+      _Pragma("unroll") for (int i_ = 1; i_ < 16; ++i_) mx_ = fmaxf(mx_, c0_[i_]); \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, c1_[i_]); \
+      mx_ = half_max(mx_);                                                        \
+      const float m_new_ = fmaxf(m_run, mx_);                                     \
+      if (!__all(m_new_ == m_run)) {                                              \
+        const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * c);        \
+        _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                       \
+          _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_; \
+        l_run *= alpha_;                                                          \
+        m_run = m_new_;                                                           \
+      }                                                                           \
+      V8 pb_[4];                                                                  \
+      QK(n0_, n1_, (par_) ^ 1) /* block j+1 (harmless garbage past the end) */    \
+      const float mc_ = m_run * c;                                                \
+      float lsum_ = 0.f;                                                          \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
+        c0_[i_] = __builtin_amdgcn_exp2f(fmaf(c0_[i_], c, -mc_));                 \
+        c1_[i_] = __builtin_amdgcn_exp2f(fmaf(c1_[i_], c, -mc_));                 \
+        lsum_ += c0_[i_] + c1_[i_];                                               \
+      }                                                                           \
+      l_run += lsum_;                                                             \
+      _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                          \
+        pb_[0][e_] = (T)c0_[e_];                                                  \
+        pb_[1][e_] = (T)c0_[8 + e_];                                              \
+        pb_[2][e_] = (T)c1_[e_];                                                  \
+        pb_[3][e_] = (T)c1_[8 + e_];                                              \
+      }                                                                           \
+      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
+        _Pragma("unroll") for (int kg_ = 0; kg_ < 4; ++kg_) {                     \
+          const V4 lo_ = MF<T>::tr(smem + (par_) * TILE_BYTES + v_rd[dt_] + (16 * kg_) * ROWB); \
+          const V4 hi_ = MF<T>::tr(smem + (par_) * TILE_BYTES + v_rd[dt_] + (16 * kg_ + 8) * ROWB); \
+          V8 vf_;                                                                 \
+          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { vf_[e_] = lo_[e_]; vf_[4 + e_] = hi_[e_]; } \
+          o[dt_] = MF<T>::mfma(vf_, pb_[kg_], o[dt_]);                            \
+        }                                                                         \
+      }                                                                           \
+      SCHED_RECIPE()                                                              \
+    }                                                                             \
+    __syncthreads();                                                              \
+  }
+
+  if (blk0 < blk1) {
+    // prologue: K(0), V(0) -> ring slot 0, K(1) -> slot 1; then rowK = rows(2), rowV = rows(1)
+    ROWS_OF(rowK, blk0)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
+    DMA_K(0)
+    DMA_V(0)
+    ROWS_OF(rowK, blk0 + 1)
+    DMA_K(1)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
+    ROWS_OF(rowK, blk0 + 2)
+    __syncthreads();
+    if (wave_active) QK(sA0, sA1, 0)
+    __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
+  }
+  for (int blk = blk0; blk < blk1; blk += 2) {
+    STEP(sA0, sA1, sB0, sB1, 0, blk)
+    if (blk + 1 >= blk1) break;
+    STEP(sB0, sB1, sA0, sA1, 1, blk + 1)
+  }
+#undef QK
+#undef STEP
+#undef STAGE_DMA
+#undef ROWS_OF
+#undef DMA_K
+#undef DMA_V
+
+  if (!wave_active) return;
+  // ---------------- epilogue ----------------
+  const float l_tot = half_sum(l_run);
+  if (p.n_splits > 1) {
+    // unnormalised partials: ws_o[y][sp][pos][d], ws_ml[y][sp][pos][2]
+    if (row_ok) {
+      const int64_t slot = ((int64_t)y * p.n_splits + sp) * p.n_q + my_p;
+      float* wo = p.ws_o + slot * D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          f32x4 v = {o[dt][4 * rg], o[dt][4 * rg + 1], o[dt][4 * rg + 2], o[dt][4 * rg + 3]};
+          *(f32x4*)(wo + 32 * dt + 8 * rg + 4 * hh) = v;
+        }
+      if (hh == 0) {
+        p.ws_ml[slot * 2] = m_run;
+        p.ws_ml[slot * 2 + 1] = l_tot;
+      }
+    }
+    return;
+  }
+  if (!row_ok) return;
+  const float inv = (my_p < q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
+  uint2 packed[16];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      V4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (T)(o[dt][4 * rg + j] * inv);
+      packed[dt * 4 + rg] = *(uint2*)&t;
+    }
+  char* obase = p.o + (int64_t)head * p.o_sh + hh * 8;
+  auto store_row = [&](int64_t row) {
+    char* op = obase + row * p.o_ss;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) *(uint2*)(op + (32 * dt + 8 * rg) * 2) = packed[dt * 4 + rg];
+  };
+  store_row(my_row);
+  if (p.dup_rows && my_p < p.n_dup_pos) {
+    const int32_t* dr = p.dup_rows + (int64_t)y * p.dup_rows_sh + (int64_t)my_p * p.n_dup;
+    for (int i = 0; i < p.n_dup; ++i) store_row((int64_t)dr[i]);
+  }
+}
+
+
+template <typename T, int NW, bool KVTAB, bool DMA>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
   // XCD-aware work order: consecutive logical ids (same head, neighbouring query blocks) share an XCD's L2
@@ -587,7 +863,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   } else {
     wg = blockIdx.x;
   }
-  attn_pipe_body<T, NW, KVTAB>(p, smem, wg);
+  if constexpr (DMA) attn_pipe_dma_body<T, NW, KVTAB>(p, smem, wg);
+  else attn_pipe_body<T, NW, KVTAB>(p, smem, wg);
 }
 
 // Several launches of the pipelined kernel fused into ONE grid (the experts of a routed layer).  Workgroups
@@ -610,8 +887,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParam
 #pragma unroll
   for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
   const Params& p = mp.seg[s];
-  if (p.kv_rows) attn_pipe_body<T, 8, true>(p, smem, b - mp.start[s]);
-  else attn_pipe_body<T, 8, false>(p, smem, b - mp.start[s]);
+  if (p.kv_rows) attn_pipe_dma_body<T, 8, true>(p, smem, b - mp.start[s]);
+  else attn_pipe_dma_body<T, 8, false>(p, smem, b - mp.start[s]);
 }
 
 // Merge the split-key partials: one wave per (head slot, query position).
@@ -656,8 +933,13 @@ int launch(const Params& p, hipStream_t st, bool pipe) {
   if (total > 0x7fffffff) return VORTA_EINVAL;
   hipError_t e;
   if (pipe) {
-    if (p.kv_rows) hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, true>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
-    else hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, false>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
+    if (p.dma) {
+      if (p.kv_rows) hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, true, true>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
+      else hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, false, true>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
+    } else {
+      if (p.kv_rows) hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, true, false>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
+      else hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, false, false>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return vorta_set_hip_error(e);
   } else {
@@ -706,16 +988,17 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   p.dup_rows = a->dup_rows; p.dup_rows_sh = a->dup_rows_stride_h; p.n_dup_pos = a->n_dup_pos; p.n_dup = a->n_dup;
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.n_splits = a->n_splits; p.ws_o = a->ws_o; p.ws_ml = a->ws_ml;
-  p.xcd_remap = a->reserved == 0 ? 1 : 0;  // experiment knob (reserved = 1 disables the remap)
+  p.xcd_remap = (a->reserved & 1) ? 0 : 1;  // experiment knobs: bit0 disables the XCD remap,
+  p.dma = (a->reserved & 2) ? 0 : 1;        //   bit1 selects register staging instead of LDS-DMA (pipelined kernel)
   p.n_groups = (p.n_q + p.q_group_len - 1) / p.q_group_len;
   block_rows = a->block_rows;
   if (block_rows == 0) {
-    // 256-row workgroups run the pipelined kernel (measured ~1.24x the 128-row kernel per row); a group that
-    // does not fill its last workgroup wastes CU time in proportion to the padding, so compare
+    // 256-row workgroups (8 waves, one per CU) measured ~1.04x the rate of 128-row ones (4 waves, two per CU); a
+    // group that does not fill its last workgroup wastes CU time in proportion to the padding, so compare
     //   rate256 * g / roundup(g,256)   with   rate128 * g / roundup(g,128)
     const int g = p.q_group_len;
     const int64_t pad256 = ((g + 255) / 256) * 256, pad128 = ((g + 127) / 128) * 128;
-    block_rows = (pad256 * 100 > pad128 * 124) ? 128 : 256;
+    block_rows = (pad256 * 100 > pad128 * 104) ? 128 : 256;
   }
   p.blocks_per_group = (p.q_group_len + block_rows - 1) / block_rows;
   const int nblk = (p.n_kv + KVB - 1) / KVB;
@@ -742,7 +1025,7 @@ extern "C" int vorta_attn_plan(const vorta_attn_args* a, int32_t* block_rows_out
   if (rc != VORTA_OK) return rc;
   if (block_rows_out) *block_rows_out = block_rows;
   if (kernel_id_out) {
-    const bool pipe = block_rows == 256 ? (a->variant != 1) : (a->variant == 2);
+    const bool pipe = a->variant != 1;
     *kernel_id_out = (block_rows == 256 ? 8 : 4) * 16 + (pipe ? 1 : 0) + ((pipe && a->kv_rows) ? 2 : 0);
   }
   if (n_workgroups_out) *n_workgroups_out = (int64_t)p.n_groups * p.blocks_per_group * p.n_heads * (p.n_heads ? p.n_splits : 0);
@@ -804,9 +1087,8 @@ extern "C" int vorta_attn_fwd(const vorta_attn_args* a, void* hip_stream) {
   if (rc != VORTA_OK) return rc;
   if (p.n_heads == 0 || p.n_groups == 0) return VORTA_OK;
   hipStream_t st = (hipStream_t)hip_stream;
-  // variant 0 (auto): 256-row workgroups run the software-pipelined kernel, 128-row ones the plain kernel
-  // (the pipelined body needs 4 more staging registers per thread at 4 waves and spills there)
-  const bool pipe = block_rows == 256 ? (a->variant != 1) : (a->variant == 2);
+  // variant 0 (auto) = the software-pipelined kernel with LDS-DMA staging, for both workgroup sizes
+  const bool pipe = a->variant != 1;
   if (a->dtype == VORTA_BF16)
     return block_rows == 256 ? launch<__bf16, 8>(p, st, pipe) : launch<__bf16, 4>(p, st, pipe);
   return block_rows == 256 ? launch<_Float16, 8>(p, st, pipe) : launch<_Float16, 4>(p, st, pipe);

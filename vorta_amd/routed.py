@@ -110,7 +110,7 @@ def _side_streams(device: torch.device):
 def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing: HeadRouting,
                      geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
                      out: Optional[torch.Tensor] = None, scale: Optional[float] = None,
-                     concurrent: bool = False, fused: bool = True) -> torch.Tensor:
+                     concurrent: bool = False, fused: bool = True, sliding_block_rows: int = 0) -> torch.Tensor:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
     hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383.
@@ -167,7 +167,8 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         sl = routing.slot_args(2, H)
         q_rows, kv_rows, n_kv = geom.sta_tables(te)
         calls = [dict(base, n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
-                      kv_rows_stride_g=n_kv, tag="sliding", flops=nheads(2) * 4.0 * D * S * n_kv, **sl)]
+                      kv_rows_stride_g=n_kv, tag="sliding", flops=nheads(2) * 4.0 * D * S * n_kv,
+                      block_rows=sliding_block_rows, **sl)]
         if T > 0:
             # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
             txt = dict(base, n_q=T, q_valid=te, n_kv=S + te, n_splits=_auto_splits(sl["n_heads"], T, S + te),
