@@ -853,6 +853,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 
 template <typename T, int NW, bool KVTAB, bool DMA>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
   // XCD-aware work order: consecutive logical ids (same head, neighbouring query blocks) share an XCD's L2
   const int nwg = gridDim.x;
@@ -865,6 +866,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   }
   if constexpr (DMA) attn_pipe_dma_body<T, NW, KVTAB>(p, smem, wg);
   else attn_pipe_body<T, NW, KVTAB>(p, smem, wg);
+#endif
 }
 
 // Several launches of the pipelined kernel fused into ONE grid (the experts of a routed layer).  Workgroups
@@ -881,6 +883,7 @@ struct MultiParams {
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParams mp) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
   const int b = blockIdx.x;
   int s = 0;
@@ -889,6 +892,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParam
   const Params& p = mp.seg[s];
   if (p.kv_rows) attn_pipe_dma_body<T, 8, true>(p, smem, b - mp.start[s]);
   else attn_pipe_dma_body<T, 8, false>(p, smem, b - mp.start[s]);
+#endif
 }
 
 // Merge the split-key partials: one wave per (head slot, query position).
