@@ -583,6 +583,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   constexpr int QB = NW * 32;
   constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
   constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
+  constexpr int KPRE = 2;              // k-steps of K fragments read ahead of the softmax head
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
@@ -694,6 +695,22 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
     }                                                                             \
   }
+  // the same with the fragments of the first KPRE k-steps already in registers (read at the top of the step,
+  // their LDS latency hides under the row-max phase)
+#define QK_PRE(d0_, d1_, par_)                                                    \
+  {                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { d0_[i_] = 0.f; d1_[i_] = 0.f; } \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
+      V8 k0_, k1_;                                                                \
+      if (ks_ < KPRE) { k0_ = kpre_[ks_][0]; k1_ = kpre_[ks_][1]; }               \
+      else {                                                                      \
+        k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);               \
+        k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB);   \
+      }                                                                           \
+      d0_ = MF<T>::mfma(k0_, qf[ks_], d0_);                                       \
+      d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
+    }                                                                             \
+  }
   // top of step j: K(j+2) -> the slot K(j) left, V(j+1) -> the slot V(j-1) left; both land before the barrier
   // that ends the step (the compiler's __syncthreads waits vmcnt(0) first), a whole step of latency cover
 #define STAGE_DMA(par_, j_)                                                       \
@@ -726,6 +743,11 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   {                                                                               \
     STAGE_DMA(par_, j_)                                                           \
     if (wave_active) {                                                            \
+      V8 kpre_[KPRE > 0 ? KPRE : 1][2];                                                          \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < KPRE; ++ks_) {                    \
+        kpre_[ks_][0] = *(const V8*)(smem + ((par_) ^ 1) * TILE_BYTES + k_rd[ks_]); \
+        kpre_[ks_][1] = *(const V8*)(smem + ((par_) ^ 1) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
+      }                                                                           \
       if ((j_) * KVB + KVB > n_kv) {                                              \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
           const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
@@ -746,7 +768,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
         m_run = m_new_;                                                           \
       }                                                                           \
       V8 pb_[4];                                                                  \
-      QK(n0_, n1_, (par_) ^ 1) /* block j+1 (harmless garbage past the end) */    \
+      QK_PRE(n0_, n1_, (par_) ^ 1) /* block j+1 (harmless garbage past the end) */ \
       const float mc_ = m_run * c;                                                \
       float lsum_ = 0.f;                                                          \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
@@ -795,6 +817,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     STEP(sB0, sB1, sA0, sA1, 1, blk + 1)
   }
 #undef QK
+#undef QK_PRE
 #undef STEP
 #undef STAGE_DMA
 #undef ROWS_OF
