@@ -136,6 +136,25 @@ def test_online_softmax_rescale_branch():
     check(out, ref, dtype)
 
 
+@pytest.mark.parametrize("boost", [0.35, 0.8, 2.0])
+def test_deferred_rescale_paths(boost):
+    """The pipelined kernel keeps the old running max while a block raises it by <= 6 (log2 units) and rescales
+    beyond: late keys that raise some rows' max by a little (no rescale, P > 1), by about the threshold, and by
+    a lot (rescale) must all match the oracle."""
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(6)
+    H, Sq, Skv = 1, 96, 640
+    q, k, v = rng.standard_normal((H, Sq, 128)), rng.standard_normal((H, Skv, 128)), rng.standard_normal((H, Skv, 128))
+    for row, key in ((5, 300), (33, 500), (70, 620)):
+        k[0, key] = q[0, row] * boost  # raw score ~ boost*|q|^2 -> scaled log2 growth ~ boost * 128 * 0.1275
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    out = torch.empty_like(qd)
+    ops.attn_fwd(qd, kd, vd, out, n_q=Sq, n_kv=Skv)
+    ref = O.dense_attention(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype))
+    check(out, ref, dtype)
+
+
 def test_bad_arguments_raise():
     from vorta_amd import ops
     q = torch.zeros((1, 64, 128), dtype=torch.bfloat16, device=dev())
@@ -145,6 +164,8 @@ def test_bad_arguments_raise():
         ops.attn_fwd(q[..., :64], q[..., :64], q[..., :64], q[..., :64].clone(), n_q=64, n_kv=64)  # head_dim 64
     with pytest.raises(ValueError):
         ops.attn_fwd(q, q, q, q.clone(), n_q=64, n_kv=64, block_rows=100)
+    with pytest.raises(ValueError):
+        ops.attn_fwd(q, q, q, q.clone(), n_q=64, n_kv=64, scale=0.0)
 
 
 @pytest.mark.parametrize("S", [32760, 118800])

@@ -33,6 +33,7 @@ struct Params {
   int n_splits, blocks_per_split;
   float* ws_o; float* ws_ml;
   int xcd_remap, dma;
+  float defer_log2;  // online-softmax rescale is skipped while the row max grows by <= this (log2 units)
 };
 
 template <typename T> struct MF;

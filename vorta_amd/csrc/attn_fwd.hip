@@ -682,6 +682,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   const float c = p.scale_log2;
+  const float defer_raw = p.defer_log2 / c;  // threshold in raw score units (c > 0)
   f32x16 sA0, sA1, sB0, sB1;  // scores of the current / next key block (roles swap every block)
 
   // scores of a block from the K ring slot `par_` into (d0_, d1_); the tail mask is applied by the consumer
@@ -760,7 +761,9 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, c1_[i_]); \
       mx_ = half_max(mx_);                                                        \
       const float m_new_ = fmaxf(m_run, mx_);                                     \
-      if (!__all(m_new_ == m_run)) {                                              \
+      /* deferred rescale: keep the old running max while no row of the wave grew by more than defer_raw, */ \
+      /* so exp() arguments stay <= DEFER_LOG2 (P <= 2^6: exact in fp32 sums, representable in fp16/bf16) */ \
+      if (!__all(m_new_ - m_run <= defer_raw)) {                                  \
         const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * c);        \
         _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                       \
           _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_; \
@@ -996,6 +999,7 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
     if (((uintptr_t)t->ptr & 15) || (t->stride_s % 8) || (t->stride_h % 8) || t->stride_s < D) return VORTA_EINVAL;
   }
   if (a->n_splits < 1 || a->n_splits > 1024) return VORTA_EINVAL;
+  if (!(a->scale > 0.f)) return VORTA_EINVAL;  // the online-softmax thresholds assume a positive scale
   if (a->n_splits > 1 && (!a->ws_o || !a->ws_ml)) return VORTA_EINVAL;
   if (a->q_group_len < 0 || a->q_valid < 0) return VORTA_EINVAL;
   if (a->dup_rows && (a->n_dup < 0 || a->n_dup_pos < 0 || a->n_dup_pos > a->n_q)) return VORTA_EINVAL;
@@ -1017,6 +1021,7 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   p.n_splits = a->n_splits; p.ws_o = a->ws_o; p.ws_ml = a->ws_ml;
   p.xcd_remap = (a->reserved & 1) ? 0 : 1;  // experiment knobs: bit0 disables the XCD remap,
   p.dma = (a->reserved & 2) ? 0 : 1;        //   bit1 selects register staging instead of LDS-DMA (pipelined kernel)
+  p.defer_log2 = (a->reserved & 4) ? 0.f : 6.f;  // bit2 turns the deferred rescale off (exact running max)
   p.n_groups = (p.n_q + p.q_group_len - 1) / p.q_group_len;
   block_rows = a->block_rows;
   if (block_rows == 0) {
