@@ -684,6 +684,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   const float c = p.scale_log2;
   const float defer_raw = p.defer_log2 / c;  // threshold in raw score units (c > 0)
   f32x16 sA0, sA1, sB0, sB1;  // scores of the current / next key block (roles swap every block)
+  float mx_cur = -1e30f;       // row max of the current block's scores
 
   // scores of a block from the K ring slot `par_` into (d0_, d1_); the tail mask is applied by the consumer
 #define QK(d0_, d1_, par_)                                                        \
@@ -695,6 +696,13 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       d0_ = MF<T>::mfma(k0_, qf[ks_], d0_);                                       \
       d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
     }                                                                             \
+  }
+#define ROW_MAX(dst_, a_, b_)                                                      \
+  {                                                                               \
+    float mx_ = a_[0];                                                            \
+    _Pragma("unroll") for (int i_ = 1; i_ < 16; ++i_) mx_ = fmaxf(mx_, a_[i_]);   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, b_[i_]);   \
+    dst_ = half_max(mx_);                                                         \
   }
   // the same with the fragments of the first KPRE k-steps already in registers (read at the top of the step,
   // their LDS latency hides under the row-max phase)
@@ -749,18 +757,17 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
         kpre_[ks_][0] = *(const V8*)(smem + ((par_) ^ 1) * TILE_BYTES + k_rd[ks_]); \
         kpre_[ks_][1] = *(const V8*)(smem + ((par_) ^ 1) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
       }                                                                           \
+      /* mx_cur (row max of this block's scores) was computed under the previous step's PV MFMAs; only the */ \
+      /* last, partial key block has to mask its tail and redo it here                                      */ \
       if ((j_) * KVB + KVB > n_kv) {                                              \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
           const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
           if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
           if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
         }                                                                         \
+        ROW_MAX(mx_cur, c0_, c1_)                                                 \
       }                                                                           \
-      float mx_ = c0_[0];                                                         \
-      _Pragma("unroll") for (int i_ = 1; i_ < 16; ++i_) mx_ = fmaxf(mx_, c0_[i_]); \
-      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, c1_[i_]); \
-      mx_ = half_max(mx_);                                                        \
-      const float m_new_ = fmaxf(m_run, mx_);                                     \
+      const float m_new_ = fmaxf(m_run, mx_cur);                                  \
       /* deferred rescale: keep the old running max while no row of the wave grew by more than defer_raw, */ \
       /* so exp() arguments stay <= DEFER_LOG2 (P <= 2^6: exact in fp32 sums, representable in fp16/bf16) */ \
       if (!__all(m_new_ - m_run <= defer_raw)) {                                  \
@@ -795,6 +802,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
           o[dt_] = MF<T>::mfma(vf_, pb_[kg_], o[dt_]);                            \
         }                                                                         \
       }                                                                           \
+      ROW_MAX(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */   \
       SCHED_RECIPE()                                                              \
     }                                                                             \
     __syncthreads();                                                              \
@@ -811,7 +819,10 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     ROWS_OF(rowK, blk0 + 2)
     __syncthreads();
-    if (wave_active) QK(sA0, sA1, 0)
+    if (wave_active) {
+      QK(sA0, sA1, 0)
+      ROW_MAX(mx_cur, sA0, sA1)
+    }
     __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
   }
   for (int blk = blk0; blk < blk1; blk += 2) {
@@ -821,6 +832,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   }
 #undef QK
 #undef QK_PRE
+#undef ROW_MAX
 #undef STEP
 #undef STAGE_DMA
 #undef ROWS_OF
