@@ -910,8 +910,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
 // Several launches of the pipelined kernel fused into ONE grid (the experts of a routed layer).  Workgroups
 // are dispatched in segment order, longest key loops first, so the tail of one expert (a launch holds only a
 // few waves of workgroups per CU-set, fewer still under sequence parallelism) is filled by the next expert's
-// workgroups instead of idling until a kernel boundary.  No XCD chunking here: with segments of different
-// cost, dealing consecutive workgroups round-robin over the XCDs keeps the chip balanced.
+// workgroups instead of idling until a kernel boundary.
 constexpr int MAX_SEGMENTS = 4;
 struct MultiParams {
   Params seg[MAX_SEGMENTS];
@@ -928,8 +927,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParam
 #pragma unroll
   for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
   const Params& p = mp.seg[s];
-  if (p.kv_rows) attn_pipe_dma_body<T, 8, true>(p, smem, b - mp.start[s]);
-  else attn_pipe_dma_body<T, 8, false>(p, smem, b - mp.start[s]);
+  // XCD-aware order INSIDE the segment: workgroups whose ids are equal mod 8 share an XCD (round-robin
+  // dispatch), so give each such class a contiguous chunk of the segment's logical ids (same head,
+  // neighbouring query blocks -> one L2 serves the K/V stream instead of eight).  Every XCD still gets 1/8 of
+  // every segment, which keeps the chip balanced across segments of different cost.
+  const int l = b - mp.start[s], n = mp.start[s + 1] - mp.start[s];
+  const int xcd = l & 7, qd = n >> 3, r = n & 7;
+  const int wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (l >> 3);
+  if (p.kv_rows) attn_pipe_dma_body<T, 8, true>(p, smem, wg);
+  else attn_pipe_dma_body<T, 8, false>(p, smem, wg);
 #endif
 }
 
