@@ -196,6 +196,29 @@ int vorta_router_route(const vorta_router_args* args, void* hip_stream);
 int vorta_route_scores(const vorta_router_args* args, void* hip_stream);
 
 /*
+ * vorta_qk_norm_rope -- the producer step right before the attention boundary, in place:
+ * RMSNorm of q or k (hunyuan.py:62-73: per head over D with attn.norm_q / norm_k [diffusers RMSNorm];
+ * wan.py:85-89: across all H*D channels of a token, before the head split) followed by the rotary embedding
+ * (hunyuan.py:75-104 via diffusers apply_rotary_emb(use_real, unbind_dim=-1); wan.py:34-37 complex product --
+ * the same rotation of interleaved pairs).  One read and one write of the tensor instead of ~10 torch passes.
+ *   tokens [token_offset, token_offset + n_tokens) of every head are normalised; the first rope_tokens of them
+ *   are rotated with cos/sin[token][D] (fp32; NULL = no rotation: text tokens, hunyuan.py:90-102).
+ */
+typedef struct vorta_norm_rope_args {
+  uint32_t struct_size;
+  int32_t dtype, head_dim, heads;
+  vorta_tensor x;       /* (H,S,D) view, updated in place */
+  const void* weight;   /* [D] or, if across_heads, [H*D]; dtype of x; NULL = no scale */
+  const float* cos;     /* [n_tokens][D] or NULL */
+  const float* sin;
+  int32_t n_tokens, token_offset, rope_tokens;
+  float eps;
+  int32_t across_heads; /* 0: mean over D per head (Hunyuan); 1: mean over H*D per token (Wan) */
+} vorta_norm_rope_args;
+
+int vorta_qk_norm_rope(const vorta_norm_rope_args* args, void* hip_stream);
+
+/*
  * vorta_seq_row_map -- physical row of every token for the zero-copy Ulysses layout.
  * After all_to_all_single of a sequence-sharded (H, S/P, D) tensor (vorta/ulysses/utils.py:61-91) rank r
  * holds P chunks of (H/P, S/P, D); the reference re-packs them into (H/P, S, D) with two
@@ -209,7 +232,7 @@ int vorta_seq_row_map(int32_t* row_map, int32_t n_tokens, int32_t seg_len, int32
 int vorta_abi_version(void);
 const char* vorta_build_info(void); /* static string: arch, compiler */
 int vorta_last_hip_error(void);     /* last hipError_t seen by a failed launch in this thread */
-int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args */
+int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args, 5 norm_rope_args */
 
 #ifdef __cplusplus
 }

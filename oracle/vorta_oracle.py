@@ -328,6 +328,25 @@ def all_gather_cat(parts: Sequence[np.ndarray], dim: int) -> np.ndarray:
     return np.concatenate(list(parts), axis=dim)
 
 
+# ----------------------------------------------------------------------------------------------- N1 producer
+def rms_norm(x: np.ndarray, weight: Optional[np.ndarray], eps: float, axis_size: Optional[int] = None) -> np.ndarray:
+    """x * rsqrt(mean(x^2, -1) + eps) * weight  (hunyuan.py:69-72 attn.norm_q / norm_k, wan.py:86-89;
+    [ext] the modules are diffusers / torch RMSNorm)."""
+    x = np.asarray(x, dtype=np.float64)
+    y = x / np.sqrt((x * x).mean(-1, keepdims=True) + eps)
+    return y if weight is None else y * np.asarray(weight, dtype=np.float64)
+
+
+def rope_interleaved(x: np.ndarray, cos: np.ndarray, sin: np.ndarray) -> np.ndarray:
+    """Rotation of adjacent pairs: out = x*cos + rot(x)*sin, rot(x)[2i] = -x[2i+1], rot(x)[2i+1] = x[2i].
+    hunyuan.py:97-98 ([ext] diffusers apply_rotary_emb(use_real=True, use_real_unbind_dim=-1)); identical to the
+    complex product of wan.py:34-37 with cos/sin = Re/Im of the frequencies repeated per pair.  x: (...,S,D)."""
+    x = np.asarray(x, dtype=np.float64)
+    xr = x.reshape(x.shape[:-1] + (-1, 2))
+    rot = np.stack([-xr[..., 1], xr[..., 0]], -1).reshape(x.shape)
+    return x * cos + rot * sin
+
+
 # ----------------------------------------------------------------------------------------------- misc
 def pixel_to_token(n_pixel: int, ratio: int) -> int:
     """vorta/patch/utils.py:84-92."""

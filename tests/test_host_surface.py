@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
     assert lib.vorta_abi_version() == _C.ABI_VERSION
     assert b"gfx950" in lib.vorta_build_info()
-    for which, st in enumerate((_C.Tensor, _C.AttnArgs, _C.CoresetArgs, _C.StaArgs, _C.RouterArgs)):
+    for which, st in enumerate((_C.Tensor, _C.AttnArgs, _C.CoresetArgs, _C.StaArgs, _C.RouterArgs, _C.NormRopeArgs)):
         assert lib.vorta_sizeof(which) == ctypes.sizeof(st)
     assert lib.vorta_sizeof(99) == -1
 

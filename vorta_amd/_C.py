@@ -68,6 +68,15 @@ class RouterArgs(C.Structure):
     ]
 
 
+class NormRopeArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32),
+        ("x", Tensor), ("weight", _vp), ("cos", _vp), ("sin", _vp),
+        ("n_tokens", _i32), ("token_offset", _i32), ("rope_tokens", _i32),
+        ("eps", _f32), ("across_heads", _i32),
+    ]
+
+
 # every symbol include/vorta_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "vorta_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
@@ -79,6 +88,7 @@ SYMBOLS = {
     "vorta_sta_build_tables": (C.c_int, [C.POINTER(StaArgs), _vp]),
     "vorta_router_route": (C.c_int, [C.POINTER(RouterArgs), _vp]),
     "vorta_route_scores": (C.c_int, [C.POINTER(RouterArgs), _vp]),
+    "vorta_qk_norm_rope": (C.c_int, [C.POINTER(NormRopeArgs), _vp]),
     "vorta_seq_row_map": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "vorta_abi_version": (C.c_int, []),
     "vorta_build_info": (C.c_char_p, []),
@@ -117,7 +127,7 @@ def lib():
         fn.argtypes = args
     if h.vorta_abi_version() != ABI_VERSION:
         raise VortaHipError(f"ABI mismatch: library {h.vorta_abi_version()} vs binding {ABI_VERSION}")
-    for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs)):
+    for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs)):
         if h.vorta_sizeof(which) != C.sizeof(st):
             raise VortaHipError(f"struct layout mismatch for {st.__name__}: "
                                 f"C {h.vorta_sizeof(which)} vs ctypes {C.sizeof(st)}")

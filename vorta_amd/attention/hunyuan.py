@@ -27,6 +27,26 @@ def apply_rotary_emb(x: torch.Tensor, freqs_cis: Tuple[torch.Tensor, torch.Tenso
     return (x.float() * cos + x_rot.float() * sin).to(x.dtype)
 
 
+def _fusable_norm(norm, x: torch.Tensor, numel: int) -> bool:
+    """can vorta_qk_norm_rope stand in for this module?  (RMSNorm with an `eps` and an optional `weight` of the
+    expected size, half-precision CUDA input)"""
+    if norm is None or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or x.shape[-1] != 128:
+        return False
+    if "RMSNorm" not in type(norm).__name__ or getattr(norm, "eps", None) is None:
+        return False
+    w = getattr(norm, "weight", None)
+    return w is None or w.numel() == numel
+
+
+def fused_norm_rope(x: torch.Tensor, norm, rope: Optional[Tuple[torch.Tensor, torch.Tensor]], rope_tokens: int = 0):
+    """RMSNorm (+ RoPE on the first `rope_tokens` tokens) of a (1,H,N,D) projection view, in place, in one HIP
+    kernel (hunyuan.py:62-104 are two module calls and ~10 elementwise passes)."""
+    w = getattr(norm, "weight", None)
+    cos, sin = rope if rope is not None else (None, None)
+    ops.qk_norm_rope(x[0], w, float(norm.eps), cos=cos, sin=sin, rope_tokens=rope_tokens if rope is not None else 0)
+    return x
+
+
 class HunyuanVideoFlashAttnProcessor:
     """Dense attention for every head: the --native_attention path (hunyuan.py:35-238)."""
 
@@ -42,25 +62,37 @@ class HunyuanVideoFlashAttnProcessor:
         q = attn.to_q(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
         k = attn.to_k(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
         v = attn.to_v(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
-        if attn.norm_q is not None:
-            q = attn.norm_q(q)
-        if attn.norm_k is not None:
-            k = attn.norm_k(k)
+        rope = None
         if image_rotary_emb is not None:
             rope = (shrink_dim(image_rotary_emb[0], dim=0), shrink_dim(image_rotary_emb[1], dim=0))
-            if single_stream:
-                q = torch.cat([apply_rotary_emb(q[:, :, :-T], rope), q[:, :, -T:]], dim=2)
-                k = torch.cat([apply_rotary_emb(k[:, :, :-T], rope), k[:, :, -T:]], dim=2)
-            else:
-                q, k = apply_rotary_emb(q, rope), apply_rotary_emb(k, rope)
+        n_video = q.shape[2] - (T if single_stream else 0)
+        if q.shape[0] == 1 and _fusable_norm(attn.norm_q, q, 128) and _fusable_norm(attn.norm_k, k, 128):
+            # one in-place HIP pass per tensor: norm everywhere, rotation on the video tokens only
+            fused_norm_rope(q, attn.norm_q, rope, n_video)
+            fused_norm_rope(k, attn.norm_k, rope, n_video)
+        else:
+            if attn.norm_q is not None:
+                q = attn.norm_q(q)
+            if attn.norm_k is not None:
+                k = attn.norm_k(k)
+            if rope is not None:
+                if single_stream:
+                    q = torch.cat([apply_rotary_emb(q[:, :, :-T], rope), q[:, :, -T:]], dim=2)
+                    k = torch.cat([apply_rotary_emb(k[:, :, :-T], rope), k[:, :, -T:]], dim=2)
+                else:
+                    q, k = apply_rotary_emb(q, rope), apply_rotary_emb(k, rope)
         if not single_stream:
             eq = attn.add_q_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
             ek = attn.add_k_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
             ev = attn.add_v_proj(encoder_hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
-            if attn.norm_added_q is not None:
-                eq = attn.norm_added_q(eq)
-            if attn.norm_added_k is not None:
-                ek = attn.norm_added_k(ek)
+            if eq.shape[0] == 1 and _fusable_norm(attn.norm_added_q, eq, 128) and _fusable_norm(attn.norm_added_k, ek, 128):
+                fused_norm_rope(eq, attn.norm_added_q, None)
+                fused_norm_rope(ek, attn.norm_added_k, None)
+            else:
+                if attn.norm_added_q is not None:
+                    eq = attn.norm_added_q(eq)
+                if attn.norm_added_k is not None:
+                    ek = attn.norm_added_k(ek)
             q, k, v = torch.cat([q, eq], dim=2), torch.cat([k, ek], dim=2), torch.cat([v, ev], dim=2)
         return q, k, v, T
 

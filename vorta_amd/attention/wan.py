@@ -20,6 +20,22 @@ def apply_rotary_emb(hidden_states: torch.Tensor, freqs: torch.Tensor) -> torch.
     return torch.view_as_real(x * freqs).flatten(3, 4).type_as(hidden_states)
 
 
+_ROPE_CACHE = {}
+
+
+def _cos_sin(freqs: torch.Tensor):
+    """complex frequencies (1,1,S,D/2) -> fp32 (cos, sin) of shape (S,D) with each value repeated for its pair;
+    cached per frequency tensor (it is built once per run, modeling_wan.py:242-262)."""
+    key = (freqs.data_ptr(), tuple(freqs.shape), freqs._version)
+    hit = _ROPE_CACHE.get(key)
+    if hit is None:
+        f = freqs.reshape(-1, freqs.shape[-1])
+        hit = (f.real.float().repeat_interleave(2, dim=1).contiguous(), f.imag.float().repeat_interleave(2, dim=1).contiguous())
+        _ROPE_CACHE.clear()
+        _ROPE_CACHE[key] = hit
+    return hit
+
+
 class WanAttnProcessor2_0:
     """Dense attention (wan.py:40-160): self, text cross (Sq != Skv) and the optional I2V image branch."""
 
@@ -37,14 +53,27 @@ class WanAttnProcessor2_0:
         q = attn.to_q(hidden_states)
         k = attn.to_k(encoder_hidden_states)
         v = attn.to_v(encoder_hidden_states)
-        if attn.norm_q is not None:
-            q = attn.norm_q(q)
-        if attn.norm_k is not None:
-            k = attn.norm_k(k)
-        q, k, v = (x.unflatten(2, (attn.heads, -1)).transpose(1, 2) for x in (q, k, v))
-        if rotary_emb is not None:
-            rotary_emb = shrink_dim(rotary_emb, dim=2)
-            q, k = apply_rotary_emb(q, rotary_emb), apply_rotary_emb(k, rotary_emb)
+        H = attn.heads
+        rope = shrink_dim(rotary_emb, dim=2) if rotary_emb is not None else None
+        from .hunyuan import _fusable_norm
+        fuse = (q.shape[0] == 1 and q.shape[-1] == H * 128
+                and (rope is None or (rope.shape[-2] == q.shape[1] == k.shape[1]))
+                and _fusable_norm(attn.norm_q, q.view(1, q.shape[1], H, 128), H * 128)
+                and _fusable_norm(attn.norm_k, k.view(1, k.shape[1], H, 128), H * 128))
+        if fuse:
+            # RMSNorm over all H*D channels of a token + rotation, one in-place HIP pass per tensor
+            cos, sin = _cos_sin(rope) if rope is not None else (None, None)
+            q, k, v = (x.unflatten(2, (H, -1)).transpose(1, 2) for x in (q, k, v))
+            ops.qk_norm_rope(q[0], attn.norm_q.weight, float(attn.norm_q.eps), cos=cos, sin=sin, across_heads=True)
+            ops.qk_norm_rope(k[0], attn.norm_k.weight, float(attn.norm_k.eps), cos=cos, sin=sin, across_heads=True)
+        else:
+            if attn.norm_q is not None:
+                q = attn.norm_q(q)
+            if attn.norm_k is not None:
+                k = attn.norm_k(k)
+            q, k, v = (x.unflatten(2, (H, -1)).transpose(1, 2) for x in (q, k, v))
+            if rope is not None:
+                q, k = apply_rotary_emb(q, rope), apply_rotary_emb(k, rope)
         return q, k, v, enc_img
 
     @staticmethod

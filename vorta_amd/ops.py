@@ -312,6 +312,39 @@ def route_scores(scores: torch.Tensor, tau: float):
     return expert, lists, counts
 
 
+def qk_norm_rope(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float, *,
+                 cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
+                 n_tokens: Optional[int] = None, token_offset: int = 0, rope_tokens: Optional[int] = None,
+                 across_heads: bool = False) -> torch.Tensor:
+    """vorta_qk_norm_rope: in-place RMSNorm (+ rotary embedding) of a (H,S,D) view of q or k."""
+    _require_gpu(x, weight, cos, sin)
+    if x.dtype not in _DT:
+        raise ValueError("x must be bf16 or fp16")
+    a = _C.NormRopeArgs()
+    a.struct_size = C.sizeof(_C.NormRopeArgs)
+    a.dtype, a.head_dim, a.heads = _DT[x.dtype], x.shape[-1], x.shape[0]
+    a.x = _tensor(x)
+    if weight is not None:
+        if weight.dtype != x.dtype or not weight.is_contiguous():
+            weight = weight.to(x.dtype).contiguous()
+        a.weight = weight.data_ptr()
+    n_tokens = x.shape[1] - token_offset if n_tokens is None else n_tokens
+    if cos is not None:
+        if cos.dtype != torch.float32 or not cos.is_contiguous():
+            cos = cos.float().contiguous()
+        if sin.dtype != torch.float32 or not sin.is_contiguous():
+            sin = sin.float().contiguous()
+        a.cos, a.sin = cos.data_ptr(), sin.data_ptr()
+        rope_tokens = min(cos.shape[0], n_tokens) if rope_tokens is None else rope_tokens
+        if cos.shape[0] < rope_tokens or cos.shape[-1] != x.shape[-1]:
+            raise ValueError("cos/sin must be (>= rope_tokens, D)")
+    a.n_tokens, a.token_offset, a.rope_tokens = n_tokens, token_offset, rope_tokens or 0
+    a.eps = eps
+    a.across_heads = 1 if across_heads else 0
+    _C.check(_C.lib().vorta_qk_norm_rope(C.byref(a), _stream()), "vorta_qk_norm_rope")
+    return x
+
+
 def seq_row_map(n_tokens: int, seg_len: int, seg_stride_rows: int, device) -> torch.Tensor:
     """vorta_seq_row_map (zero-copy Ulysses layout)."""
     out = torch.empty(n_tokens, dtype=torch.int32, device=device)
