@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
           *(f32x4*)(wo + 32 * dt + 8 * rg + 4 * hh) = v;
         }
       if (hh == 0) {
-        p.ws_ml[slot * 2] = m_run;
+        p.ws_ml[slot * 2] = m_run * c;  // exp2 domain
         p.ws_ml[slot * 2 + 1] = l_tot;
       }
     }
@@ -541,7 +541,7 @@ __device__ __forceinline__ void attn_pipe_body(const Params& p, char* __restrict
           *(f32x4*)(wo + 32 * dt + 8 * rg + 4 * hh) = v;
         }
       if (hh == 0) {
-        p.ws_ml[slot * 2] = m_run;
+        p.ws_ml[slot * 2] = m_run * c;  // exp2 domain
         p.ws_ml[slot * 2 + 1] = l_tot;
       }
     }
@@ -618,11 +618,18 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
   const int64_t my_row = q_rows ? (int64_t)q_rows[ld_p] : (int64_t)(p.q_row_offset + ld_p);
 
+  // Q is pre-multiplied by scale*log2(e) once (re-rounded to T): the MFMA then delivers scores in the exp2
+  // domain, and with the running max folded into the accumulator's initial value (below) the softmax needs no
+  // per-element multiply/subtract at all.
   V8 qf[8];
   {
     const char* qp = p.q + (int64_t)head * p.q_sh + my_row * p.q_ss + hh * 16;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const V8*)(qp + ks * 32);
+    for (int ks = 0; ks < 8; ++ks) {
+      const V8 raw = *(const V8*)(qp + ks * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qf[ks][i] = (T)((float)raw[i] * p.scale_log2);
+    }
   }
 
   // ---- loader setup ----
@@ -680,21 +687,25 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  // Online softmax in the exp2 domain.  m_run = reference point of this row (a lower bound of its running max,
+  // at most defer_log2 below it); the score MFMAs start from minit = -m_run in every accumulator register, so
+  // they produce z - m_run directly and P = exp2 of that.  minit only changes in the (rare) rescale branch.
   float m_run = -1e30f, l_run = 0.f;
-  const float c = p.scale_log2;
-  const float defer_raw = p.defer_log2 / c;  // threshold in raw score units (c > 0)
-  f32x16 sA0, sA1, sB0, sB1;  // scores of the current / next key block (roles swap every block)
-  float mx_cur = -1e30f;       // row max of the current block's scores
+  const float defer = p.defer_log2;
+  f32x16 sA0, sA1, sB0, sB1;  // scores (minus m_run) of the current / next key block (roles swap every block)
+  f32x16 minit;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) minit[i] = 0.f;
+  float mx_cur = -1e30f;       // row max of the current block's (offset) scores
 
   // scores of a block from the K ring slot `par_` into (d0_, d1_); the tail mask is applied by the consumer
 #define QK(d0_, d1_, par_)                                                        \
   {                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { d0_[i_] = 0.f; d1_[i_] = 0.f; } \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
       const V8 k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);        \
       const V8 k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
-      d0_ = MF<T>::mfma(k0_, qf[ks_], d0_);                                       \
-      d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
+      d0_ = MF<T>::mfma(k0_, qf[ks_], ks_ == 0 ? minit : d0_);                    \
+      d1_ = MF<T>::mfma(k1_, qf[ks_], ks_ == 0 ? minit : d1_);                    \
     }                                                                             \
   }
 #define ROW_MAX(dst_, a_, b_)                                                      \
@@ -708,7 +719,6 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   // their LDS latency hides under the row-max phase)
 #define QK_PRE(d0_, d1_, par_)                                                    \
   {                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { d0_[i_] = 0.f; d1_[i_] = 0.f; } \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
       V8 k0_, k1_;                                                                \
       if (ks_ < KPRE) { k0_ = kpre_[ks_][0]; k1_ = kpre_[ks_][1]; }               \
@@ -716,9 +726,22 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
         k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);               \
         k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB);   \
       }                                                                           \
-      d0_ = MF<T>::mfma(k0_, qf[ks_], d0_);                                       \
-      d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
+      d0_ = MF<T>::mfma(k0_, qf[ks_], ks_ == 0 ? minit : d0_);                    \
+      d1_ = MF<T>::mfma(k1_, qf[ks_], ks_ == 0 ? minit : d1_);                    \
     }                                                                             \
+  }
+  // move the reference point of the row up by g_ (>= 0): everything accumulated so far and the current block's
+  // offset scores are brought to the new reference, and the accumulator seed follows.  The empty asm keeps the
+  // seed an opaque 16-register value (otherwise the compiler re-materialises the splat before every use).
+#define RAISE_REF(g_, c0_, c1_)                                                   \
+  {                                                                               \
+    const float alpha_ = __builtin_amdgcn_exp2f(-(g_));                           \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                           \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;     \
+    l_run *= alpha_;                                                              \
+    m_run += (g_);                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= (g_); c1_[i_] -= (g_); minit[i_] = -m_run; } \
+    asm volatile("" : "+v"(minit));                                               \
   }
   // top of step j: K(j+2) -> the slot K(j) left, V(j+1) -> the slot V(j-1) left; both land before the barrier
   // that ends the step (the compiler's __syncthreads waits vmcnt(0) first), a whole step of latency cover
@@ -767,23 +790,19 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
         }                                                                         \
         ROW_MAX(mx_cur, c0_, c1_)                                                 \
       }                                                                           \
-      const float m_new_ = fmaxf(m_run, mx_cur);                                  \
-      /* deferred rescale: keep the old running max while no row of the wave grew by more than defer_raw, */ \
-      /* so exp() arguments stay <= DEFER_LOG2 (P <= 2^6: exact in fp32 sums, representable in fp16/bf16) */ \
-      if (!__all(m_new_ - m_run <= defer_raw)) {                                  \
-        const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * c);        \
-        _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                       \
-          _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_; \
-        l_run *= alpha_;                                                          \
-        m_run = m_new_;                                                           \
+      /* deferred rescale: the reference point moves only when some row of the wave outgrew it by more than */ \
+      /* `defer` (so P <= 2^defer: exact in the fp32 sums, representable in fp16/bf16); rows that did not grow  */ \
+      /* keep theirs (g = 0)                                                                                  */ \
+      if (!__all(mx_cur <= defer)) {                                              \
+        const float g_ = fmaxf(mx_cur, 0.f);                                      \
+        RAISE_REF(g_, c0_, c1_)                                                   \
       }                                                                           \
       V8 pb_[4];                                                                  \
       QK_PRE(n0_, n1_, (par_) ^ 1) /* block j+1 (harmless garbage past the end) */ \
-      const float mc_ = m_run * c;                                                \
       float lsum_ = 0.f;                                                          \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
-        c0_[i_] = __builtin_amdgcn_exp2f(fmaf(c0_[i_], c, -mc_));                 \
-        c1_[i_] = __builtin_amdgcn_exp2f(fmaf(c1_[i_], c, -mc_));                 \
+        c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                \
+        c1_[i_] = __builtin_amdgcn_exp2f(c1_[i_]);                                \
         lsum_ += c0_[i_] + c1_[i_];                                               \
       }                                                                           \
       l_run += lsum_;                                                             \
@@ -820,8 +839,23 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     ROWS_OF(rowK, blk0 + 2)
     __syncthreads();
     if (wave_active) {
-      QK(sA0, sA1, 0)
+      QK(sA0, sA1, 0)  // seed 0: plain scores of the first block
+      if (blk0 * KVB + KVB > n_kv) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (blk0 * KVB + row >= n_kv) sA0[i] = -INFINITY;
+          if (blk0 * KVB + 32 + row >= n_kv) sA1[i] = -INFINITY;
+        }
+      }
       ROW_MAX(mx_cur, sA0, sA1)
+      // the first block fixes the reference point at its true row max (block blk0 always has a valid key);
+      // O and l are still zero, so nothing is rescaled (exp2(-max) could overflow for very negative scores)
+      m_run = mx_cur;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sA0[i] -= m_run; sA1[i] -= m_run; minit[i] = -m_run; }
+      asm volatile("" : "+v"(minit));
+      mx_cur = 0.f;
     }
     __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
   }
@@ -833,6 +867,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #undef QK
 #undef QK_PRE
 #undef ROW_MAX
+#undef RAISE_REF
 #undef STEP
 #undef STAGE_DMA
 #undef ROWS_OF
@@ -855,7 +890,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
           *(f32x4*)(wo + 32 * dt + 8 * rg + 4 * hh) = v;
         }
       if (hh == 0) {
-        p.ws_ml[slot * 2] = m_run;
+        p.ws_ml[slot * 2] = m_run;  // already in the exp2 domain
         p.ws_ml[slot * 2 + 1] = l_tot;
       }
     }
@@ -954,7 +989,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const Params p) {
   float acc0 = 0.f, acc1 = 0.f, l = 0.f;
   for (int s = 0; s < p.n_splits; ++s) {
     const int64_t slot = ((int64_t)y * p.n_splits + s) * p.n_q + pos;
-    const float w = __builtin_amdgcn_exp2f((p.ws_ml[slot * 2] - m) * p.scale_log2);
+    const float w = __builtin_amdgcn_exp2f(p.ws_ml[slot * 2] - m);  // reference points are stored in the exp2 domain
     l += w * p.ws_ml[slot * 2 + 1];
     const float2 v = *(const float2*)(p.ws_o + slot * D + lane * 2);
     acc0 += w * v.x;
