@@ -1078,12 +1078,12 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   p.n_groups = (p.n_q + p.q_group_len - 1) / p.q_group_len;
   block_rows = a->block_rows;
   if (block_rows == 0) {
-    // 256-row workgroups (8 waves, one per CU) measured ~1.04x the rate of 128-row ones (4 waves, two per CU); a
+    // 256-row workgroups (8 waves, one per CU) measured ~1.06x the rate of 128-row ones (4 waves, two per CU); a
     // group that does not fill its last workgroup wastes CU time in proportion to the padding, so compare
     //   rate256 * g / roundup(g,256)   with   rate128 * g / roundup(g,128)
     const int g = p.q_group_len;
     const int64_t pad256 = ((g + 255) / 256) * 256, pad128 = ((g + 127) / 128) * 128;
-    block_rows = (pad256 * 100 > pad128 * 104) ? 128 : 256;
+    block_rows = (pad256 * 100 > pad128 * 106) ? 128 : 256;
   }
   p.blocks_per_group = (p.q_group_len + block_rows - 1) / block_rows;
   const int nblk = (p.n_kv + KVB - 1) / KVB;
