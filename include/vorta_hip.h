@@ -97,7 +97,8 @@ typedef struct vorta_attn_args {
   const int32_t* n_kv_dev;
   const int32_t* q_valid_dev;
   int32_t variant; /* kernel body: 0 = auto = 2; 1 = plain (attn_fwd_kernel<T,NW>), 2 = software-pipelined, scores one
-                      key block ahead, K/V tiles by LDS-DMA (attn_fwd_pipe_kernel<T,NW,KVTAB,DMA>) */
+                      key block ahead, K/V tiles by LDS-DMA, softmax folded into the score MFMA
+                      (attn_fwd_pipe_kernel<T,NW,KVTAB>) */
   int32_t reserved;
 } vorta_attn_args;
 
@@ -111,7 +112,7 @@ int vorta_attn_fwd_batch(const vorta_attn_args* args, int32_t n, void* hip_strea
  * 256 -> attn_fwd_kernel<T,8>) and the number of workgroups; pure host computation */
 int vorta_attn_plan(const vorta_attn_args* args, int32_t* block_rows, int64_t* n_workgroups, int32_t* kernel_id);
 /* kernel_id = waves*16 + (pipelined ? 1 : 0) + (pipelined with kv table ? 2 : 0):
- *   attn_fwd_kernel<T,NW> (plain) or attn_fwd_pipe_kernel<T,NW,KVTAB,DMA> */
+ *   attn_fwd_kernel<T,NW> (plain) or attn_fwd_pipe_kernel<T,NW,KVTAB> */
 /* bytes of ws_o and ws_ml for a given launch (0,0 when n_splits <= 1) */
 int vorta_attn_workspace_bytes(const vorta_attn_args* args, uint64_t* ws_o_bytes, uint64_t* ws_ml_bytes);
 

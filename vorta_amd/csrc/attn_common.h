@@ -32,7 +32,7 @@ struct Params {
   float scale_log2;  // scale * log2(e)
   int n_splits, blocks_per_split;
   float* ws_o; float* ws_ml;
-  int xcd_remap, dma;
+  int xcd_remap;
   float defer_log2;  // online-softmax rescale is skipped while the row max grows by <= this (log2 units)
 };
 

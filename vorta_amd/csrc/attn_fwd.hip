@@ -278,303 +278,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
   }
 }
 
-// Same kernel with the scores computed one key block ahead (software pipeline across blocks): the MFMAs of
-// QK(j+1) are independent of the softmax of block j, so the wave has matrix work to issue while its VALU
-// is busy, and the two waves of a SIMD no longer need to be in opposite phases to overlap.
-template <typename T, int NW, bool KVTAB>
-__device__ __forceinline__ void attn_pipe_body(const Params& p, char* __restrict__ smem, const int wg) {
-  using V8 = typename MF<T>::v8;
-  using V4 = typename MF<T>::v4;
-  constexpr int NT = NW * 64;
-  constexpr int QB = NW * 32;
-  constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
-  constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
-  const int sp = wg % p.n_splits;
-  const int rest = wg / p.n_splits;
-  const int n_qb = p.n_groups * p.blocks_per_group;
-  const int qb = rest % n_qb;
-  const int y = rest / n_qb;
-  if (p.n_heads_dev && y >= *p.n_heads_dev) return;
-  const int head = p.head_list ? p.head_list[y] : y;
-  const int grp = qb / p.blocks_per_group;
-  const int bi = qb - grp * p.blocks_per_group;
-  const int p0 = grp * p.q_group_len + bi * QB;
-  const int pend = min((grp + 1) * p.q_group_len, p.n_q);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r32 = lane & 31;
-  const int hh = lane >> 5;
-
-  // ---- key block range of this split (n_kv / q_valid may live on the device: no host sync) ----
-  const int n_kv = p.n_kv_dev ? max(1, min(*p.n_kv_dev, p.n_kv)) : p.n_kv;
-  const int q_valid = p.q_valid_dev ? min(*p.q_valid_dev, p.q_valid) : p.q_valid;
-  const int nblk_total = (n_kv + KVB - 1) / KVB;
-  const int blk0 = sp * p.blocks_per_split;
-  const int blk1 = min(blk0 + p.blocks_per_split, nblk_total);
-
-  // ---- query rows ----
-  const int wrow0 = p0 + wave * 32;
-  const bool wave_active = wrow0 < pend;  // wave-uniform
-  const int my_p = wrow0 + r32;
-  const bool row_ok = my_p < pend;
-  const int ld_p = min(my_p, pend - 1);
-  const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
-  const int64_t my_row = q_rows ? (int64_t)q_rows[ld_p] : (int64_t)(p.q_row_offset + ld_p);
-
-  V8 qf[8];
-  {
-    const char* qp = p.q + (int64_t)head * p.q_sh + my_row * p.q_ss + hh * 16;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const V8*)(qp + ks * 32);
-  }
-
-  // ---- loader setup ----
-  const int32_t* kv_rows =
-      p.kv_rows ? p.kv_rows + (int64_t)y * p.kv_rows_sh + (int64_t)grp * p.kv_rows_sg : nullptr;
-  const char* kbase = p.k + (int64_t)head * p.k_sh + (tid & 15) * 16;
-  const char* vbase = p.v + (int64_t)head * p.v_sh + (tid & 15) * 16;
-  const int lrow0 = tid >> 4;
-  const int lcc = tid & 15;
-  int k_wr[CH], v_wr[CH];
-#pragma unroll
-  for (int i = 0; i < CH; ++i) {
-    const int row = lrow0 + i * ROWSTEP;
-    k_wr[i] = row * ROWB + ((lcc ^ (row & 15)) << 4);
-    v_wr[i] = 2 * TILE_BYTES + row * ROWB + ((lcc ^ ((row & 3) << 2)) << 4);
-  }
-  // K(b) is staged one block ahead of V(b): block b's keys are needed by iteration b-1 (scores are computed
-  // one block ahead of the PV product), its values by iteration b.  Rings: K tiles at [0,32K), V at [32K,64K).
-  u32x4 kreg[CH], vreg[CH];
-  // K / V rows are fetched with buffer loads: wave-uniform descriptor on the head's base, 32-bit byte offset
-  // per lane (row * stride via the full-rate 24-bit multiply) -- no 64-bit address arithmetic in the loop.
-  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.k + (int64_t)head * p.k_sh), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(p.v + (int64_t)head * p.v_sh), 0, 0x7fffffff, 0x00020000);
-  const int k_ss32 = (int)p.k_ss, v_ss32 = (int)p.v_ss, lane_col = (tid & 15) * 16;
-  int rowK[CH], rowV[CH];  // rows of the next K block / next V block to fetch
-#define ROWS_OF(dst_, blk_)                                                       \
-  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
-    const int pos_ = min((blk_) * KVB + lrow0 + i_ * ROWSTEP, n_kv - 1);          \
-    if constexpr (KVTAB) dst_[i_] = kv_rows[pos_];                                \
-    else dst_[i_] = p.kv_row_offset + pos_;                                       \
-  }
-#define LOAD_K() _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) kreg[i_] = __builtin_amdgcn_raw_buffer_load_b128( \
-      k_rsrc, (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + lane_col, 0, 0);
-#define LOAD_V() _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) vreg[i_] = __builtin_amdgcn_raw_buffer_load_b128( \
-      v_rsrc, (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + lane_col, 0, 0);
-#define WRITE_K(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) *(u32x4*)(smem + (par_) * TILE_BYTES + k_wr[i_]) = kreg[i_];
-#define WRITE_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) *(u32x4*)(smem + (par_) * TILE_BYTES + v_wr[i_]) = vreg[i_];
-
-  // ---- LDS read addresses ----
-  int k_rd[8];
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) k_rd[ks] = r32 * ROWB + (((2 * ks + hh) ^ (r32 & 15)) << 4);
-  int v_rd[4];
-  {
-    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      v_rd[dt] = 2 * TILE_BYTES + (4 * (g >> 1) + q4) * ROWB + ((dt ^ q4) << 6) + 32 * (g & 1) + 8 * pp;
-  }
-
-  f32x16 o[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const float c = p.scale_log2;
-  f32x16 sA0, sA1, sB0, sB1;  // scores of the current / next key block (roles swap every block)
-
-  // scores of a block from the K ring slot `par_` into (d0_, d1_); the tail mask is applied by the consumer
-#define QK(d0_, d1_, par_)                                                        \
-  {                                                                               \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { d0_[i_] = 0.f; d1_[i_] = 0.f; } \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
-      const V8 k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);        \
-      const V8 k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
-      d0_ = MF<T>::mfma(k0_, qf[ks_], d0_);                                       \
-      d1_ = MF<T>::mfma(k1_, qf[ks_], d1_);                                       \
-    }                                                                             \
-  }
-#define STAGE_WRITE(par_)                                                         \
-  /* K(j+2) into the slot K(j) left, V(j+1) into the slot V(j-1) left (loaded during the previous step) */ \
-  WRITE_K(par_)                                                                   \
-  WRITE_V((par_) ^ 1)                                                             \
-  __builtin_amdgcn_sched_barrier(0);
-#define STAGE_LOAD(j_)                                                            \
-  /* fetch K(j+3), V(j+2): issued between the two MFMA phases, landed by the next step's STAGE_WRITE */ \
-  __builtin_amdgcn_sched_barrier(0);                                              \
-  LOAD_K()                                                                        \
-  LOAD_V()                                                                        \
-  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
-  ROWS_OF(rowK, (j_) + 4)                                                         \
-  __builtin_amdgcn_sched_barrier(0);
-
-#ifndef VORTA_SCHED
-#define VORTA_SCHED 0
-#endif
-#if VORTA_SCHED == 1
-  // QK phase: per MFMA gap 2 exp + 4 plain VALU + 2 LDS reads; PV phase: per gap 2 VALU + 2 LDS reads
-#define SCHED_RECIPE()                                                            \
-  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
-  }
-#else
-#define SCHED_RECIPE()
-#endif
-
-  // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
-  // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
-  // all visible to the scheduler together.
-#define STEP(c0_, c1_, n0_, n1_, par_, j_)                                        \
-  {                                                                               \
-    STAGE_WRITE(par_)                                                             \
-    if (wave_active) {                                                            \
-      if ((j_) * KVB + KVB > n_kv) {                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
-          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
-          if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
-          if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
-        }                                                                         \
-      }                                                                           \
-      float mx_ = c0_[0];                                                         \
-      _Pragma("unroll") for (int i_ = 1; i_ < 16; ++i_) mx_ = fmaxf(mx_, c0_[i_]); \
-      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, c1_[i_]); \
-      mx_ = half_max(mx_);                                                        \
-      const float m_new_ = fmaxf(m_run, mx_);                                     \
-      if (!__all(m_new_ == m_run)) {                                              \
-        const float alpha_ = __builtin_amdgcn_exp2f((m_run - m_new_) * c);        \
-        _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                       \
-          _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_; \
-        l_run *= alpha_;                                                          \
-        m_run = m_new_;                                                           \
-      }                                                                           \
-      V8 pb_[4];                                                                  \
-      QK(n0_, n1_, (par_) ^ 1) /* block j+1 (harmless garbage past the end) */    \
-      const float mc_ = m_run * c;                                                \
-      float lsum_ = 0.f;                                                          \
-      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
-        c0_[i_] = __builtin_amdgcn_exp2f(fmaf(c0_[i_], c, -mc_));                 \
-        c1_[i_] = __builtin_amdgcn_exp2f(fmaf(c1_[i_], c, -mc_));                 \
-        lsum_ += c0_[i_] + c1_[i_];                                               \
-      }                                                                           \
-      l_run += lsum_;                                                             \
-      _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                          \
-        pb_[0][e_] = (T)c0_[e_];                                                  \
-        pb_[1][e_] = (T)c0_[8 + e_];                                              \
-        pb_[2][e_] = (T)c1_[e_];                                                  \
-        pb_[3][e_] = (T)c1_[8 + e_];                                              \
-      }                                                                           \
-      STAGE_LOAD(j_)                                                              \
-      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
-        _Pragma("unroll") for (int kg_ = 0; kg_ < 4; ++kg_) {                     \
-          const V4 lo_ = MF<T>::tr(smem + (par_) * TILE_BYTES + v_rd[dt_] + (16 * kg_) * ROWB); \
-          const V4 hi_ = MF<T>::tr(smem + (par_) * TILE_BYTES + v_rd[dt_] + (16 * kg_ + 8) * ROWB); \
-          V8 vf_;                                                                 \
-          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { vf_[e_] = lo_[e_]; vf_[4 + e_] = hi_[e_]; } \
-          o[dt_] = MF<T>::mfma(vf_, pb_[kg_], o[dt_]);                            \
-        }                                                                         \
-      }                                                                           \
-      SCHED_RECIPE()                                                              \
-    } else {                                                                      \
-      STAGE_LOAD(j_)                                                              \
-    }                                                                             \
-    __syncthreads();                                                              \
-  }
-
-  if (blk0 < blk1) {
-    // prologue: K(0),V(0) -> ring slot 0, K(1) -> slot 1; registers then hold K(2), V(1)
-    ROWS_OF(rowK, blk0)
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-    LOAD_K()
-    LOAD_V()
-    ROWS_OF(rowK, blk0 + 1)
-    WRITE_K(0)
-    WRITE_V(0)
-    LOAD_K()
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-    ROWS_OF(rowK, blk0 + 2)
-    WRITE_K(1)
-    LOAD_K()
-    LOAD_V()
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-    ROWS_OF(rowK, blk0 + 3)
-    __syncthreads();
-    if (wave_active) QK(sA0, sA1, 0)
-    __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
-  }
-  for (int blk = blk0; blk < blk1; blk += 2) {
-    STEP(sA0, sA1, sB0, sB1, 0, blk)
-    if (blk + 1 >= blk1) break;
-    STEP(sB0, sB1, sA0, sA1, 1, blk + 1)
-  }
-#undef QK
-#undef STEP
-#undef STAGE_LOAD
-#undef STAGE_WRITE
-#undef ROWS_OF
-#undef LOAD_K
-#undef LOAD_V
-#undef WRITE_K
-#undef WRITE_V
-
-  if (!wave_active) return;
-  // ---------------- epilogue ----------------
-  const float l_tot = half_sum(l_run);
-  if (p.n_splits > 1) {
-    // unnormalised partials: ws_o[y][sp][pos][d], ws_ml[y][sp][pos][2]
-    if (row_ok) {
-      const int64_t slot = ((int64_t)y * p.n_splits + sp) * p.n_q + my_p;
-      float* wo = p.ws_o + slot * D;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          f32x4 v = {o[dt][4 * rg], o[dt][4 * rg + 1], o[dt][4 * rg + 2], o[dt][4 * rg + 3]};
-          *(f32x4*)(wo + 32 * dt + 8 * rg + 4 * hh) = v;
-        }
-      if (hh == 0) {
-        p.ws_ml[slot * 2] = m_run * c;  // exp2 domain
-        p.ws_ml[slot * 2 + 1] = l_tot;
-      }
-    }
-    return;
-  }
-  if (!row_ok) return;
-  const float inv = (my_p < q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
-  uint2 packed[16];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      V4 t;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t[j] = (T)(o[dt][4 * rg + j] * inv);
-      packed[dt * 4 + rg] = *(uint2*)&t;
-    }
-  char* obase = p.o + (int64_t)head * p.o_sh + hh * 8;
-  auto store_row = [&](int64_t row) {
-    char* op = obase + row * p.o_ss;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) *(uint2*)(op + (32 * dt + 8 * rg) * 2) = packed[dt * 4 + rg];
-  };
-  store_row(my_row);
-  if (p.dup_rows && my_p < p.n_dup_pos) {
-    const int32_t* dr = p.dup_rows + (int64_t)y * p.dup_rows_sh + (int64_t)my_p * p.n_dup;
-    for (int i = 0; i < p.n_dup; ++i) store_row((int64_t)dr[i]);
-  }
-}
-
-
+// The default kernel: scores computed one key block ahead (software pipeline across blocks), K/V tiles staged
+// global -> LDS by DMA, softmax folded into the score MFMA.  See the notes inside and DESIGN.md (d).
 template <typename T, int NW, bool KVTAB>
 __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __restrict__ smem, const int wg) {
   using V8 = typename MF<T>::v8;
@@ -924,7 +629,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 }
 
 
-template <typename T, int NW, bool KVTAB, bool DMA>
+template <typename T, int NW, bool KVTAB>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
@@ -937,8 +642,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   } else {
     wg = blockIdx.x;
   }
-  if constexpr (DMA) attn_pipe_dma_body<T, NW, KVTAB>(p, smem, wg);
-  else attn_pipe_body<T, NW, KVTAB>(p, smem, wg);
+  attn_pipe_dma_body<T, NW, KVTAB>(p, smem, wg);
 #endif
 }
 
@@ -1016,13 +720,8 @@ int launch(const Params& p, hipStream_t st, bool pipe) {
   if (total > 0x7fffffff) return VORTA_EINVAL;
   hipError_t e;
   if (pipe) {
-    if (p.dma) {
-      if (p.kv_rows) hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, true, true>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
-      else hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, false, true>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
-    } else {
-      if (p.kv_rows) hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, true, false>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
-      else hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, false, false>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
-    }
+    if (p.kv_rows) hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, true>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
+    else hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, NW, false>), dim3((unsigned)total), dim3(NW * 64), 0, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return vorta_set_hip_error(e);
   } else {
@@ -1073,7 +772,6 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   p.scale_log2 = a->scale * 1.4426950408889634f;
   p.n_splits = a->n_splits; p.ws_o = a->ws_o; p.ws_ml = a->ws_ml;
   p.xcd_remap = (a->reserved & 1) ? 0 : 1;  // experiment knobs: bit0 disables the XCD remap,
-  p.dma = (a->reserved & 2) ? 0 : 1;        //   bit1 selects register staging instead of LDS-DMA (pipelined kernel)
   p.defer_log2 = (a->reserved & 4) ? 0.f : 6.f;  // bit2 turns the deferred rescale off (exact running max)
   p.n_groups = (p.n_q + p.q_group_len - 1) / p.q_group_len;
   block_rows = a->block_rows;

@@ -142,7 +142,7 @@ def _plan(a) -> Tuple[int, int, str]:
     _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg), C.byref(kid)), "vorta_attn_plan")
     tname = "_Float16" if a.dtype == _C.VORTA_FP16 else "__bf16"
     nw, kk = kid.value // 16, kid.value % 16
-    sym = (f"attn_fwd_pipe_kernel<{tname},{nw},{'true' if kk & 2 else 'false'},{'false' if NO_XCD_REMAP & 2 else 'true'}>" if kk & 1
+    sym = (f"attn_fwd_pipe_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>" if kk & 1
            else f"attn_fwd_kernel<{tname},{nw}>")
     return br.value, nwg.value, sym
 
