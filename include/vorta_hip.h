@@ -195,6 +195,14 @@ int vorta_router_route(const vorta_router_args* args, void* hip_stream);
 /* Same dispatch rule applied to scores that already exist (the `routing_score` argument of the processors,
  * hunyuan.py:528): uses temb/weight/bias = NULL, `scores` as INPUT [batch][heads][n_experts], no workspace. */
 int vorta_route_scores(const vorta_router_args* args, void* hip_stream);
+/* Route plan: the router input is the pure timestep embedding (modeling_hunyuan.py:627-628,
+ * modeling_wan.py:215), the same for every block, so all layers' routes are known at the start of a denoising
+ * step.  One call (2 launches) for n_layers routers sharing `temb`: every array gains a leading [n_layers]
+ * dimension -- weight [L][heads*n_experts][embed_dim], bias [L][heads*n_experts], scores [L][batch][heads][n_experts],
+ * expert_of_head [L][heads], head_lists [L][n_experts][heads], head_counts [L][n_experts], ws_logits
+ * [L][batch][heads][n_experts].  The reference runs one Router module per block inside the block's forward
+ * (modeling_hunyuan.py:491,555; modeling_wan.py:127). */
+int vorta_route_plan(const vorta_router_args* args, int32_t n_layers, void* hip_stream);
 
 /*
  * vorta_qk_norm_rope -- the producer step right before the attention boundary, in place:

@@ -1,16 +1,43 @@
-"""Import alias: `import vorta.attention`, `vorta.patch.utils`, `vorta.ulysses`, `vorta.utils` resolve to the
-MI355X-native implementation in `vorta_amd`, so code written against the reference's package name
-(scripts/hunyuan/inference.py:27-39) imports unchanged.  The model / pipeline monkey-patch modules
-(`vorta.patch.modeling_*`, `vorta.patch.pipeline_*`) are not re-stated yet (they need `diffusers`)."""
+"""Import alias: every `vorta.X` module IS the `vorta_amd.X` module (same object), so code written against the
+reference's package name -- `vorta.attention`, `vorta.patch.modeling_hunyuan`, `vorta.patch.pipeline_wan`,
+`vorta.patch.utils`, `vorta.ulysses`, `vorta.utils` (scripts/hunyuan/inference.py:27-44, scripts/wan/inference.py:32-49)
+-- imports unchanged and shares all state (SP_STATE, pipeline registry) with the native package."""
 import importlib
+import importlib.abc
+import importlib.util
 import sys
 
 import vorta_amd
 
-for _name in ("attention", "attention.coreset_select", "attention.hunyuan", "attention.wan", "patch", "patch.router",
-              "patch.utils", "ulysses", "utils"):
-    sys.modules[f"{__name__}.{_name}"] = importlib.import_module(f"vorta_amd.{_name}")
-attention = sys.modules[f"{__name__}.attention"]
-patch = sys.modules[f"{__name__}.patch"]
-ulysses = sys.modules[f"{__name__}.ulysses"]
-utils = sys.modules[f"{__name__}.utils"]
+
+class _AliasLoader(importlib.abc.Loader):
+    def __init__(self, real_name):
+        self.real_name = real_name
+
+    def create_module(self, spec):
+        return importlib.import_module(self.real_name)
+
+    def exec_module(self, module):  # already executed under its real name
+        pass
+
+
+class _AliasFinder(importlib.abc.MetaPathFinder):
+    def find_spec(self, fullname, path=None, target=None):
+        if not fullname.startswith(__name__ + "."):
+            return None
+        real = "vorta_amd" + fullname[len(__name__):]
+        try:
+            if importlib.util.find_spec(real) is None:
+                return None
+        except ModuleNotFoundError:
+            return None
+        return importlib.util.spec_from_loader(fullname, _AliasLoader(real))
+
+
+if not any(isinstance(f, _AliasFinder) for f in sys.meta_path):
+    sys.meta_path.insert(0, _AliasFinder())
+
+attention = importlib.import_module(__name__ + ".attention")
+patch = importlib.import_module(__name__ + ".patch")
+ulysses = importlib.import_module(__name__ + ".ulysses")
+utils = importlib.import_module(__name__ + ".utils")

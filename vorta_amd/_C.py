@@ -88,6 +88,7 @@ SYMBOLS = {
     "vorta_sta_build_tables": (C.c_int, [C.POINTER(StaArgs), _vp]),
     "vorta_router_route": (C.c_int, [C.POINTER(RouterArgs), _vp]),
     "vorta_route_scores": (C.c_int, [C.POINTER(RouterArgs), _vp]),
+    "vorta_route_plan": (C.c_int, [C.POINTER(RouterArgs), C.c_int32, _vp]),
     "vorta_qk_norm_rope": (C.c_int, [C.POINTER(NormRopeArgs), _vp]),
     "vorta_seq_row_map": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "vorta_abi_version": (C.c_int, []),

@@ -28,7 +28,7 @@ def _layout(H, S, T, D, device, dtype):
 
 def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_sparse: Optional[float], *, model: str,
                  text_valid: int = 0, attention_mask=None, lowres_group_info=None, window_size=(3, 3, 3),
-                 tile_size=(6, 8, 8), latent_shape=None) -> torch.Tensor:
+                 tile_size=(6, 8, 8), latent_shape=None, experts_host=None) -> torch.Tensor:
     """q,k,v: (1, H, S/P + T, D) local sequence shard with the replicated text at the end.
     Returns the attention output as a (1, S/P + T, H, D) buffer (text rows: all heads, gathered)."""
     B, H, N, D = q.shape
@@ -39,7 +39,13 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     lay, bufs = _layout(H, S, T, D, q.device, q.dtype)
     if routing_score is None:  # dense for every head
         experts = [0] * H
-        te = T if attention_mask is None else int(attention_mask.sum().item()) - S  # host read, as hunyuan.py:169
+        te = T
+        if attention_mask is not None:  # host read, as hunyuan.py:169; the mask covers the global video (reference's
+            # patched forward, modeling_hunyuan.py:86-88) or the local shard (stock diffusers forward)
+            te = int(attention_mask.sum().item()) - (attention_mask.shape[-1] - T)
+    elif experts_host is not None:  # dispatched by the step's route plan: no device read in this layer
+        experts = list(experts_host)
+        te = text_valid
     else:
         # balanced placement needs the routes on the host: one small read per layer (the reference reads
         # torch.nonzero per expert, hunyuan.py:633); routes depend only on the timestep

@@ -5,7 +5,7 @@ and the patched block forwards (modeling_hunyuan.py:492-499,556-563) can call th
 RMSNorm and RoPE stay in torch (rocBLAS); everything between post-RoPE q,k,v and the output projection runs in
 libvorta_hip.so (vorta_amd/routed.py).
 """
-from typing import Callable, Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -115,11 +115,13 @@ class HunyuanVideoFlashAttnProcessor:
         return buf, buf.permute(0, 2, 1, 3)  # (B,H,N,D) view for the kernels
 
     @staticmethod
-    def _text_valid(attention_mask: torch.Tensor, n_video: int, descriptor=None) -> int:
+    def _text_valid(attention_mask: torch.Tensor, T: int, descriptor=None) -> int:
         if descriptor is not None:
             return descriptor.text_seq_length_no_pad
-        # the reference reads this on the host as well (hunyuan.py:169 `attention_mask.squeeze().sum()`)
-        return int(attention_mask.sum().item()) - n_video * (SP_STATE.sp_size if SP_STATE.enabled else 1)
+        # the reference reads this on the host as well (hunyuan.py:169 `attention_mask.squeeze().sum()`).  The mask
+        # spans [video | text]: the global video under the reference's patched forward (modeling_hunyuan.py:86-88),
+        # the local shard under the stock diffusers forward -- either way its video part is all ones.
+        return int(attention_mask.sum().item()) - (attention_mask.shape[-1] - T)
 
     def _dense(self, q, k, v, attention_mask, T):
         B = q.shape[0]
@@ -169,24 +171,29 @@ class HunyuanVideoFlashAttnProcessorTripleEval(HunyuanVideoFlashAttnProcessor):
                  lowres_group_info: Optional[LowresGroupInfo] = None,
                  flex_attn_mask_func: Optional[SlidingTileDescriptor] = None,
                  window_size: Tuple[int, int, int] = (3, 3, 3), tile_size: Tuple[int, int, int] = (6, 8, 8),
-                 latent_shape: Tuple[int, int, int] = (30, 48, 80)):
+                 latent_shape: Tuple[int, int, int] = (30, 48, 80),
+                 head_routing: Optional[HeadRouting] = None, experts_host: Optional[List[int]] = None):
+        """Keyword names as hunyuan.py:521-539.  `head_routing` / `experts_host` are this build's additions: the
+        routes of this layer already dispatched by the step's route plan (vorta_amd/patch/_engine.py), on the device /
+        on the host; without them the dispatch runs here from `routing_score`."""
         self._check_input(hidden_states, lowres_group_info, latent_shape, window_size, tile_size)
         q, k, v, T = self._project(attn, hidden_states, encoder_hidden_states, image_rotary_emb)
         assert q.shape[0] == 1, f"Batch size {q.shape[0]} is not supported for {self.__class__.__name__}."
-        te = self._text_valid(attention_mask, q.shape[2] - T, flex_attn_mask_func)
+        te = self._text_valid(attention_mask, T, flex_attn_mask_func)
         if SP_STATE.enabled:
             from ._sp import sp_attention
             buf = sp_attention(q, k, v, T, routing_score, tau_sparse, model="hunyuan", text_valid=te,
                                lowres_group_info=lowres_group_info, window_size=window_size, tile_size=tile_size,
-                               latent_shape=latent_shape)
+                               latent_shape=latent_shape, experts_host=experts_host)
             return self._output(attn, buf, T)
         geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
                             lowres_group_info.reduction_rate, q.device)
         # top-1 / tau dispatch on the device: no torch.nonzero host sync (hunyuan.py:612-640)
-        _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+        if head_routing is None:
+            _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+            head_routing = HeadRouting.from_device(lists, counts)
         buf, out = self._new_out(q)
-        routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,
-                         text_valid=te, out=out)
+        routed_attention(q, k, v, head_routing, geom, model="hunyuan", text_len=T, text_valid=te, out=out)
         return self._output(attn, buf, T)
 
 

@@ -3,7 +3,7 @@
 Same classes, call protocol and keyword names as vorta/attention/wan.py.  Only self attention is routed
 (modeling_wan.py:215-229); cross attention and `use_original_attn` go through the dense kernel.
 """
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -144,7 +144,9 @@ class WanAttnProcessorTripleEval(WanAttnProcessor2_0):
                  lowres_group_info: Optional[LowresGroupInfo] = None,
                  flex_attn_mask_func: Optional[SlidingTileDescriptor] = None,
                  window_size: Tuple[int, int, int] = (3, 3, 3), tile_size: Tuple[int, int, int] = (6, 8, 8),
-                 latent_shape: Tuple[int, int, int] = (20, 30, 52), use_original_attn: bool = False):
+                 latent_shape: Tuple[int, int, int] = (20, 30, 52), use_original_attn: bool = False,
+                 head_routing: Optional[HeadRouting] = None, experts_host: Optional[List[int]] = None):
+        """Keyword names as wan.py:308-328; `head_routing` / `experts_host`: see the Hunyuan processor."""
         if encoder_hidden_states is not None or use_original_attn:
             return WanAttnProcessor2_0.__call__(self, attn, hidden_states, encoder_hidden_states, attention_mask,
                                                 rotary_emb)
@@ -154,13 +156,16 @@ class WanAttnProcessorTripleEval(WanAttnProcessor2_0):
         if SP_STATE.enabled:
             from ._sp import sp_attention
             buf = sp_attention(q, k, v, 0, routing_score, tau_sparse, model="wan", lowres_group_info=lowres_group_info,
-                               window_size=window_size, tile_size=tile_size, latent_shape=latent_shape)
+                               window_size=window_size, tile_size=tile_size, latent_shape=latent_shape,
+                               experts_host=experts_host)
             return self._output_proj(attn, buf)
         geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
                             lowres_group_info.reduction_rate, q.device)
-        _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+        if head_routing is None:
+            _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+            head_routing = HeadRouting.from_device(lists, counts)
         buf, out = self._new_out(q)
-        routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="wan", out=out)
+        routed_attention(q, k, v, head_routing, geom, model="wan", out=out)
         return self._output_proj(attn, buf)
 
 

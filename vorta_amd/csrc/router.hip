@@ -32,8 +32,9 @@ __global__ __launch_bounds__(256) void router_logits_kernel(const RParams p) {
   const int n_out = p.H * p.NE;
   if (item >= p.batch * n_out) return;
   const int b = item / n_out, o = item - b * n_out;
+  const int layer = blockIdx.y;  // vorta_route_plan: one grid row per layer, same temb for all of them
   const T* x = (const T*)p.temb + (int64_t)b * p.E;
-  const T* w = (const T*)p.w + (int64_t)o * p.E;
+  const T* w = (const T*)p.w + ((int64_t)layer * n_out + o) * p.E;
   float acc = 0.f;
   const int e8 = p.E & ~7;
   for (int i = lane * 8; i < e8; i += 512) {
@@ -51,16 +52,21 @@ __global__ __launch_bounds__(256) void router_logits_kernel(const RParams p) {
   }
 #pragma unroll
   for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-  if (lane == 0) p.logits[item] = rnd<T>(acc + (float)((const T*)p.b)[o]);
+  if (lane == 0)
+    p.logits[(int64_t)layer * p.batch * n_out + item] = rnd<T>(acc + (float)((const T*)p.b)[(int64_t)layer * n_out + o]);
 }
 
 template <typename T>
 __global__ __launch_bounds__(64) void router_route_kernel(const RParams p) {
   const int lane = threadIdx.x;
+  const int layer = blockIdx.x;
   __shared__ int s_expert[1024];
+  int32_t* const expert = p.expert + (int64_t)layer * p.H;
+  int32_t* const lists = p.lists + (int64_t)layer * p.NE * p.H;
   for (int it = lane; it < p.batch * p.H; it += 64) {
     const int b = it / p.H, h = it - b * p.H;
-    const float* lg = p.logits + (int64_t)it * p.NE;
+    const int64_t git = (int64_t)layer * p.batch * p.H + it;
+    const float* lg = p.logits + git * p.NE;
     float mx = lg[0];
     for (int e = 1; e < p.NE; ++e) mx = fmaxf(mx, lg[e]);
     float den = 0.f;
@@ -69,14 +75,14 @@ __global__ __launch_bounds__(64) void router_route_kernel(const RParams p) {
     float best_s = -1.f;
     for (int e = 0; e < p.NE; ++e) {
       const float sc = rnd<T>(__expf(lg[e] - mx) / den);
-      if (p.scores) ((T*)p.scores)[(int64_t)it * p.NE + e] = (T)sc;
+      if (p.scores) ((T*)p.scores)[git * p.NE + e] = (T)sc;
       if (sc > best_s) { best_s = sc; best = e; }  // first maximum wins (torch.topk on ties)
     }
     if (b == 0) {
       // hunyuan.py:623 `top1_score < tau_sparse`: torch compares a tensor with a Python scalar in the tensor's
       // dtype, i.e. tau is rounded to the score dtype first
       if (best_s < rnd<T>(p.tau)) best = 0;
-      p.expert[h] = best;
+      expert[h] = best;
       s_expert[h] = best;
     }
   }
@@ -84,8 +90,8 @@ __global__ __launch_bounds__(64) void router_route_kernel(const RParams p) {
   if (lane < p.NE) {
     int n = 0;
     for (int h = 0; h < p.H; ++h)
-      if (s_expert[h] == lane) p.lists[lane * p.H + n++] = h;
-    p.counts[lane] = n;
+      if (s_expert[h] == lane) lists[lane * p.H + n++] = h;
+    p.counts[layer * p.NE + lane] = n;
   }
 }
 
@@ -131,7 +137,19 @@ extern "C" int vorta_route_scores(const vorta_router_args* a, void* hip_stream) 
   return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
 }
 
-extern "C" int vorta_router_route(const vorta_router_args* a, void* hip_stream) {
+namespace {
+int route_layers(const vorta_router_args* a, int n_layers, void* hip_stream);
+}
+
+extern "C" int vorta_router_route(const vorta_router_args* a, void* hip_stream) { return route_layers(a, 1, hip_stream); }
+
+extern "C" int vorta_route_plan(const vorta_router_args* a, int32_t n_layers, void* hip_stream) {
+  if (n_layers <= 0 || n_layers > 65535) return VORTA_EINVAL;
+  return route_layers(a, n_layers, hip_stream);
+}
+
+namespace {
+int route_layers(const vorta_router_args* a, int n_layers, void* hip_stream) {
   if (!a || a->struct_size != sizeof(vorta_router_args)) return VORTA_EINVAL;
   if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
   if (a->batch <= 0 || a->embed_dim <= 0 || a->heads <= 0 || a->heads > 1024 || a->n_experts <= 0 || a->n_experts > 64)
@@ -143,13 +161,15 @@ extern "C" int vorta_router_route(const vorta_router_args* a, void* hip_stream) 
             a->scores, a->expert_of_head, a->head_lists, a->head_counts, a->ws_logits};
   hipStream_t st = (hipStream_t)hip_stream;
   const int items = p.batch * p.H * p.NE;
+  const dim3 lg((items + 3) / 4, n_layers);
   if (a->dtype == VORTA_BF16) {
-    hipLaunchKernelGGL(router_logits_kernel<__bf16>, dim3((items + 3) / 4), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(router_route_kernel<__bf16>, dim3(1), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(router_logits_kernel<__bf16>, lg, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(router_route_kernel<__bf16>, dim3(n_layers), dim3(64), 0, st, p);
   } else {
-    hipLaunchKernelGGL(router_logits_kernel<_Float16>, dim3((items + 3) / 4), dim3(256), 0, st, p);
-    hipLaunchKernelGGL(router_route_kernel<_Float16>, dim3(1), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(router_logits_kernel<_Float16>, lg, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(router_route_kernel<_Float16>, dim3(n_layers), dim3(64), 0, st, p);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
 }
+}  // namespace

@@ -289,6 +289,40 @@ def router_route(temb: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, h
     return scores, expert, lists, counts
 
 
+def route_plan(temb: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, heads: int, tau: float,
+               n_experts: int = 3, out=None):
+    """vorta_route_plan: the routes of ALL layers from one timestep embedding.
+    temb (B,E); weight (L,heads*n_experts,E); bias (L,heads*n_experts).  Returns
+    (scores (L,B,H,E'), expert_of_head (L,H), head_lists (L,E',H), head_counts (L,E')), all on device, no sync.
+    `out` = a previous result to overwrite in place (fixed addresses: hipGraph replay)."""
+    _require_gpu(temb, weight, bias)
+    B, E = temb.shape
+    L = weight.shape[0]
+    if weight.shape != (L, heads * n_experts, E) or bias.shape != (L, heads * n_experts):
+        raise ValueError(f"route_plan: weight {tuple(weight.shape)} / bias {tuple(bias.shape)} do not match "
+                         f"(L, {heads * n_experts}, {E})")
+    dev = temb.device
+    temb, weight, bias = temb.contiguous(), weight.contiguous(), bias.contiguous()
+    if out is None:
+        scores = torch.empty((L, B, heads, n_experts), dtype=temb.dtype, device=dev)
+        expert = torch.empty((L, heads), dtype=torch.int32, device=dev)
+        lists = torch.zeros((L, n_experts, heads), dtype=torch.int32, device=dev)
+        counts = torch.empty((L, n_experts), dtype=torch.int32, device=dev)
+    else:
+        scores, expert, lists, counts = out
+    ws = torch.empty(L * B * heads * n_experts, dtype=torch.float32, device=dev)
+    a = _C.RouterArgs()
+    a.struct_size = C.sizeof(_C.RouterArgs)
+    a.dtype = _DT[temb.dtype]
+    a.batch, a.embed_dim, a.heads, a.n_experts = B, E, heads, n_experts
+    a.temb, a.weight, a.bias = temb.data_ptr(), weight.data_ptr(), bias.data_ptr()
+    a.tau = tau
+    a.scores, a.expert_of_head = scores.data_ptr(), expert.data_ptr()
+    a.head_lists, a.head_counts, a.ws_logits = lists.data_ptr(), counts.data_ptr(), ws.data_ptr()
+    _C.check(_C.lib().vorta_route_plan(C.byref(a), L, _stream()), "vorta_route_plan")
+    return scores, expert, lists, counts
+
+
 def route_scores(scores: torch.Tensor, tau: float):
     """vorta_route_scores: top-1 / tau dispatch of an existing (B,H,E) score tensor (batch item 0 routes).
     Returns (expert_of_head (H,), head_lists (E,H), head_counts (E,)) on device, no host sync."""
