@@ -1,0 +1,45 @@
+"""GPU: bench.py's contract -- one JSON line with the required keys -- at N=1 and through the N>1 code path
+(2 ranks sharing the GPU, gloo host-staged rehearsal of the RCCL exchange), on the tiny configuration."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _line(out: str) -> dict:
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    r = subprocess.run([sys.executable, "bench.py", "--config", "tiny", "--steps", "2", "--warmup", "1"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert KEYS <= set(j) and "cpu_baseline" in j
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and j["vs_baseline"] is None
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(j["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(j["cpu_baseline"]) and "workload" in j["config"]
+
+
+def test_bench_two_rank_rehearsal():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                        "--config", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = _line(r.stdout)
+    assert KEYS <= set(j) and j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0

@@ -95,8 +95,27 @@ def _engine_worker(rank, world, port, ret):
     out_text = torch.full((H, T, D), -2.0)
     lay.gather_heads(bufs[0], out_shard, order, out_text)
     ok = ok and torch.equal(out_shard, shards[0]) and torch.equal(out_text, texts[0])
+    keep = lay.head_view(bufs[0]).clone().numpy()
+    # other transport shapes of the same exchange: heads of every peer already consecutive (sent straight from
+    # the shard, no staging pass), and strided shards / outputs (the projection's (Sl, H*D) buffer seen per head)
+    for order2, strided in ((list(range(H)), False), (order, True), (list(range(H)), True)):
+        sh2 = [x.transpose(0, 1).contiguous().transpose(0, 1) for x in shards] if strided else shards
+        assert sh2[0].is_contiguous() != strided
+        b2 = [lay.new_buffer().fill_(-1) for _ in range(3)]
+        lay.scatter_heads(sh2, b2, order2, texts)
+        for t in range(3):
+            hv = lay.head_view(b2[t])
+            for i in range(Hl):
+                h = order2[rank * Hl + i]
+                want = torch.cat([_tag(torch.tensor(float(h)), torch.arange(S).view(S, 1), dd[0]),
+                                  _tag(torch.tensor(float(h)), torch.arange(T).view(T, 1) + 90000, dd[0])]) + 1e7 * t
+                ok = ok and torch.equal(hv[i][rm], want)
+        o2 = torch.full((Sl, H, D), -2.0).transpose(0, 1) if strided else torch.full((H, Sl, D), -2.0)
+        t2 = torch.full((H, T, D), -2.0)
+        lay.gather_heads(b2[0], o2, order2, t2)
+        ok = ok and torch.equal(o2, shards[0]) and torch.equal(t2, texts[0])
     # the same layout expressed with the oracle's reference maps: seq->head of the head-permuted shard
-    ret[rank] = (bool(ok), order, shards[0].numpy(), lay.head_view(bufs[0]).clone().numpy(), rm.numpy())
+    ret[rank] = (bool(ok), order, shards[0].numpy(), keep, rm.numpy())
     dist.barrier()
     dist.destroy_process_group()
 

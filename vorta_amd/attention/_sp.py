@@ -73,13 +73,9 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     else:
         routed_attention(qv, kv, vv, HeadRouting.from_expert_ids(local, q.device), geom, model=model, text_len=T,
                          text_valid=te, out=ov)
-    out_h = torch.empty((H, Sl, D), dtype=q.dtype, device=q.device)
-    out_t = torch.empty((H, T, D), dtype=q.dtype, device=q.device) if T else None
-    lay.gather_heads(bufs[3], out_h, order, out_t)
+    # the received heads are written straight into the (1, N, H, D) result the output projection reads
     buf = torch.empty((1, N, H, D), dtype=q.dtype, device=q.device)
-    buf[0, :Sl] = out_h.transpose(0, 1)
-    if T:
-        buf[0, Sl:] = out_t.transpose(0, 1)
+    lay.gather_heads(bufs[3], buf[0, :Sl].transpose(0, 1), order, buf[0, Sl:].transpose(0, 1) if T else None)
     return buf
 
 

@@ -4,13 +4,13 @@ Reference flow per tensor (vorta/ulysses/utils.py:61-91): transpose+contiguous -
 device sync -> transpose+contiguous, i.e. four extra HBM passes per tensor and a host stall, applied per
 routed subset (hunyuan.py:153-155,425-427,483-485), which also forces h_e % P == 0.
 
-Here every head of the local sequence shard is sent as ONE contiguous (S/P, D) message straight from the
-projection output into its final place in the receiver's buffer, and the attention kernels read that
-buffer in place through a row table (`row_map`): token s of local head slot i lives at row
+Here the heads of the local sequence shard bound for one peer travel as ONE contiguous (H/P, S/P, D) message
+into their final place in the receiver's buffer, and the attention kernels read that buffer in place through
+a row table (`row_map`): token s of local head slot i lives at row
     (s // Sl) * (Hl*Sl) + i*Sl + s % Sl                      (Sl = S/P, Hl = H/P)
-so no pack/unpack kernel exists on either side.  The output travels back the same way.  All H heads are
-resharded once, BEFORE routing (any expert mix works), and because messages are per head the head -> rank
-placement is free: `balanced_head_order` gives every rank the same number of heads and a near-equal sum
+so the receive side has no unpack pass (the send side orders the heads with one gather pass, or none when they
+already are).  The output travels back the same way.  All H heads are resharded once, BEFORE routing (any expert
+mix works), and the head -> rank placement is free: `balanced_head_order` gives every rank the same number of heads and a near-equal sum
 of expert costs (routes depend only on the timestep, so they are known when the layer starts).
 Text tokens are replicated: each rank copies its heads' text rows behind the video rows
 (`shrink_dim` in the reference, hunyuan.py:158-160) and the text outputs are all-gathered over heads (:187).
@@ -97,25 +97,52 @@ class UlyssesLayout:
             if k == "recv":
                 t.copy_(h)
 
+    def _stage(self, key):
+        """(H, Sl, D) staging buffers in head_order (one per tensor slot), allocated once per layout."""
+        st = self.__dict__.setdefault("_stages", {})
+        if key not in st:
+            st[key] = torch.empty((self.H, self.Sl, self.D), dtype=self.dtype, device=self.device)
+        return st[key]
+
+    @staticmethod
+    def _run_of(order: Sequence[int], lo: int, n: int) -> Optional[int]:
+        """first head if order[lo:lo+n] is a run of consecutive heads, else None"""
+        a = order[lo]
+        return a if all(order[lo + i] == a + i for i in range(n)) else None
+
     # ---- sequence shards -> head shards -------------------------------------------------------------
     def scatter_heads(self, shards: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor], head_order: Sequence[int],
                       texts: Optional[Sequence[torch.Tensor]] = None):
-        """shards[t]: (H, Sl, D) sequence shard of tensor t (q, k, v); bufs[t]: its layout buffer.
-        One grouped send/recv for all tensors of the layer."""
-        Hl, Sl, me = self.Hl, self.Sl, self.rank
+        """shards[t]: (H, Sl, D) sequence shard of tensor t (q, k, v; any strides); bufs[t]: its layout buffer.
+        ONE message per (tensor, peer): the Hl heads bound for rank j are contiguous on the wire and land as the
+        contiguous row block [j*Hl*Sl, (j+1)*Hl*Sl) of the receiver's buffer -- 2(P-1) point-to-point ops per
+        tensor in one group (per-head messages would be 2(P-1)Hl: ~1000 ops per layer at P=8, H=24, a host-side
+        cost of the same order as the layer's compute).  The sender needs those heads contiguous: they are read
+        straight from the shard when they already are (a run of consecutive heads of a contiguous shard),
+        otherwise one gather pass (`index_select` into a staging buffer) orders all heads at once -- the
+        projection output is a strided (S, H*D) view anyway, so this replaces the per-head `.contiguous()`."""
+        Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
+        blk = Hl * Sl
         p2p = []
-        for x, buf in zip(shards, bufs):
-            for j in range(self.P):
-                for i in range(Hl):
-                    src = x[head_order[j * Hl + i]]
-                    if j == me:
-                        buf[me * Hl * Sl + i * Sl: me * Hl * Sl + (i + 1) * Sl].copy_(src)
-                    else:
-                        p2p.append(("send", src if src.is_contiguous() else src.contiguous(), j))
-            for j in range(self.P):
+        idx = None
+        for t, (x, buf) in enumerate(zip(shards, bufs)):
+            direct = x.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
+            if direct:
+                src = x
+                first = [self._run_of(head_order, j * Hl, Hl) for j in range(P)]
+            else:
+                if idx is None:
+                    idx = torch.as_tensor(list(head_order), device=x.device)
+                src = self._stage(("s", t))
+                torch.index_select(x, 0, idx, out=src)
+                first = [j * Hl for j in range(P)]
+            buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D).copy_(src[first[me]:first[me] + Hl])
+            for j in range(P):
                 if j != me:
-                    for i in range(Hl):
-                        p2p.append(("recv", buf[j * Hl * Sl + i * Sl: j * Hl * Sl + (i + 1) * Sl], j))
+                    p2p.append(("send", src[first[j]:first[j] + Hl], j))
+            for j in range(P):
+                if j != me:
+                    p2p.append(("recv", buf[j * blk:(j + 1) * blk], j))
         if texts is not None and self.T:
             for t, buf in zip(texts, bufs):  # t: (H, T, D) replicated
                 for i in range(Hl):
@@ -126,23 +153,25 @@ class UlyssesLayout:
     # ---- head shards -> sequence shards -------------------------------------------------------------
     def gather_heads(self, buf: torch.Tensor, out_shard: torch.Tensor, head_order: Sequence[int],
                      out_text: Optional[torch.Tensor] = None):
-        """inverse of scatter_heads for the attention output: out_shard (H, Sl, D) contiguous per head."""
-        Hl, Sl, me = self.Hl, self.Sl, self.rank
+        """inverse of scatter_heads for the attention output: out_shard (H, Sl, D), any strides.  One message per
+        peer; received head blocks go straight into out_shard when their heads are a consecutive run of a
+        contiguous out_shard, else through a staging buffer and one `index_copy_`."""
+        Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
+        blk = Hl * Sl
+        direct = out_shard.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
+        dst = out_shard if direct else self._stage(("g", 0))
+        first = [self._run_of(head_order, j * Hl, Hl) if direct else j * Hl for j in range(P)]
         p2p = []
-        for j in range(self.P):
-            for i in range(Hl):
-                src = buf[j * Hl * Sl + i * Sl: j * Hl * Sl + (i + 1) * Sl]
-                if j == me:
-                    out_shard[head_order[me * Hl + i]].copy_(src)
-                else:
-                    p2p.append(("send", src, j))
-        for j in range(self.P):
+        dst[first[me]:first[me] + Hl].copy_(buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D))
+        for j in range(P):
             if j != me:
-                for i in range(Hl):
-                    dst = out_shard[head_order[j * Hl + i]]
-                    assert dst.is_contiguous()
-                    p2p.append(("recv", dst, j))
+                p2p.append(("send", buf[j * blk:(j + 1) * blk], j))
+        for j in range(P):
+            if j != me:
+                p2p.append(("recv", dst[first[j]:first[j] + Hl], j))
         self._run(p2p)
+        if not direct:
+            out_shard.index_copy_(0, torch.as_tensor(list(head_order), device=out_shard.device), dst)
         if out_text is not None and self.T:
             local = torch.stack([buf[self.rows_video + i * Sl: self.rows_video + i * Sl + self.T] for i in range(Hl)])
             parts = [torch.empty_like(local) for _ in range(self.P)]
@@ -163,12 +192,13 @@ class UlyssesRoutedAttention:
     heads (zero-copy layout) -> gather_heads.  Also the template for the attention processors under SP."""
 
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
-                 rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True):
+                 rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
+                 sliding_block_rows: int = 0):
         from ..routed import HeadRouting, RoutedGeometry
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
         self.cfg, self.P, self.rank = cfg, P, rank
-        self.concurrent, self.fused = concurrent, fused
+        self.concurrent, self.fused, self.sliding_block_rows = concurrent, fused, sliding_block_rows
         self.te = cfg["text_valid"]
         self.lay = UlyssesLayout(H, S, T, 128, P, rank, device, dtype, group)
         self.geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"],
@@ -200,5 +230,6 @@ class UlyssesRoutedAttention:
         self.lay.scatter_heads(shards, self.bufs[:3], order, texts)
         q, k, v, o = (self.lay.head_view(b) for b in self.bufs)
         routed_attention(q, k, v, self.routes[l], self.geom, model=self.cfg["model"], text_len=self.cfg["text"],
-                         text_valid=self.te, out=o, concurrent=self.concurrent, fused=self.fused)
+                         text_valid=self.te, out=o, concurrent=self.concurrent, fused=self.fused,
+                         sliding_block_rows=self.sliding_block_rows)
         self.lay.gather_heads(self.bufs[3], self.out_shard, order, self.out_text)
