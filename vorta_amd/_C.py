@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvorta_hip.so")
+# VORTA_HIP_LIB: experiments only (A/B of two builds in one session); the product is the in-tree library
+LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvorta_hip.so")
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
 VORTA_BF16, VORTA_FP16 = 0, 1

@@ -280,8 +280,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
 
 // The default kernel: scores computed one key block ahead (software pipeline across blocks), K/V tiles staged
 // global -> LDS by DMA, softmax folded into the score MFMA.  See the notes inside and DESIGN.md (d).
-template <typename T, int NW, bool KVTAB>
+#ifndef VORTA_RING
+// K/V ring depth of the 8-wave kernels: 2 = one step of DMA latency cover (64 KiB LDS), 3 = two steps (96 KiB).
+// Measured equal (1216 vs 1217 TFLOP/s, S=32 760 H=12 bf16, same box): the end-of-step vmcnt wait is not where
+// the loop stalls, so the smaller ring stays.
+#define VORTA_RING 2
+#endif
+
+template <typename T, int NW, bool KVTAB, int NS>
 __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __restrict__ smem, const int wg) {
+  // NS = depth of the K and of the V tile rings (NS * 32 KiB of LDS): K(j+NS) / V(j+NS-1) are requested at the
+  // top of step j, NS-1 steps before the step that reads them
+  static_assert(NS == 2 || NS == 3, "ring depth");
   using V8 = typename MF<T>::v8;
   using V4 = typename MF<T>::v4;
   constexpr int NT = NW * 64;
@@ -348,7 +358,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   // instruction fills 1 KiB = 4 tile rows (16 lanes x 16 B per row); the destination is lane-linear, so the
   // bank swizzles of the tile images are applied on the SOURCE side: the lane that lands in chunk c' of row r
   // fetches chunk c' ^ swz(r) of that row (same involution the fragment reads apply).
-  // K(b) is staged one block ahead of V(b); rings: K tiles at [0,32K), V at [32K,64K).
+  // K(b) is staged one block ahead of V(b); rings: K tiles at [0, NS*16K), V tiles behind them.
   const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.k + (int64_t)head * p.k_sh), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -372,7 +382,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       k_rsrc, (LDS_AS void*)(smem + (par_) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                            \
       (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + k_col[i_], 0, 0, 0);
 #define DMA_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
-      v_rsrc, (LDS_AS void*)(smem + (2 + (par_)) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                      \
+      v_rsrc, (LDS_AS void*)(smem + (NS + (par_)) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                     \
       (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
 
   // ---- LDS read addresses ----
@@ -384,7 +394,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      v_rd[dt] = 2 * TILE_BYTES + (4 * (g >> 1) + q4) * ROWB + ((dt ^ q4) << 6) + 32 * (g & 1) + 8 * pp;
+      v_rd[dt] = NS * TILE_BYTES + (4 * (g >> 1) + q4) * ROWB + ((dt ^ q4) << 6) + 32 * (g & 1) + 8 * pp;
   }
 
   f32x16 o[4];
@@ -448,14 +458,23 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= (g_); c1_[i_] -= (g_); minit[i_] = -m_run; } \
     asm volatile("" : "+v"(minit));                                               \
   }
-  // top of step j: K(j+2) -> the slot K(j) left, V(j+1) -> the slot V(j-1) left; both land before the barrier
-  // that ends the step (the compiler's __syncthreads waits vmcnt(0) first), a whole step of latency cover
-#define STAGE_DMA(par_, j_)                                                       \
-  DMA_K(par_)                                                                     \
-  DMA_V((par_) ^ 1)                                                               \
+  // top of step j: K(j+NS) -> the slot K(j) left, V(j+NS-1) -> the slot V(j-1) left.  They are read in step
+  // j+NS-1, so the barrier that ends step j only waits for the requests of step j-NS+2 and older: with NS = 3
+  // the 2*CH requests of the current step stay in flight across it (two steps of latency cover, one with NS = 2)
+#define STAGE_DMA(kfree_, vfree_, j_)                                             \
+  DMA_K(kfree_)                                                                   \
+  DMA_V(vfree_)                                                                   \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
-  ROWS_OF(rowK, (j_) + 3)                                                         \
+  ROWS_OF(rowK, (j_) + NS + 1)                                                    \
   __builtin_amdgcn_sched_barrier(0);
+  // end of a step: own DMA requests older than the current step have landed, then the workgroup barrier (which
+  // also orders every wave's LDS reads of this step before the next step's overwrites)
+#define STEP_SYNC()                                                               \
+  {                                                                               \
+    if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    else if constexpr (CH == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+  }
 
 #ifndef VORTA_SCHED
 #define VORTA_SCHED 0
@@ -476,14 +495,14 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
   // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
   // all visible to the scheduler together.
-#define STEP(c0_, c1_, n0_, n1_, par_, j_)                                        \
-  {                                                                               \
-    STAGE_DMA(par_, j_)                                                           \
+#define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, vfree_, j_)                       \
+  { /* kcur_ = j % NS: slot of K(j) (free) and of V(j); knext_ = (j+1) % NS; vfree_ = (j-1) % NS */ \
+    STAGE_DMA(kcur_, vfree_, j_)                                                  \
     if (wave_active) {                                                            \
       V8 kpre_[KPRE > 0 ? KPRE : 1][2];                                                          \
       _Pragma("unroll") for (int ks_ = 0; ks_ < KPRE; ++ks_) {                    \
-        kpre_[ks_][0] = *(const V8*)(smem + ((par_) ^ 1) * TILE_BYTES + k_rd[ks_]); \
-        kpre_[ks_][1] = *(const V8*)(smem + ((par_) ^ 1) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
+        kpre_[ks_][0] = *(const V8*)(smem + (knext_) * TILE_BYTES + k_rd[ks_]);   \
+        kpre_[ks_][1] = *(const V8*)(smem + (knext_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
       }                                                                           \
       /* mx_cur (row max of this block's scores) was computed under the previous step's PV MFMAs; only the */ \
       /* last, partial key block has to mask its tail and redo it here                                      */ \
@@ -503,7 +522,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
         RAISE_REF(g_, c0_, c1_)                                                   \
       }                                                                           \
       V8 pb_[4];                                                                  \
-      QK_PRE(n0_, n1_, (par_) ^ 1) /* block j+1 (harmless garbage past the end) */ \
+      QK_PRE(n0_, n1_, knext_) /* block j+1 (harmless garbage past the end) */    \
       float lsum_ = 0.f;                                                          \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
         c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                \
@@ -519,8 +538,8 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       }                                                                           \
       _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
         _Pragma("unroll") for (int kg_ = 0; kg_ < 4; ++kg_) {                     \
-          const V4 lo_ = MF<T>::tr(smem + (par_) * TILE_BYTES + v_rd[dt_] + (16 * kg_) * ROWB); \
-          const V4 hi_ = MF<T>::tr(smem + (par_) * TILE_BYTES + v_rd[dt_] + (16 * kg_ + 8) * ROWB); \
+          const V4 lo_ = MF<T>::tr(smem + (kcur_) * TILE_BYTES + v_rd[dt_] + (16 * kg_) * ROWB); \
+          const V4 hi_ = MF<T>::tr(smem + (kcur_) * TILE_BYTES + v_rd[dt_] + (16 * kg_ + 8) * ROWB); \
           V8 vf_;                                                                 \
           _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { vf_[e_] = lo_[e_]; vf_[4 + e_] = hi_[e_]; } \
           o[dt_] = MF<T>::mfma(vf_, pb_[kg_], o[dt_]);                            \
@@ -529,19 +548,25 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       ROW_MAX(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */   \
       SCHED_RECIPE()                                                              \
     }                                                                             \
-    __syncthreads();                                                              \
+    STEP_SYNC()                                                                   \
   }
 
   if (blk0 < blk1) {
-    // prologue: K(0), V(0) -> ring slot 0, K(1) -> slot 1; then rowK = rows(2), rowV = rows(1)
+    // prologue: K(0..NS-1) and V(0..NS-2) -> their ring slots; then rowK = rows(NS), rowV = rows(NS-1)
     ROWS_OF(rowK, blk0)
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     DMA_K(0)
     DMA_V(0)
     ROWS_OF(rowK, blk0 + 1)
     DMA_K(1)
+    if constexpr (NS == 3) {
+      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
+      DMA_V(1)
+      ROWS_OF(rowK, blk0 + 2)
+      DMA_K(2)
+    }
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-    ROWS_OF(rowK, blk0 + 2)
+    ROWS_OF(rowK, blk0 + NS)
     __syncthreads();
     if (wave_active) {
       QK(sA0, sA1, 0)  // seed 0: plain scores of the first block
@@ -564,10 +589,26 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     }
     __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
   }
-  for (int blk = blk0; blk < blk1; blk += 2) {
-    STEP(sA0, sA1, sB0, sB1, 0, blk)
-    if (blk + 1 >= blk1) break;
-    STEP(sB0, sB1, sA0, sA1, 1, blk + 1)
+  if constexpr (NS == 2) {
+    for (int blk = blk0; blk < blk1; blk += 2) {
+      STEP(sA0, sA1, sB0, sB1, 0, 1, 1, blk)
+      if (blk + 1 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 1, 0, 0, blk + 1)
+    }
+  } else {  // ring slots cycle with period 3, score roles with period 2: unrolled by 6
+    for (int blk = blk0; blk < blk1; blk += 6) {
+      STEP(sA0, sA1, sB0, sB1, 0, 1, 2, blk)
+      if (blk + 1 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 1, 2, 0, blk + 1)
+      if (blk + 2 >= blk1) break;
+      STEP(sA0, sA1, sB0, sB1, 2, 0, 1, blk + 2)
+      if (blk + 3 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 0, 1, 2, blk + 3)
+      if (blk + 4 >= blk1) break;
+      STEP(sA0, sA1, sB0, sB1, 1, 2, 0, blk + 4)
+      if (blk + 5 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 2, 0, 1, blk + 5)
+    }
   }
 #undef QK
 #undef QK_PRE
@@ -575,6 +616,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #undef RAISE_REF
 #undef STEP
 #undef STAGE_DMA
+#undef STEP_SYNC
 #undef ROWS_OF
 #undef DMA_K
 #undef DMA_V
@@ -632,7 +674,8 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 template <typename T, int NW, bool KVTAB>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+  constexpr int NS = NW == 8 ? VORTA_RING : 2;  // 8 waves = the CU's whole wave budget at this VGPR count: 96 of its 160 KiB
+  __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE_BYTES];
   // XCD-aware work order: consecutive logical ids (same head, neighbouring query blocks) share an XCD's L2
   const int nwg = gridDim.x;
   int wg;
@@ -642,7 +685,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   } else {
     wg = blockIdx.x;
   }
-  attn_pipe_dma_body<T, NW, KVTAB>(p, smem, wg);
+  attn_pipe_dma_body<T, NW, KVTAB, NS>(p, smem, wg);
 #endif
 }
 
@@ -660,7 +703,7 @@ struct MultiParams {
 template <typename T>
 __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParams mp) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
-  __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
+  __shared__ __attribute__((aligned(16))) char smem[2 * VORTA_RING * TILE_BYTES];  // K and V rings
   const int b = blockIdx.x;
   int s = 0;
 #pragma unroll
@@ -673,8 +716,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParam
   const int l = b - mp.start[s], n = mp.start[s + 1] - mp.start[s];
   const int xcd = l & 7, qd = n >> 3, r = n & 7;
   const int wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (l >> 3);
-  if (p.kv_rows) attn_pipe_dma_body<T, 8, true>(p, smem, wg);
-  else attn_pipe_dma_body<T, 8, false>(p, smem, wg);
+  if (p.kv_rows) attn_pipe_dma_body<T, 8, true, VORTA_RING>(p, smem, wg);
+  else attn_pipe_dma_body<T, 8, false, VORTA_RING>(p, smem, wg);
 #endif
 }
 
