@@ -228,6 +228,23 @@ typedef struct vorta_norm_rope_args {
 int vorta_qk_norm_rope(const vorta_norm_rope_args* args, void* hip_stream);
 
 /*
+ * vorta_mix_experts -- the score-weighted sum of the training-time forward:
+ *   out[h][row][:] = sum_e scores[h][e] * x[e][h][row][:]        (fp32 accumulation, one rounding)
+ * `_combine_attn_outputs`, hunyuan.py:509-513 == wan.py:296-300 (stack + multiply + sum over the expert axis).
+ * Forward only: the library has no backward kernels.
+ */
+typedef struct vorta_mix_args {
+  uint32_t struct_size;
+  int32_t dtype, head_dim, heads, n_experts; /* n_experts = 3 */
+  int32_t n_rows;
+  vorta_tensor x[3];   /* (H, n_rows, D) views: outputs of expert 0 / 1 / 2 for ALL heads */
+  vorta_tensor out;    /* (H, n_rows, D) view; may alias one of x */
+  const void* scores;  /* [heads][n_experts], dtype of x: routing scores of batch item 0 */
+} vorta_mix_args;
+
+int vorta_mix_experts(const vorta_mix_args* args, void* hip_stream);
+
+/*
  * vorta_seq_row_map -- physical row of every token for the zero-copy Ulysses layout.
  * After all_to_all_single of a sequence-sharded (H, S/P, D) tensor (vorta/ulysses/utils.py:61-91) rank r
  * holds P chunks of (H/P, S/P, D); the reference re-packs them into (H/P, S, D) with two
@@ -241,7 +258,8 @@ int vorta_seq_row_map(int32_t* row_map, int32_t n_tokens, int32_t seg_len, int32
 int vorta_abi_version(void);
 const char* vorta_build_info(void); /* static string: arch, compiler */
 int vorta_last_hip_error(void);     /* last hipError_t seen by a failed launch in this thread */
-int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args, 5 norm_rope_args */
+int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args, 5 norm_rope_args,
+                                       6 mix_args */
 
 #ifdef __cplusplus
 }

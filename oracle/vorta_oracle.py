@@ -299,6 +299,21 @@ def routed_attention(q, k, v, expert_of_head: np.ndarray, *, model: str, latent:
     return out
 
 
+def soft_mixture_attention(q, k, v, scores: np.ndarray, *, model: str, latent: Triple, tile: Triple, window: Triple,
+                           gi: GroupInfo, t_text: int = 0, t_eff: int = 0):
+    """Training-time forward: every head runs all three experts and the outputs are mixed with the routing
+    scores, out[b,h] = sum_e scores[b,h,e] * expert_e(q,k,v)[b,h].
+    hunyuan.py:341-408 + `_combine_attn_outputs` :509-513;  wan.py:218-241 + :296-300.  """
+    H = q.shape[1]
+    sc = np.asarray(scores, dtype=np.float64)
+    out = np.zeros(q.shape, dtype=np.float64)
+    for e in range(3):
+        o = routed_attention(q, k, v, np.full(H, e, dtype=np.int32), model=model, latent=latent, tile=tile,
+                             window=window, gi=gi, t_text=t_text, t_eff=t_eff)
+        out += sc[:, :, e, None, None] * o
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- A13
 def ulysses_seq_to_head(shards: Sequence[np.ndarray]) -> List[np.ndarray]:
     """all_to_all_4D(x, scatter_idx=1, gather_idx=2) for every rank at once.

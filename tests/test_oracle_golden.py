@@ -139,6 +139,35 @@ def test_hunyuan_eval_steps(golden):
     assert np.all(g["hy_eout"][:, :, te:] == 0)
 
 
+# ---------------------------------------------------------------- G11
+def test_soft_mixture_forward(golden):
+    """the training-time forward of the reference (all heads through all experts, score-weighted sum)"""
+    g8, g = golden("g8_eval_calls"), golden("g11_soft_mixture")
+    H, D = 6, 16
+    gi = O.group_info(LATENT, GROUP, 0.5)
+    sc = g["routing_score"]
+    assert np.allclose(sc.sum(-1), 1.0, atol=1e-6)
+    t, te = (int(x) for x in g8["text"])
+    o = O.soft_mixture_attention(g8["hy_q"], g8["hy_k"], g8["hy_v"], sc, model="hunyuan", latent=LATENT, tile=TILE,
+                                 window=WINDOW, gi=gi, t_text=t, t_eff=te)
+    np.testing.assert_allclose(o[:, :, :S], g["hy_soft_out"], atol=3e-5, rtol=1e-4)
+    np.testing.assert_allclose(o[:, :, S:], g["hy_soft_eout"], atol=3e-5, rtol=1e-4)
+
+    def lin(x, n):
+        return x @ g8[f"wan_w_{n}_weight"].astype(np.float64).T + g8[f"wan_w_{n}_bias"]
+
+    hidden = g8["wan_hidden"].astype(np.float64)
+    q = _rmsnorm(lin(hidden, "to_q"), g8["wan_w_norm_q_weight"])
+    k = _rmsnorm(lin(hidden, "to_k"), g8["wan_w_norm_k_weight"])
+    v = lin(hidden, "to_v")
+    q, k, v = (a.reshape(1, S, H, D).transpose(0, 2, 1, 3) for a in (q, k, v))
+    o = O.soft_mixture_attention(q, k, v, sc, model="wan", latent=LATENT, tile=TILE, window=WINDOW, gi=gi)
+    y = lin(o.transpose(0, 2, 1, 3).reshape(1, S, H * D), "to_out_0")
+    np.testing.assert_allclose(y, g["wan_soft_out"], atol=5e-5, rtol=1e-4)
+    teacher = lin(O.dense_attention(q, k, v).transpose(0, 2, 1, 3).reshape(1, S, H * D), "to_out_0")
+    np.testing.assert_allclose(teacher, g["wan_teacher_out"], atol=5e-5, rtol=1e-4)
+
+
 # ---------------------------------------------------------------- G9
 @pytest.mark.parametrize("P", [2, 4])
 def test_ulysses_maps(golden, P):

@@ -354,6 +354,48 @@ def g8_eval_calls(A):
     save("g8_eval_calls", **out)
 
 
+# ----------------------------------------------------------------------------- G11: soft-mixture (training) forward
+def g11_soft_mixture(A):
+    """The training-time forward (soft mixture of the three experts over ALL heads): wan.py:195-241,296-300 (whole
+    processor call) and hunyuan.py:341-408,509-513 (expert steps + combine).  Inputs are G8's (same seeds), so only
+    the soft scores and the outputs are stored."""
+    g8 = np.load(os.path.join(OUT, "g8_eval_calls.npz"))
+    gi = A.get_group_info(LATENT, GROUP, reduction_rate=0.5)
+    torch.manual_seed(4242)
+    sc = torch.softmax(torch.randn(1, H, 3) * 1.5, dim=-1)
+    out = {"routing_score": sc}
+    torch.manual_seed(5678)
+    attn = _FakeAttn(H, D, wan=True)
+    with torch.no_grad():
+        attn.norm_q.weight.uniform_(0.5, 1.5)
+        attn.norm_k.weight.uniform_(0.5, 1.5)
+    hidden = torch.randn(1, S, H * D)
+    assert np.array_equal(hidden.numpy(), g8["wan_hidden"]) and \
+        np.array_equal(attn.to_q.weight.detach().numpy(), g8["wan_w_to_q_weight"])
+    bm = _block_mask(A, latent_shape=LATENT, window_size=WINDOW, tile_size=TILE, text_seq_length=0,
+                     text_seq_length_no_pad=0)
+    wproc = A.WanAttnProcessorTripleTrain(check_input=True)
+    with torch.no_grad():
+        y = wproc(attn, hidden, None, None, None, routing_score=sc.clone(), lowres_group_info=gi,
+                  flex_attn_mask_func=bm, window_size=WINDOW, tile_size=TILE, latent_shape=LATENT)
+        teacher = wproc(attn, hidden, None, None, None, use_original_attn=True)
+    out.update(wan_soft_out=y, wan_teacher_out=teacher)
+
+    q, k, v = (torch.tensor(g8[n]) for n in ("hy_q", "hy_k", "hy_v"))
+    mask = _hy_mask(S, T_TXT, T_EFF)
+    bm2 = _block_mask(A, latent_shape=LATENT, window_size=WINDOW, tile_size=TILE, text_seq_length=T_TXT,
+                      text_seq_length_no_pad=T_EFF)
+    proc = A.HunyuanVideoFlashAttnProcessorTripleTrain()
+    with torch.no_grad():
+        fo, feo = proc._step_attention(q, k, v, mask, T_TXT)
+        lo, leo = proc._step_lowres_attention(q, k, v, mask, T_TXT, gi)
+        so, seo = proc._step_sliding_attention(q, k, v, T_TXT, bm2, TILE, LATENT)
+        o = proc._combine_attn_outputs(sc, [fo, lo, so])
+        eo = proc._combine_attn_outputs(sc, [feo, leo, seo])
+    out.update(hy_soft_out=o, hy_soft_eout=eo)
+    save("g11_soft_mixture", **out)
+
+
 # ----------------------------------------------------------------------------- G9: Ulysses maps under gloo
 def _g9_worker(rank, world, port, ret):
     import torch.distributed as dist
@@ -423,7 +465,7 @@ def main():
     jobs = [("G1", lambda: g1_group_info(A)), ("G2", lambda: g2_pool_unpool(A)), ("G3", lambda: g3_sta_mask(A)),
             ("G4", lambda: g4_tile_perm(A)), ("G5", lambda: g5_sliding_out(A)), ("G6", lambda: g6_dense_out(A)),
             ("G7", lambda: g7_router(A, router_mod)), ("G8", lambda: g8_eval_calls(A)), ("G9", g9_ulysses),
-            ("G10", g10_pixel2token)]
+            ("G10", g10_pixel2token), ("G11", lambda: g11_soft_mixture(A))]
     for name, fn in jobs:
         if only and name not in only:
             continue

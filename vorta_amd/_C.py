@@ -78,6 +78,13 @@ class NormRopeArgs(C.Structure):
     ]
 
 
+class MixArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32), ("n_experts", _i32),
+        ("n_rows", _i32), ("x", Tensor * 3), ("out", Tensor), ("scores", _vp),
+    ]
+
+
 # every symbol include/vorta_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "vorta_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
@@ -91,6 +98,7 @@ SYMBOLS = {
     "vorta_route_scores": (C.c_int, [C.POINTER(RouterArgs), _vp]),
     "vorta_route_plan": (C.c_int, [C.POINTER(RouterArgs), C.c_int32, _vp]),
     "vorta_qk_norm_rope": (C.c_int, [C.POINTER(NormRopeArgs), _vp]),
+    "vorta_mix_experts": (C.c_int, [C.POINTER(MixArgs), _vp]),
     "vorta_seq_row_map": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
     "vorta_abi_version": (C.c_int, []),
     "vorta_build_info": (C.c_char_p, []),
@@ -129,7 +137,7 @@ def lib():
         fn.argtypes = args
     if h.vorta_abi_version() != ABI_VERSION:
         raise VortaHipError(f"ABI mismatch: library {h.vorta_abi_version()} vs binding {ABI_VERSION}")
-    for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs)):
+    for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs, MixArgs)):
         if h.vorta_sizeof(which) != C.sizeof(st):
             raise VortaHipError(f"struct layout mismatch for {st.__name__}: "
                                 f"C {h.vorta_sizeof(which)} vs ctypes {C.sizeof(st)}")

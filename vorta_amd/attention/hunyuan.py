@@ -10,7 +10,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from .. import ops
-from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention
+from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention, soft_mixture_attention
 from ..ulysses import SP_STATE, shrink_dim
 from .coreset_select import LowresGroupInfo
 from .sliding_tile import SlidingTileDescriptor
@@ -198,12 +198,32 @@ class HunyuanVideoFlashAttnProcessorTripleEval(HunyuanVideoFlashAttnProcessor):
 
 
 class HunyuanVideoFlashAttnProcessorTripleTrain(HunyuanVideoFlashAttnProcessorTripleEval):
-    """Training-time soft mixture of the three experts (hunyuan.py:241-513): OUT OF SCOPE of this build
-    (training only).  `use_original_attn=True` (the dense teacher) is served."""
+    """Training-time soft mixture of the three experts (hunyuan.py:241-513), FORWARD only: every head runs all
+    three experts and the outputs are summed with the routing scores.  There are no backward
+    kernels: a call that would need gradients raises instead of silently returning a detached result.
+    `use_original_attn=True` (the dense teacher, hunyuan.py:312-321) is the dense processor."""
 
     def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask, image_rotary_emb,
-                 use_original_attn: bool = False, **kwargs):
+                 use_original_attn: bool = False, routing_score: Optional[torch.Tensor] = None,
+                 lowres_group_info: Optional[LowresGroupInfo] = None,
+                 flex_attn_mask_func: Optional[SlidingTileDescriptor] = None,
+                 window_size: Tuple[int, int, int] = (3, 3, 3), tile_size: Tuple[int, int, int] = (6, 8, 8),
+                 latent_shape: Tuple[int, int, int] = (30, 48, 80)):
         if use_original_attn:
             return HunyuanVideoFlashAttnProcessor.__call__(self, attn, hidden_states, encoder_hidden_states,
                                                            attention_mask, image_rotary_emb)
-        raise NotImplementedError("the soft-mixture training forward is outside the inference hot path of this build")
+        if torch.is_grad_enabled() and (hidden_states.requires_grad or routing_score.requires_grad):
+            raise NotImplementedError("the soft-mixture forward of this build has no backward: call it under "
+                                      "torch.no_grad() (router training is outside the inference hot path)")
+        if SP_STATE.enabled:
+            raise NotImplementedError("the soft-mixture forward is not sequence-parallel in this build")
+        with torch.no_grad():
+            self._check_input(hidden_states, lowres_group_info, latent_shape, window_size, tile_size)
+            q, k, v, T = self._project(attn, hidden_states, encoder_hidden_states, image_rotary_emb)
+            assert q.shape[0] == 1, f"Batch size {q.shape[0]} is not supported for {self.__class__.__name__}."
+            te = self._text_valid(attention_mask, T, flex_attn_mask_func)
+            geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
+                                lowres_group_info.reduction_rate, q.device)
+            buf, out = self._new_out(q)
+            soft_mixture_attention(q, k, v, routing_score, geom, model="hunyuan", text_len=T, text_valid=te, out=out)
+            return self._output(attn, buf, T)

@@ -8,7 +8,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from .. import ops
-from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention
+from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention, soft_mixture_attention
 from ..ulysses import SP_STATE, shrink_dim
 from .coreset_select import LowresGroupInfo
 from .sliding_tile import SlidingTileDescriptor
@@ -170,12 +170,29 @@ class WanAttnProcessorTripleEval(WanAttnProcessor2_0):
 
 
 class WanAttnProcessorTripleTrain(WanAttnProcessorTripleEval):
-    """Soft-mixture training forward (wan.py:163-300): OUT OF SCOPE (training only); the dense teacher
-    (`use_original_attn=True`) and cross attention are served."""
+    """Soft-mixture training forward (wan.py:163-300), FORWARD only (no backward kernels); the
+    dense teacher (`use_original_attn=True`) and cross attention are the dense processor."""
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, rotary_emb=None,
-                 use_original_attn: bool = False, **kwargs):
+                 use_original_attn: bool = False, routing_score: Optional[torch.Tensor] = None,
+                 lowres_group_info: Optional[LowresGroupInfo] = None,
+                 flex_attn_mask_func: Optional[SlidingTileDescriptor] = None,
+                 window_size: Tuple[int, int, int] = (3, 3, 3), tile_size: Tuple[int, int, int] = (6, 8, 8),
+                 latent_shape: Tuple[int, int, int] = (20, 30, 52)):
         if encoder_hidden_states is not None or use_original_attn:
             return WanAttnProcessor2_0.__call__(self, attn, hidden_states, encoder_hidden_states, attention_mask,
                                                 rotary_emb)
-        raise NotImplementedError("the soft-mixture training forward is outside the inference hot path of this build")
+        if torch.is_grad_enabled() and (hidden_states.requires_grad or routing_score.requires_grad):
+            raise NotImplementedError("the soft-mixture forward of this build has no backward: call it under "
+                                      "torch.no_grad() (router training is outside the inference hot path)")
+        if SP_STATE.enabled:
+            raise NotImplementedError("the soft-mixture forward is not sequence-parallel in this build")
+        with torch.no_grad():
+            self._check_input(hidden_states, lowres_group_info, latent_shape, window_size, tile_size)
+            q, k, v, _ = self._input_proj(attn, hidden_states, None, rotary_emb)
+            assert q.shape[0] == 1, "the soft mixture runs one batch item per call"
+            geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
+                                lowres_group_info.reduction_rate, q.device)
+            buf, out = self._new_out(q)
+            soft_mixture_attention(q, k, v, routing_score, geom, model="wan", out=out)
+            return self._output_proj(attn, buf)

@@ -24,6 +24,7 @@ extern "C" int vorta_sizeof(int which) {
     case 3: return (int)sizeof(vorta_sta_args);
     case 4: return (int)sizeof(vorta_router_args);
     case 5: return (int)sizeof(vorta_norm_rope_args);
+    case 6: return (int)sizeof(vorta_mix_args);
     default: return -1;
   }
 }

@@ -379,6 +379,26 @@ def qk_norm_rope(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float, *,
     return x
 
 
+def mix_experts(xs, scores: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """vorta_mix_experts: out[h] = sum_e scores[0,h,e] * xs[e][h] for (H,N,D) views (hunyuan.py:509-513)."""
+    _require_gpu(scores, out, *xs)
+    if len(xs) != 3 or scores.shape[-1] != 3:
+        raise ValueError("mix_experts takes the outputs of the three experts and (B,H,3) scores")
+    H, N, D = out.shape
+    sc = scores[0].to(out.dtype).contiguous()
+    a = _C.MixArgs()
+    a.struct_size = C.sizeof(_C.MixArgs)
+    a.dtype, a.head_dim, a.heads, a.n_experts, a.n_rows = _DT[out.dtype], D, H, 3, N
+    for e in range(3):
+        if xs[e].shape != out.shape or xs[e].dtype != out.dtype:
+            raise ValueError("mix_experts: expert outputs must match the output's shape and dtype")
+        a.x[e] = _tensor(xs[e])
+    a.out = _tensor(out)
+    a.scores = sc.data_ptr()
+    _C.check(_C.lib().vorta_mix_experts(C.byref(a), _stream()), "vorta_mix_experts")
+    return out
+
+
 def seq_row_map(n_tokens: int, seg_len: int, seg_stride_rows: int, device) -> torch.Tensor:
     """vorta_seq_row_map (zero-copy Ulysses layout)."""
     out = torch.empty(n_tokens, dtype=torch.int32, device=device)

@@ -43,6 +43,12 @@ class HeadRouting:
     def from_device(lists: torch.Tensor, counts: torch.Tensor) -> "HeadRouting":
         return HeadRouting(lists, None, counts)
 
+    @staticmethod
+    def every_head_everywhere(H: int, device) -> "HeadRouting":
+        """all H heads on each of the three experts (the training-time soft mixture, hunyuan.py:375-396)"""
+        lists = torch.arange(H, dtype=torch.int32).repeat(3, 1)
+        return HeadRouting(lists.to(device), [H, H, H], None)
+
     def slot_args(self, e: int, H: int):
         if self.counts_host is not None:
             return dict(head_list=self.lists[e], n_heads=self.counts_host[e], n_heads_dev=None)
@@ -110,7 +116,8 @@ def _side_streams(device: torch.device):
 def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing: HeadRouting,
                      geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
                      out: Optional[torch.Tensor] = None, scale: Optional[float] = None,
-                     concurrent: bool = False, fused: bool = True, sliding_block_rows: int = 0) -> torch.Tensor:
+                     concurrent: bool = False, fused: bool = True, sliding_block_rows: int = 0,
+                     expert_outs: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
     hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383.
@@ -119,7 +126,8 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     the full expert first, then coreset, then sliding tile, so each expert's tail is filled by the next one.
     concurrent=True instead enqueues the coreset and sliding-tile experts on two side HIP streams (forked from and joined
     back into the current stream with events): the experts are independent, so the tail of one launch (a few
-    hundred workgroups on 256 CUs when only H/P heads are local) is filled by the next expert's workgroups."""
+    hundred workgroups on 256 CUs when only H/P heads are local) is filled by the next expert's workgroups.
+    expert_outs: one output tensor per expert instead of `out` (heads may then appear under several experts)."""
     if q.dim() == 4 and q.shape[0] != 1:
         # hunyuan.py:168 asserts batch 1; Wan's CFG runs two batch-1 forwards (pipeline_wan.py:322-344)
         raise AssertionError(f"Batch size {q.shape[0]} is not supported by routed_attention.")
@@ -130,9 +138,13 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     if rm is None and N != S + T:
         raise ValueError(f"Input sequence length {N - T} does not match latent shape {geom.latent}.")
     te = text_valid if hy else 0
-    if out is None:
+    if out is None and expert_outs is None:
         out = torch.empty_like(q)
-    q3, k3, v3, o3 = (x[0] if x.dim() == 4 else x for x in (q, k, v, out))
+    q3, k3, v3 = (x[0] if x.dim() == 4 else x for x in (q, k, v))
+    if expert_outs is not None:
+        o_e = [x[0] if x.dim() == 4 else x for x in expert_outs]
+    else:
+        o_e = [out[0] if out.dim() == 4 else out] * 3
 
     def live(e):
         return routing.counts_host is None or routing.counts_host[e] > 0
@@ -140,11 +152,11 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     def nheads(e):  # for the algorithmic-work tags only
         return routing.counts_host[e] if routing.counts_host is not None else 0
 
-    base = dict(q=q3, k=k3, v=v3, out=o3, scale=scale)
+    base = dict(q=q3, k=k3, v=v3, scale=scale)
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     def expert_full():
-        return [dict(base, n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full",
+        return [dict(base, out=o_e[0], n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full",
                      q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
                      flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H))]
 
@@ -158,7 +170,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                                            row_map=rm, want_drop=False, **sl)
         else:   # K and V follow Q's matching (wan.py:250-255)
             keep_k = keep_q
-        return [dict(base, n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te, q_rows=keep_q,
+        return [dict(base, out=o_e[1], n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te, q_rows=keep_q,
                      kv_rows=keep_k, dup_rows=drop_q, n_dup_pos=geom.G, tag="lowres",
                      flops=nheads(1) * 4.0 * (geom.S_low + te) ** 2 * D, **sl)]
 
@@ -166,12 +178,12 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     def expert_sliding():
         sl = routing.slot_args(2, H)
         q_rows, kv_rows, n_kv = geom.sta_tables(te)
-        calls = [dict(base, n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
+        calls = [dict(base, out=o_e[2], n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
                       kv_rows_stride_g=n_kv, tag="sliding", flops=nheads(2) * 4.0 * D * S * n_kv,
                       block_rows=sliding_block_rows, **sl)]
         if T > 0:
             # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
-            txt = dict(base, n_q=T, q_valid=te, n_kv=S + te, n_splits=_auto_splits(sl["n_heads"], T, S + te),
+            txt = dict(base, out=o_e[2], n_q=T, q_valid=te, n_kv=S + te, n_splits=_auto_splits(sl["n_heads"], T, S + te),
                        tag="sliding_text", flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
             if rm is None:
                 txt.update(q_row_offset=S)
@@ -215,6 +227,23 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
             done = torch.cuda.Event()
             done.record(st)
         cur.wait_event(done)
+    return out
+
+
+def soft_mixture_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing_score: torch.Tensor,
+                           geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
+                           out: Optional[torch.Tensor] = None, scale: Optional[float] = None) -> torch.Tensor:
+    """Training-time FORWARD: every head through all three experts, outputs mixed with the routing
+    scores of batch item 0 -- hunyuan.py:375-408,509-513 / wan.py:226-241,296-300.  The three experts over all H
+    heads run as one fused grid into three buffers; `vorta_mix_experts` does the weighted sum in one pass.
+    No autograd: the library has no backward kernels (router training itself is out of scope)."""
+    H = q.shape[-3]
+    if out is None:
+        out = torch.empty_like(q)
+    bufs = [torch.empty_like(out) for _ in range(3)]
+    routed_attention(q, k, v, HeadRouting.every_head_everywhere(H, q.device), geom, model=model, text_len=text_len,
+                     text_valid=text_valid, scale=scale, expert_outs=bufs)
+    ops.mix_experts([b[0] if b.dim() == 4 else b for b in bufs], routing_score, out[0] if out.dim() == 4 else out)
     return out
 
 
