@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"])
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-ceiling", action="store_true",
+                    help="skip the torch.matmul (hipBLASLt) context measurement reported beside roofline.frac")
     ap.add_argument("--sliding-block-rows", type=int, default=0, choices=[0, 128, 256],
                     help="query rows per workgroup of the sliding-tile launch (0 = library heuristic; 256 lets it join "
                          "the fused grid)")
@@ -267,6 +269,25 @@ def main():
         "roofline": roofline,
         "per_launch": per_tag,
     }
+    if world == 1 and not args.no_gemm_ceiling:
+        # context for `frac`: what a plain library GEMM (hipBLASLt via torch.matmul, same dtype) sustains on THIS
+        # box right now -- the practical MFMA ceiling under the chip's power/clock management (measured after the
+        # timed region, never part of `value`)
+        n = 16384
+        a = torch.randn((n, n), device=dev).to(dt)
+        b = torch.randn((n, n), device=dev).to(dt)
+        for _ in range(2):
+            a @ b
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            a @ b
+        e1.record()
+        torch.cuda.synchronize()
+        gemm = 2.0 * n ** 3 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+        roofline["library_gemm_tflops"] = round(gemm, 1)
+        roofline["frac_of_library_gemm"] = round(achieved / gemm, 4) if gemm > 0 else None
+        del a, b
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, args.mix, step_flops)
