@@ -34,6 +34,10 @@ def test_config0_wan13b_49f_native_attention():
     for h in (0, 7):  # two full heads against the oracle
         ref = O.dense_attention(q[0, h].double().cpu().numpy(), k[0, h].double().cpu().numpy(), v[0, h].double().cpu().numpy())
         check(out[0, h], ref, dtype)
+        # the north star's image-level bar, applied to the operator: PSNR >= 40 dB against the float64 result
+        got = out[0, h].double().cpu().numpy()
+        psnr = 20.0 * np.log10(np.abs(ref).max() / np.sqrt(np.mean((got - ref) ** 2)))
+        assert psnr >= 40.0, psnr
     # every head: softmax rows sum to one (constant V reproduced)
     const = _rand((1, H, 1, 128), 4, dtype)
     out2 = dense_attention(q, k, const.expand(1, H, S, 128).contiguous())

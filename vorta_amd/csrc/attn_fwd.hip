@@ -476,22 +476,6 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
   }
 
-#ifndef VORTA_SCHED
-#define VORTA_SCHED 0
-#endif
-#if VORTA_SCHED == 1
-  // QK phase: per MFMA gap 2 exp + 4 plain VALU + 2 LDS reads; PV phase: per gap 2 VALU + 2 LDS reads
-#define SCHED_RECIPE()                                                            \
-  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
-  }
-#else
-#define SCHED_RECIPE()
-#endif
-
   // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
   // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
   // all visible to the scheduler together.
@@ -546,7 +530,6 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
         }                                                                         \
       }                                                                           \
       ROW_MAX(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */   \
-      SCHED_RECIPE()                                                              \
     }                                                                             \
     STEP_SYNC()                                                                   \
   }
