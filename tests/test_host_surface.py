@@ -136,3 +136,16 @@ def test_router_module_state_dict_keys():
     r = Router(48, 6)
     assert set(r.state_dict()) == {"linear.weight", "linear.bias"}
     assert r.linear.weight.shape == (18, 48)
+
+
+def test_prepare_kwargs_validates_geometry_early():
+    """the published (6,9,8)/(2,3,2) geometry fits the 117-frame latent, not the 129-frame one"""
+    import torch
+    from vorta.patch.utils import hunyuan_pixel2token, prepare_hunyuan_self_attn_kwargs, prepare_wan_self_attn_kwargs
+    cfg = dict(window_size=(3, 3, 3), tile_size=(6, 9, 8), lowres_window_size=(2, 3, 2), lowres_reduction_rate=0.5)
+    ok = prepare_hunyuan_self_attn_kwargs(dict(cfg, latent_shape=hunyuan_pixel2token((117, 720, 1280))), torch.device("cpu"))
+    assert ok["lowres_group_info"].window_size == (2, 3, 2)
+    with pytest.raises(ValueError, match="does not divide latent shape"):
+        prepare_hunyuan_self_attn_kwargs(dict(cfg, latent_shape=hunyuan_pixel2token((129, 720, 1280))), torch.device("cpu"))
+    with pytest.raises(ValueError, match="Low-res window"):
+        prepare_wan_self_attn_kwargs(dict(cfg, tile_size=(3, 9, 8), latent_shape=(21, 45, 80)), torch.device("cpu"))

@@ -6,7 +6,25 @@ import torch
 from ..attention import create_sliding_tile_attn_mask_func, get_group_info
 
 
+def validate_geometry(kw: Dict[str, Any]) -> None:
+    """Fail at configuration time, with the messages the processors raise at the first forward
+    (hunyuan.py:260-272), when the `self_attention_kwargs` of a checkpoint's config.json do not fit the latent grid
+    of the requested video size: the published (6,9,8)/(2,3,2) geometry fits 117 frames, not 129."""
+    latent = tuple(int(v) for v in kw["latent_shape"])
+    tile = tuple(int(v) for v in kw.get("tile_size", (1, 1, 1)))
+    for t_size, l_size in zip(tile, latent):
+        if l_size % t_size != 0:
+            raise ValueError(f"Tile size {tile} (dim={t_size}) does not divide latent shape {latent} (dim={l_size}).")
+    group = kw.get("lowres_window_size")
+    if group is not None:
+        for g_size, l_size in zip(group, latent):
+            if l_size % g_size != 0:
+                raise ValueError(f"Low-res window {tuple(group)} (dim={g_size}) does not divide latent shape {latent} "
+                                 f"(dim={l_size}): the coreset expert would crop the sequence.")
+
+
 def _add_group_info(kw: Dict[str, Any], device) -> None:
+    validate_geometry(kw)
     kw.update(lowres_group_info=get_group_info(kw["latent_shape"], kw.pop("lowres_window_size"),
                                                reduction_rate=kw.pop("lowres_reduction_rate"), device=device))
 
