@@ -469,12 +469,27 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   __builtin_amdgcn_sched_barrier(0);
   // end of a step: own DMA requests older than the current step have landed, then the workgroup barrier (which
   // also orders every wave's LDS reads of this step before the next step's overwrites)
+#ifdef VORTA_TRACE  // diagnostic build only (tools/trace_barrier.py): cycles spent in the wait and in the barrier
+  long long tr_wait_ = 0, tr_bar_ = 0;
+  const long long tr_t0_ = clock64();
+#define STEP_SYNC()                                                               \
+  {                                                                               \
+    const long long a_ = clock64();                                               \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
+    const long long b_ = clock64();                                               \
+    asm volatile("s_barrier" ::: "memory");                                       \
+    const long long c_ = clock64();                                               \
+    tr_wait_ += b_ - a_;                                                          \
+    tr_bar_ += c_ - b_;                                                           \
+  }
+#else
 #define STEP_SYNC()                                                               \
   {                                                                               \
     if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
     else if constexpr (CH == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
   }
+#endif
 
   // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
   // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
@@ -604,6 +619,12 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #undef DMA_K
 #undef DMA_V
 
+#ifdef VORTA_TRACE
+  if (p.n_splits == 1 && p.ws_ml && lane == 0) {
+    long long* tr = (long long*)p.ws_ml + ((int64_t)wg * NW + wave) * 4;
+    tr[0] = clock64() - tr_t0_; tr[1] = tr_wait_; tr[2] = tr_bar_; tr[3] = blk1 - blk0;
+  }
+#endif
   if (!wave_active) return;
   // ---------------- epilogue ----------------
   const float l_tot = half_sum(l_run);
