@@ -19,7 +19,7 @@ def main():
     br = int(os.environ.get("BLOCK_ROWS", 256))
     nw = br // 32
     n_wg = H * ((S + br - 1) // br)
-    tr = torch.zeros((n_wg, nw, 4), dtype=torch.int64, device=dev)
+    tr = torch.zeros((n_wg, nw, 8), dtype=torch.int64, device=dev)
     a, keep = ops._attn_args(q, k, v, o, n_q=S, n_kv=S, block_rows=br, variant=2)
     a.ws_ml = tr.data_ptr()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,7 +35,8 @@ def main():
         return  # not a -DVORTA_TRACE build
     t = tr.double().cpu()
     tot, wait, bar, steps = t[..., 0], t[..., 1], t[..., 2], t[..., 3]
-    print(f"workgroups {n_wg}, steps/wave {steps.mean():.0f}")
+    mhz = (tot / t[..., 4]).mean().item() * 100.0  # wall_clock64 ticks at 100 MHz
+    print(f"workgroups {n_wg}, steps/wave {steps.mean():.0f}, shader clock over the loops {mhz:.0f} MHz")
     print(f"loop cycles/step: {(tot / steps).mean():.0f}  (min {(tot / steps).min():.0f}, max {(tot / steps).max():.0f})")
     print(f"wait  cycles/step: {(wait / steps).mean():.0f}  = {100 * (wait / tot).mean():.1f} % of the loop")
     print(f"barrier cycles/step: {(bar / steps).mean():.0f}  = {100 * (bar / tot).mean():.1f} % of the loop")
@@ -43,6 +44,31 @@ def main():
     print("barrier share by wave:", " ".join(f"{100 * x:.1f}" for x in per_wave.tolist()))
     per_wave = (wait / tot).mean(0)
     print("wait share by wave:   ", " ".join(f"{100 * x:.1f}" for x in per_wave.tolist()))
+    # timeline per CU slot (last launch): entry -> end of loop of consecutive workgroups on the same CU
+    ti = tr[:, 0].cpu()  # wave 0 of every workgroup
+    start, end, hw = ti[:, 5], ti[:, 6], ti[:, 7]
+    cu = (hw & 0xffff) >> 8 & 0xf
+    se = (hw >> 13) & 0x7
+    xcc = (hw >> 32) & 0xf
+    key = (xcc * 8 + se) * 16 + cu
+    t0 = start.min().item()
+    span = (end.max().item() - t0) / 100.0
+    busy = ((end - start).double().sum().item() / 100.0)
+    slots = key.unique().numel() * (2 if br == 128 else 1)
+    print(f"launch span {span:.0f} us over {key.unique().numel()} CUs; sum of (entry -> loop end) {busy:.0f} us "
+          f"= {100 * busy / (span * slots):.1f} % of span x slots")
+    gaps = []
+    for k_ in key.unique().tolist():
+        m = key == k_
+        s_, e_ = start[m].sort().values, end[m].sort().values
+        if br == 256 and len(s_) > 1:
+            gaps += ((s_[1:] - e_[:-1]).double() / 100.0).tolist()
+    if gaps:
+        g = torch.tensor(gaps)
+        print(f"gap loop-end -> next entry on the same CU: mean {g.mean():.1f} us, max {g.max():.1f} us, n={len(gaps)}")
+    first = (start - t0).double() / 100.0
+    print(f"first-round entries: within {first.sort().values[key.unique().numel() - 1]:.1f} us; last loop end at {span:.0f} us; "
+          f"loop time per workgroup {((end - start).double() / 100.0).mean():.0f} us")
 
 
 if __name__ == "__main__":

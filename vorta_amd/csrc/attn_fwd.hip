@@ -292,6 +292,9 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   // NS = depth of the K and of the V tile rings (NS * 32 KiB of LDS): K(j+NS) / V(j+NS-1) are requested at the
   // top of step j, NS-1 steps before the step that reads them
   static_assert(NS == 2 || NS == 3, "ring depth");
+#ifdef VORTA_TRACE
+  const long long tr_e0_ = wall_clock64();  // workgroup entry, absolute (100 MHz)
+#endif
   using V8 = typename MF<T>::v8;
   using V4 = typename MF<T>::v4;
   constexpr int NT = NW * 64;
@@ -472,6 +475,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #ifdef VORTA_TRACE  // diagnostic build only (tools/trace_barrier.py): cycles spent in the wait and in the barrier
   long long tr_wait_ = 0, tr_bar_ = 0;
   const long long tr_t0_ = clock64();
+  const long long tr_w0_ = wall_clock64();  // constant 100 MHz: the shader clock over the loop follows from the two
 #define STEP_SYNC()                                                               \
   {                                                                               \
     const long long a_ = clock64();                                               \
@@ -621,8 +625,12 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 
 #ifdef VORTA_TRACE
   if (p.n_splits == 1 && p.ws_ml && lane == 0) {
-    long long* tr = (long long*)p.ws_ml + ((int64_t)wg * NW + wave) * 4;
+    long long* tr = (long long*)p.ws_ml + ((int64_t)wg * NW + wave) * 8;
     tr[0] = clock64() - tr_t0_; tr[1] = tr_wait_; tr[2] = tr_bar_; tr[3] = blk1 - blk0;
+    tr[4] = wall_clock64() - tr_w0_;
+    tr[5] = tr_e0_; tr[6] = wall_clock64();  // absolute entry / end-of-loop times
+    tr[7] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_ID
+            ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // XCC_ID
   }
 #endif
   if (!wave_active) return;
