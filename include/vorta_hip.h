@@ -96,6 +96,9 @@ typedef struct vorta_attn_args {
    * effective n_kv = clamp(*n_kv_dev, 1, n_kv), effective q_valid = min(*q_valid_dev, q_valid) */
   const int32_t* n_kv_dev;
   const int32_t* q_valid_dev;
+  /* variant 2 addresses K/V rows with 32-bit offsets: row < 2^24, row_stride_bytes < 2^24 and
+   * row * row_stride_bytes < 2^31 for every key row of a head (checked for contiguous ranges, VORTA_EUNSUPPORTED;
+   * guaranteed by the caller for kv_rows tables).  Variant 1 has no such limit. */
   int32_t variant; /* kernel body: 0 = auto = 2; 1 = plain (attn_fwd_kernel<T,NW>), 2 = software-pipelined, scores one
                       key block ahead, K/V tiles by LDS-DMA, softmax folded into the score MFMA
                       (attn_fwd_pipe_kernel<T,NW,KVTAB>) */

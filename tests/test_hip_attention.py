@@ -193,3 +193,26 @@ def test_full_size_properties(S):
     ref = O.dense_attention(q[0, rows].double().cpu().numpy(), k[0].double().cpu().numpy(), v[0].double().cpu().numpy())
     got = out[0, rows.to(dev())].float().cpu().numpy()
     assert np.abs(got - ref).max() <= ATOL_SAME[dtype]
+
+
+def test_wide_row_stride_takes_the_64bit_kernel():
+    """K/V rows spread over more than the 2 GiB window of the pipelined kernel's 32-bit offsets: ops selects the
+    plain kernel (64-bit addressing) and the C ABI refuses variant 2 for a contiguous range it cannot address."""
+    from vorta_amd import _C, ops
+    import ctypes as C
+    dtype = torch.bfloat16
+    Hh, n, stride = 1, 4096, 300_000  # 4096 rows x 600 kB = 2.4 GB per tensor
+    torch.manual_seed(0)
+    q = torch.randn((Hh, 256, 128), device=dev()).to(dtype)
+    kc, vc = (torch.randn((Hh, n, 128), device=dev()).to(dtype) for _ in range(2))
+    big = [torch.empty(n * stride + 128, dtype=dtype, device=dev()) for _ in range(2)]
+    k, v = (b.as_strided((Hh, n, 128), (0, stride, 1)) for b in big)
+    k.copy_(kc); v.copy_(vc)
+    out, ref = torch.empty_like(q), torch.empty_like(q)
+    a, _ = ops._attn_args(q, k, v, out, n_q=256, n_kv=n)
+    assert a.variant == 1
+    ops.attn_fwd(q, k, v, out, n_q=256, n_kv=n)
+    ops.attn_fwd(q, kc, vc, ref, n_q=256, n_kv=n, variant=1)
+    assert torch.equal(out, ref)
+    a.variant = 2
+    assert _C.lib().vorta_attn_fwd(C.byref(a), ops._stream()) == _C.VORTA_EUNSUPPORTED

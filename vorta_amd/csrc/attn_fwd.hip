@@ -813,6 +813,13 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   if (a->block_rows != 0 && a->block_rows != 128 && a->block_rows != 256) return VORTA_EINVAL;
   if (a->variant < 0 || a->variant > 2) return VORTA_EINVAL;
   if (a->variant != 1 && (a->k.stride_s * 2 >= (1 << 24) || a->v.stride_s * 2 >= (1 << 24))) return VORTA_EUNSUPPORTED;
+  // the pipelined kernel addresses K/V rows with 32-bit buffer offsets (24-bit row x 24-bit stride, 2 GiB window per
+  // head): checked here for contiguous key ranges; with a kv_rows table the caller guarantees it (vorta_hip.h)
+  if (a->variant != 1 && !a->kv_rows) {
+    const int64_t last = (int64_t)a->kv_row_offset + a->n_kv;
+    const int64_t ss = (a->k.stride_s > a->v.stride_s ? a->k.stride_s : a->v.stride_s) * 2;
+    if (last >= (1 << 24) || last * ss > 0x7fffffffll) return VORTA_EUNSUPPORTED;
+  }
   p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr; p.o = (char*)a->o.ptr;
   p.q_sh = a->q.stride_h * 2; p.k_sh = a->k.stride_h * 2; p.v_sh = a->v.stride_h * 2; p.o_sh = a->o.stride_h * 2;
   p.q_ss = a->q.stride_s * 2; p.k_ss = a->k.stride_s * 2; p.v_ss = a->v.stride_s * 2; p.o_ss = a->o.stride_s * 2;

@@ -126,6 +126,12 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     a.n_splits = n_splits
     a.n_kv_dev, a.q_valid_dev = _ptr(n_kv_dev), _ptr(q_valid_dev)
     a.variant = variant or DEFAULT_VARIANT
+    if a.variant != 1:
+        # the pipelined kernel's 32-bit K/V offsets (vorta_hip.h): beyond a 2 GiB window per head, or 2^24 rows, use
+        # the plain HIP kernel (64-bit addressing) instead
+        for t in (k, v):
+            if t.shape[1] >= (1 << 24) or t.shape[1] * t.stride(1) * 2 > 0x7fffffff or t.stride(1) * 2 >= (1 << 24):
+                a.variant = 1
     a.reserved = NO_XCD_REMAP
     ws = None
     if n_splits > 1:
