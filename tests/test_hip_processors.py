@@ -339,3 +339,53 @@ def test_hunyuan_soft_mixture_vs_oracle_and_golden(golden):
             # vs the reference's own fp32 run: with bf16 inputs the rounding reorders a few coreset rankings (every
             # head runs the coreset expert here), so the golden comparison is made in fp16
             assert rel_fro(got, gold) < 2e-2
+
+
+# --------------------------------------------------------------------------- Wan cross attention with image tokens
+class _WanI2VAttn(nn.Module):
+    """cross-attention module of the image-to-video models: 257 image tokens in front of the text (wan.py:70-73)"""
+
+    def __init__(self, dim, dtype, seed=21):
+        super().__init__()
+        torch.manual_seed(seed)
+        inner = 4 * 128
+        self.heads = 4
+        self.to_q, self.to_k, self.to_v = nn.Linear(dim, inner), nn.Linear(dim, inner), nn.Linear(dim, inner)
+        self.add_k_proj, self.add_v_proj = nn.Linear(dim, inner), nn.Linear(dim, inner)
+        self.norm_q, self.norm_k, self.norm_added_k = (nn.RMSNorm(inner, eps=1e-6) for _ in range(3))
+        for m in (self.norm_q, self.norm_k, self.norm_added_k):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+        self.to_out = nn.ModuleList([nn.Linear(inner, dim), nn.Identity()])
+        self.to(dev()).to(dtype)
+
+
+def test_wan_cross_attention_with_image_tokens_vs_oracle():
+    """wan.py:70-73,121-139: the first 257 encoder tokens are image tokens with their own K/V projections; their
+    attention output is added to the text cross-attention output before the output projection."""
+    from vorta_amd.attention import WanAttnProcessor2_0
+    dtype = torch.bfloat16
+    dim, Sq, n_txt = 96, 300, 40
+    attn = _WanI2VAttn(dim, dtype)
+    torch.manual_seed(22)
+    hidden = torch.randn((2, Sq, dim), device=dev()).to(dtype)  # batch 2: the dense processor serves any batch
+    enc = torch.randn((2, 257 + n_txt, dim), device=dev()).to(dtype)
+    y = WanAttnProcessor2_0()(attn, hidden, enc, None, None)
+
+    def lin(m, x):
+        return x @ _f64(m.weight).T + _f64(m.bias)
+
+    def rms(m, x):
+        return x / np.sqrt((x * x).mean(-1, keepdims=True) + 1e-6) * _f64(m.weight)
+
+    def heads(x):
+        return x.reshape(x.shape[0], x.shape[1], 4, 128).transpose(0, 2, 1, 3)
+
+    h, e = _f64(hidden), _f64(enc)
+    img, txt = e[:, :257], e[:, 257:]
+    q = heads(rms(attn.norm_q, lin(attn.to_q, h)))
+    k, v = heads(rms(attn.norm_k, lin(attn.to_k, txt))), heads(lin(attn.to_v, txt))
+    ki, vi = heads(rms(attn.norm_added_k, lin(attn.add_k_proj, img))), heads(lin(attn.add_v_proj, img))
+    o = O.dense_attention(q, k, v) + O.dense_attention(q, ki, vi)
+    want = lin(attn.to_out[0], o.transpose(0, 2, 1, 3).reshape(2, Sq, 512))
+    assert y.shape == want.shape
+    assert rel_fro(y.float().cpu().numpy(), want) < 1.5e-2
