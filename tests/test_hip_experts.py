@@ -164,6 +164,33 @@ def test_sliding_golden(golden):
     assert torch.all(out[0, :, S + te:] == 0)
 
 
+def test_sliding_tile_flex_attn_entry_point(golden):
+    """vorta.attention.sliding_attn_flex.sliding_tile_flex_attn (sliding_attn_flex.py:137-211) by name and
+    signature, both tensor layouts, against golden G5 (the reference's compiled flex_attention output)"""
+    from vorta.attention.sliding_attn_flex import create_sliding_tile_attn_mask_func, sliding_tile_flex_attn
+    g = golden("g5_sliding_out")
+    dtype = torch.bfloat16
+    up = math.sqrt(128 / 16)  # golden head dim 16 zero-padded to 128: pre-scale q so 1/sqrt(128) acts as 1/sqrt(16)
+    desc = create_sliding_tile_attn_mask_func(LATENT, WINDOW, TILE, 0, 0, dev())
+    q, k, v = (to_dev(pad128(g[n]) * s, dtype) for n, s in (("wan_q", up), ("wan_k", 1.0), ("wan_v", 1.0)))
+    out = sliding_tile_flex_attn(q, k, v, desc, tile_size=TILE, latent_shape=LATENT, head_dim=1)
+    assert out.shape == q.shape
+    check(out[0, :, :, :16], g["wan_out"][0], dtype, gold=True)
+    out2 = sliding_tile_flex_attn(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), desc, tile_size=TILE,
+                                  latent_shape=LATENT)  # (B,S,H,D), the reference's default layout
+    assert torch.equal(out2.transpose(1, 2), out)
+    t, te = (int(x) for x in g["text"])
+    desc = create_sliding_tile_attn_mask_func(LATENT, WINDOW, TILE, t, te, dev())
+    vq, vk, vv, eq, ek, ev = (to_dev(pad128(g[n]) * s, dtype) for n, s in
+                              (("hy_q", up), ("hy_k", 1.0), ("hy_v", 1.0), ("hy_eq", up), ("hy_ek", 1.0), ("hy_ev", 1.0)))
+    o, eo = sliding_tile_flex_attn(vq, vk, vv, desc, eq, ek, ev, tile_size=TILE, latent_shape=LATENT, head_dim=1)
+    check(o[0, :, :, :16], g["hy_out"][0], dtype, gold=True)
+    check(eo[0, :, :, :16], g["hy_eout"][0], dtype, gold=True)
+    assert torch.all(eo[0, :, te:] == 0)
+    with pytest.raises(ValueError):
+        sliding_tile_flex_attn(vq, vk, vv, desc, eq, ek, ev, tile_size=(4, 3, 4), latent_shape=LATENT, head_dim=1)
+
+
 @pytest.mark.parametrize("model", ["hunyuan", "wan"])
 def test_routed_golden(golden, model):
     """The whole routed op (dispatch, three experts, direct write-back) vs the reference's own output."""

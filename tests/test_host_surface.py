@@ -149,3 +149,21 @@ def test_prepare_kwargs_validates_geometry_early():
         prepare_hunyuan_self_attn_kwargs(dict(cfg, latent_shape=hunyuan_pixel2token((129, 720, 1280))), torch.device("cpu"))
     with pytest.raises(ValueError, match="Low-res window"):
         prepare_wan_self_attn_kwargs(dict(cfg, tile_size=(3, 9, 8), latent_shape=(21, 45, 80)), torch.device("cpu"))
+
+
+@pytest.mark.parametrize("sp", [1, 2])
+def test_tile_layout_module_matches_reference_permutation(sp):
+    """vorta.attention.tile.{tile_layout, untile_layout} (tile.py:7-78) against golden G4, both head layouts"""
+    from vorta.attention.tile import tile_layout, untile_layout
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g4_tile_perm.npz"))
+    latent, tile = (8, 6, 8), (2, 3, 4)
+    n = latent[0] * latent[1] * latent[2]
+    x = torch.arange(n, dtype=torch.float32).view(1, 1, n, 1).expand(1, 2, n, 3)  # value = source position
+    tiled = tile_layout(x, sp, tile, latent, head_dim=1)
+    assert np.array_equal(tiled[0, 0, :, 0].long().numpy(), g[f"sp{sp}_tiled_src"])
+    assert torch.equal(untile_layout(tiled, sp, tile, latent, head_dim=1), x)
+    x2 = x.transpose(1, 2)  # (B,S,H,D), the default head_dim=2
+    assert torch.equal(tile_layout(x2, sp, tile, latent).transpose(1, 2), tiled)
+    assert torch.equal(untile_layout(tile_layout(x2, sp, tile, latent), sp, tile, latent), x2)
+    with pytest.raises(ValueError):
+        tile_layout(x, 1, (3, 3, 4), latent, head_dim=1)

@@ -83,3 +83,18 @@ def dist_prefix(msg: str) -> str:
     s = SP_STATE
     return (f"[Rank: {s.local_rank}/{s.rank}/{s.world_size} | DP: {s.group_id}/{s.num_sp_groups} | "
             f"SP: {s.group_local_rank}/{s.sp_size}] {msg}")
+
+
+def set_seed(seed: int, device_specific: bool = False) -> None:
+    """Seed `random`, `numpy` and `torch` (vorta/ulysses/utils.py:238-257); `device_specific` offsets by the global
+    rank."""
+    import random
+
+    import numpy as np
+    if device_specific:
+        seed += SP_STATE.rank
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)

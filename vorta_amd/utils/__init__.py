@@ -76,3 +76,30 @@ def dtype_to_str(dtype: torch.dtype) -> str:
         if v == dtype:
             return k
     raise ValueError(f"Unsupported dtype {dtype}")
+
+
+# ---- the remaining small helpers of vorta/utils (log.py:45-46, misc.py:11-23,40-49,91-92); video file I/O
+# (video_io.py: decord / torchvision) is not part of this build -------------------------------------------------
+def arg_to_yaml(arg: argparse.Namespace) -> str:
+    import yaml
+    return yaml.dump(vars(arg), indent=4, sort_keys=True)
+
+
+def isinstance_str(x: object, cls_name: str) -> bool:
+    """does any class in x's ancestry carry this NAME (no import of the class needed; used when patching)"""
+    return any(c.__name__ == cls_name for c in type(x).__mro__)
+
+
+def get_cuda_memory_usage(device: torch.device) -> float:
+    free, total = torch.cuda.mem_get_info(device)
+    used = (total - free) / 1024 ** 3
+    logging.getLogger(__name__).debug(f"CUDA memory used: {used:.2f} GB")
+    return used
+
+
+def format_metrics_to_gb(item) -> float:
+    return round(item / 1024 ** 3, ndigits=4)
+
+
+def accumulate_loss(current_loss, new_loss):
+    return new_loss if current_loss is None else current_loss + new_loss
