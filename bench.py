@@ -13,7 +13,6 @@ Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofli
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

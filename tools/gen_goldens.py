@@ -20,7 +20,6 @@ import importlib.util
 import os
 import sys
 import types
-from functools import partial
 
 os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
 sys.dont_write_bytecode = True

@@ -10,7 +10,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from .. import ops
-from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention, soft_mixture_attention
+from ..routed import HeadRouting, geometry_for, routed_attention, soft_mixture_attention
 from ..ulysses import SP_STATE, shrink_dim
 from .coreset_select import LowresGroupInfo
 from .sliding_tile import SlidingTileDescriptor

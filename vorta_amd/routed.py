@@ -10,7 +10,7 @@ head gathers (hunyuan.py:612-640), pooled copies (coreset_select.py:68-124), til
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple, Union
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 

@@ -9,8 +9,6 @@ world_size>1 tests.  Differences from the reference, by design:
     engine.py.  These functions exist so code written against the reference keeps working.
 Backward passes (SeqAllToAll4D.backward, AllGather.backward) are training-only and out of scope.
 """
-from typing import Optional
-
 import torch
 import torch.distributed as dist
 
