@@ -216,3 +216,87 @@ def test_wide_row_stride_takes_the_64bit_kernel():
     assert torch.equal(out, ref)
     a.variant = 2
     assert _C.lib().vorta_attn_fwd(C.byref(a), ops._stream()) == _C.VORTA_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_randomised_launch_shapes(seed):
+    """Random launch geometry -- head lists, query groups with their own key lists, row tables, duplicate lists,
+    q_valid / n_kv tails, key splits, both workgroup sizes and both kernel bodies -- against the oracle."""
+    from vorta_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    dtype = (torch.bfloat16, torch.float16)[seed % 2]
+    H_buf = int(rng.integers(1, 5))
+    S = int(rng.integers(40, 700))
+    q, k, v = (rng.standard_normal((H_buf, S, 128)) for _ in range(3))
+    heads = rng.permutation(H_buf)[: int(rng.integers(1, H_buf + 1))].astype(np.int32)
+    use_groups = bool(rng.integers(0, 2))
+    use_qtab = use_groups or bool(rng.integers(0, 2))
+    use_kvtab = use_groups or bool(rng.integers(0, 2))
+    if use_groups:
+        n_groups = int(rng.integers(1, 5))
+        glen = int(rng.integers(1, max(2, S // n_groups)))
+        n_q = n_groups * glen
+    else:
+        n_groups, n_q = 1, int(rng.integers(1, S + 1))
+        glen = n_q
+    n_kv = int(rng.integers(1, S + 1))
+    q_rows = rng.permutation(S)[:n_q].astype(np.int32) if use_qtab else None
+    q_off = 0 if use_qtab else int(rng.integers(0, S - n_q + 1))
+    kv_rows = np.stack([rng.permutation(S)[:n_kv] for _ in range(n_groups)]).astype(np.int32) if use_kvtab else None
+    kv_arg = kv_rows if (kv_rows is None or use_groups) else kv_rows[0]  # 1-D = one list shared by all heads
+    kv_off = 0 if use_kvtab else int(rng.integers(0, S - n_kv + 1))
+    q_valid = int(rng.integers(0, n_q + 1)) if rng.integers(0, 3) == 0 else n_q
+    n_splits = int(rng.integers(1, 4)) if (not use_groups and rng.integers(0, 3) == 0) else 1
+    block_rows = int(rng.choice([0, 128, 256]))
+    variant = int(rng.choice([1, 2]))
+    written = q_rows if use_qtab else np.arange(q_off, q_off + n_q)
+    rest = np.setdiff1d(np.arange(S), written)
+    n_dup, n_dup_pos = 0, 0
+    dup = None
+    if use_qtab and n_splits == 1 and len(rest) >= 2 and rng.integers(0, 2):
+        n_dup = int(rng.integers(1, 3))
+        n_dup_pos = int(rng.integers(1, min(n_q, len(rest) // n_dup) + 1))
+        dup = rng.permutation(rest)[: n_dup_pos * n_dup].reshape(n_dup_pos, n_dup).astype(np.int32)
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    out = torch.full_like(qd, 7.0)
+    t = lambda a: None if a is None else torch.as_tensor(a, device=dev())
+    ops.attn_fwd(qd, kd, vd, out, n_q=n_q, q_group_len=glen if use_groups else 0, n_kv=n_kv, q_valid=q_valid,
+                 head_list=t(heads), n_heads=len(heads), q_rows=t(q_rows), q_row_offset=q_off, kv_rows=t(kv_arg),
+                 kv_row_offset=kv_off, kv_rows_stride_g=n_kv if use_groups else 0, dup_rows=t(dup), n_dup_pos=n_dup_pos,
+                 n_splits=n_splits, block_rows=block_rows, variant=variant)
+    torch.cuda.synchronize()
+    rq, rk, rv = rounded(q, dtype), rounded(k, dtype), rounded(v, dtype)
+    ref = np.full((H_buf, S, 128), 7.0)
+    for h in heads:
+        for g in range(n_groups):
+            pos = np.arange(g * glen, min((g + 1) * glen, n_q))
+            rows = written[pos]
+            keys = kv_rows[g] if use_kvtab else np.arange(kv_off, kv_off + n_kv)
+            o = O.dense_attention(rq[h:h + 1, rows], rk[h:h + 1, keys], rv[h:h + 1, keys])[0]
+            o[pos >= q_valid] = 0.0  # rows past q_valid are written as zeros (hunyuan.py:176)
+            ref[h, rows] = o
+        for p in range(n_dup_pos):
+            ref[h, dup[p]] = ref[h, written[p]]
+    desc = dict(seed=seed, H_buf=H_buf, S=S, heads=heads.tolist(), n_q=n_q, glen=glen, n_kv=n_kv, q_valid=q_valid,
+                n_splits=n_splits, block_rows=block_rows, variant=variant, qtab=use_qtab, kvtab=use_kvtab, n_dup=n_dup)
+    got = out.float().cpu().numpy()
+    assert np.abs(got - ref).max() <= ATOL_SAME[dtype], desc
+
+
+def test_table_extents_are_checked_on_the_host():
+    """the kernels trust their tables; ops refuses every shape that cannot cover the launch (a 2-D key table is one
+    list PER HEAD SLOT -- a single shared list must be 1-D)"""
+    from vorta_amd import ops
+    q, k, v = (torch.randn((3, 200, 128), device=dev()).to(torch.bfloat16) for _ in range(3))
+    out = torch.empty_like(q)
+    i32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=dev())
+    for kw in (dict(kv_rows=i32(1, 100)),                       # 3 head slots, one row
+               dict(kv_rows=i32(90)),                           # shorter than n_kv
+               dict(q_rows=i32(2, 200)),                        # 2 rows for 3 head slots
+               dict(q_rows=i32(150)),                           # shorter than n_q
+               dict(q_group_len=50, kv_rows=i32(4, 100)),       # groups without a group stride
+               dict(q_group_len=50, kv_rows=i32(3, 100), kv_rows_stride_g=100),  # 4 groups, 3 key lists
+               dict(head_list=i32(2), n_heads=3),
+               dict(q_rows=i32(200), dup_rows=i32(2, 10, 2))):  # per-slot duplicate lists for 2 of 3 slots
+        with pytest.raises(ValueError):
+            ops.attn_fwd(q, k, v, out, n_q=200, n_kv=100, **kw)

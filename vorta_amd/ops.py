@@ -108,6 +108,28 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     a.n_heads_dev = _ptr(n_heads_dev)
     a.n_q, a.q_group_len, a.q_row_offset = n_q, q_group_len, q_row_offset
     a.q_valid = n_q if q_valid is None else q_valid
+    # the kernels trust the tables: check every extent that can be checked on the host (the row VALUES live on the
+    # device and are the caller's contract, vorta_hip.h)
+    n_groups = 1 if q_group_len <= 0 else -(-n_q // q_group_len)
+    if head_list is not None and head_list.numel() < n_heads:
+        raise ValueError(f"head_list holds {head_list.numel()} heads, n_heads = {n_heads}")
+    if q_rows is not None and (q_rows.dim() not in (1, 2) or q_rows.shape[-1] < n_q
+                               or (q_rows.dim() == 2 and q_rows.shape[0] < n_heads)):
+        raise ValueError(f"q_rows {tuple(q_rows.shape)} does not cover n_q = {n_q} rows for {n_heads} head slots")
+    if kv_rows is not None:
+        if kv_rows_stride_g > 0:
+            need = (n_groups - 1) * kv_rows_stride_g + n_kv
+            if kv_rows.numel() < need or kv_rows_stride_g < 0:
+                raise ValueError(f"kv_rows {tuple(kv_rows.shape)} does not cover {n_groups} groups x {n_kv} keys "
+                                 f"at group stride {kv_rows_stride_g}")
+        elif n_groups > 1:
+            raise ValueError("query groups need kv_rows_stride_g (one key list per group)")
+        elif kv_rows.dim() not in (1, 2) or kv_rows.shape[-1] < n_kv or (kv_rows.dim() == 2 and kv_rows.shape[0] < n_heads):
+            raise ValueError(f"kv_rows {tuple(kv_rows.shape)} does not cover n_kv = {n_kv} keys for {n_heads} head slots "
+                             f"(1-D: shared by all heads; 2-D: one row per head slot)")
+    if dup_rows is not None and (dup_rows.dim() not in (2, 3) or (dup_rows.dim() == 3 and dup_rows.shape[0] < n_heads)
+                                 or dup_rows.shape[-2] < (n_dup_pos or dup_rows.shape[-2])):
+        raise ValueError(f"dup_rows {tuple(dup_rows.shape)} does not cover {n_dup_pos} positions for {n_heads} head slots")
     a.q_rows = _ptr(q_rows)
     a.q_rows_stride_h = q_rows.stride(0) if (q_rows is not None and q_rows.dim() == 2) else 0
     a.n_kv, a.kv_row_offset = n_kv, kv_row_offset
