@@ -437,3 +437,67 @@ def test_fused_layer_launch_matches_separate_launches():
     c = routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,
                          text_valid=te)
     assert torch.equal(a, c)
+
+
+# ------------------------------------------------------------------------------- randomised geometry sweeps
+@pytest.mark.parametrize("seed", range(20))
+def test_sta_tables_random_geometry(seed):
+    """vorta_sta_build_tables against the oracle's restatement of the reference mask (sliding_attn_flex.py:93-128)
+    for random latent / tile / window shapes, including windows wider than the tile grid and even windows."""
+    from vorta_amd import ops
+    rng = np.random.default_rng(500 + seed)
+    tile = tuple(int(rng.integers(1, 4)) for _ in range(3))
+    n_tiles3 = tuple(int(rng.integers(1, 6)) for _ in range(3))
+    latent = tuple(a * b for a, b in zip(tile, n_tiles3))
+    window = tuple(int(rng.integers(1, 7)) for _ in range(3))
+    te = int(rng.integers(0, 9))
+    Sv, tok = latent[0] * latent[1] * latent[2], tile[0] * tile[1] * tile[2]
+    q_rows, kv_rows = ops.sta_build_tables(latent, tile, window, te, dev())
+    q_rows, kv_rows = q_rows.cpu().numpy(), kv_rows.cpu().numpy()
+    perm = O.tile_major_order(latent, tile)
+    assert np.array_equal(q_rows, perm), (latent, tile)
+    sees = O.sta_window_tiles(latent, tile, window)  # (n_tiles, n_tiles)
+    n_tiles, tok2, n_kv = ops.sta_table_sizes(latent, tile, window, te)
+    assert (n_tiles, tok2) == (Sv // tok, tok) and kv_rows.shape == (n_tiles, n_kv)
+    for ti in range(n_tiles):
+        want = np.concatenate([perm[j * tok:(j + 1) * tok] for j in np.nonzero(sees[ti])[0]] + [np.arange(Sv, Sv + te)])
+        assert np.array_equal(np.sort(kv_rows[ti]), np.sort(want)), (latent, tile, window, te, ti)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_coreset_select_random_geometry(seed):
+    """vorta_coreset_select against the oracle for random window shapes / reduction rates / head lists: kept and
+    dropped rows index for index wherever the similarity gaps exceed fp32 noise, partition property everywhere."""
+    from vorta_amd import ops
+    rng = np.random.default_rng(900 + seed)
+    group = tuple(int(rng.integers(1, 4)) for _ in range(3))
+    while group[0] * group[1] * group[2] < 3:
+        group = tuple(int(rng.integers(1, 4)) for _ in range(3))
+    latent = tuple(g * int(rng.integers(1, 5)) for g in group)
+    rate = float(rng.choice([0.25, 0.5, 0.75]))
+    gi = O.group_info(latent, group, rate)
+    if gi.n_keep_margin < 0 or gi.n_keep_margin > gi.group_size - 1:
+        pytest.skip("degenerate keep count")
+    Sv = latent[0] * latent[1] * latent[2]
+    H_buf, n_tail = int(rng.integers(1, 4)), int(rng.integers(0, 6))
+    dtype = (torch.bfloat16, torch.float16)[seed % 2]
+    x = rng.standard_normal((H_buf, Sv + n_tail, 128))
+    heads = rng.permutation(H_buf).astype(np.int32)
+    keep, drop = ops.coreset_select(to_dev(x, dtype), latent, group, gi.n_keep_margin, tail_first=Sv, n_tail=n_tail,
+                                    head_list=torch.as_tensor(heads, device=dev()), n_heads=H_buf)
+    keep, drop = keep.cpu().numpy(), drop.cpu().numpy()
+    xr = rounded(x[:, :Sv], dtype)[None][:, heads]  # slot order
+    kept, dropped = O.coreset_match(xr, gi)
+    keep_ref, drop_ref = O.coreset_row_lists(gi, kept, dropped)
+    G, nk = gi.n_groups, gi.n_keep_margin
+    assert keep.shape == (H_buf, G * (1 + nk) + n_tail)
+    assert np.array_equal(keep[:, G * (1 + nk):], np.tile(np.arange(Sv, Sv + n_tail), (H_buf, 1)))
+    assert np.array_equal(keep[:, :G], keep_ref[0][:, :G])
+    sims = np.sort(O.coreset_similarity(xr, gi), axis=-1)
+    clear = (np.diff(sims, axis=-1).min(-1) > 1e-5)[0] if sims.shape[-1] > 1 else np.ones((H_buf, G), bool)
+    got_k = keep[:, G:G + G * nk].reshape(H_buf, G, nk)
+    ref_k = keep_ref[0][:, G:].reshape(H_buf, G, nk)
+    assert np.array_equal(got_k[clear], ref_k[clear]), (latent, group, rate)
+    assert np.array_equal(drop[clear], drop_ref[0][clear])
+    allrows = np.concatenate([keep[:, :G, None], got_k, drop], axis=-1)
+    assert np.array_equal(np.sort(allrows.reshape(H_buf, -1), axis=-1), np.tile(np.arange(Sv), (H_buf, 1)))
