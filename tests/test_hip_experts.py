@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import vorta_oracle as O
-from _util import check, dev, pad128, rounded, to_dev
+from _util import ATOL_SAME, check, dev, pad128, rounded, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -501,3 +501,49 @@ def test_coreset_select_random_geometry(seed):
     assert np.array_equal(drop[clear], drop_ref[0][clear])
     allrows = np.concatenate([keep[:, :G, None], got_k, drop], axis=-1)
     assert np.array_equal(np.sort(allrows.reshape(H_buf, -1), axis=-1), np.tile(np.arange(Sv), (H_buf, 1)))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_routed_attention_random_configs(seed):
+    """The whole routed op -- random geometry, head->expert assignment (including experts without heads), text
+    lengths, model flavour, host- or device-resident routing, fused or serial launches -- against the oracle."""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    rng = np.random.default_rng(7000 + seed)
+    dtype = (torch.bfloat16, torch.float16)[seed % 2]
+    group = [(2, 3, 2), (3, 1, 2), (1, 2, 2), (2, 2, 1)][int(rng.integers(0, 4))]
+    tile = tuple(int(rng.integers(1, 4)) for _ in range(3))
+    latent = tuple(int(np.lcm(g, t)) * int(rng.integers(1, 3)) for g, t in zip(group, tile))
+    window = tuple(int(rng.choice([1, 3, 5])) for _ in range(3))
+    model = ("hunyuan", "wan")[int(rng.integers(0, 2))]
+    T = int(rng.integers(1, 20)) if model == "hunyuan" else 0
+    te = int(rng.integers(0, T + 1)) if T else 0
+    H = int(rng.integers(1, 7))
+    experts = rng.integers(0, 3, size=H)
+    Sv = latent[0] * latent[1] * latent[2]
+    q, k, v = (rng.standard_normal((1, H, Sv + T, 128)) for _ in range(3))
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    if rng.integers(0, 2):
+        routing = HeadRouting.from_expert_ids(experts.tolist(), dev())
+    else:
+        host = HeadRouting.from_expert_ids(experts.tolist(), dev())
+        routing = HeadRouting.from_device(host.lists, torch.tensor(host.counts_host, dtype=torch.int32, device=dev()))
+    out = routed_attention(to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype), routing, geom, model=model, text_len=T,
+                           text_valid=te, fused=bool(rng.integers(0, 2)))
+    gi = O.group_info(latent, group, 0.5)
+    rq, rk, rv = rounded(q, dtype), rounded(k, dtype), rounded(v, dtype)
+    ref = O.routed_attention(rq, rk, rv, experts, model=model, latent=latent, tile=tile, window=window, gi=gi, t_text=T,
+                             t_eff=te)
+    got = out.float().cpu().numpy()
+    desc = dict(seed=seed, model=model, latent=latent, tile=tile, window=window, group=group, T=T, te=te,
+                experts=experts.tolist())
+    # coreset heads: rounding cannot reorder (same rounded inputs on both sides) unless two similarities tie in fp32
+    sims = np.sort(O.coreset_similarity(rq[..., :Sv, :], gi), axis=-1)
+    tie_free = (np.diff(sims, axis=-1).min(-1) > 1e-5).all(-1)[0] if sims.shape[-1] > 1 else np.ones(H, bool)
+    simk = np.sort(O.coreset_similarity(rk[..., :Sv, :], gi), axis=-1)
+    tie_free &= (np.diff(simk, axis=-1).min(-1) > 1e-5).all(-1)[0] if simk.shape[-1] > 1 else True
+    for h in range(H):
+        if experts[h] == 1 and not tie_free[h]:
+            continue
+        assert np.abs(got[0, h] - ref[0, h]).max() <= ATOL_SAME[dtype], (desc, h)
+    if T:
+        assert (got[0, :, Sv + te:] == 0).all(), desc
