@@ -401,3 +401,43 @@ def test_hunyuan_pipeline_under_sequence_parallel_rehearsal():
             err, mag, same_scores, same_seed = ret[r]
             assert err <= 2e-2 * max(mag, 1.0), (r, err, mag)
             assert same_scores and same_seed
+
+
+def test_train_router_patch_runs_the_soft_mixture_forward():
+    """apply_vorta_transformer(train_router=True): Train processors, no tau in the keyword set (the reference's training
+    config has none), every layer = score-weighted sum of the three experts; gradients are refused, not dropped."""
+    import vorta_amd.attention.hunyuan as hy
+    from vorta.patch.modeling_hunyuan import apply_vorta_transformer
+    from vorta.patch.utils import prepare_hunyuan_self_attn_kwargs
+    torch.manual_seed(21)
+    model = M.MiniHunyuanTransformer().to(dev()).to(torch.bfloat16)
+    apply_vorta_transformer(model, train_router=True, router_dtype=torch.bfloat16)
+    _spread_routers(model, 22)
+    kw = prepare_hunyuan_self_attn_kwargs(dict(latent_shape=LATENT, window_size=WINDOW, tile_size=TILE,
+                                               lowres_window_size=GROUP, lowres_reduction_rate=0.5), dev())
+    assert "tau_sparse" not in kw
+    calls = []
+    stock = hy.soft_mixture_attention
+
+    def rec(q, k, v, scores, geom, **k2):
+        out = stock(q, k, v, scores, geom, **k2)
+        calls.append((q.detach().clone(), k.detach().clone(), v.detach().clone(), scores.detach().clone(), out.detach().clone(), k2))
+        return out
+
+    hy.soft_mixture_attention = rec
+    try:
+        with torch.no_grad():
+            out = model(**_hy_inputs(), return_dict=False, self_attention_kwargs=kw, return_routing_scores=True)
+    finally:
+        hy.soft_mixture_attention = stock
+    assert len(out) == 5 and len(calls) == 4 and torch.isfinite(out[0].float()).all()
+    gi = O.group_info(LATENT, GROUP, 0.5)
+    for layer, (q, k, v, sc, o, k2) in enumerate(calls):
+        assert torch.equal(sc.cpu(), out[4][layer])
+        ref = O.soft_mixture_attention(_f64(q), _f64(k), _f64(v), _f64(sc), model="hunyuan", latent=LATENT, tile=TILE,
+                                       window=WINDOW, gi=gi, t_text=T, t_eff=TE)
+        assert rel_fro(o.float().cpu().numpy(), ref) < 1e-2, layer
+    with pytest.raises(NotImplementedError):  # grad mode on + trainable router scores would need a backward
+        inp = _hy_inputs()
+        inp["hidden_states"].requires_grad_(True)
+        model(**inp, return_dict=False, self_attention_kwargs=kw)

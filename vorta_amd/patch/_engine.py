@@ -113,6 +113,7 @@ class StepContext:
     last_token: Any = None
     descriptor_cache: Dict[Any, Any] = field(default_factory=dict)
     forwards: int = 0
+    needs_tau: bool = True       # hard top-1 dispatch (Eval processors); False for the soft mixture (Train)
 
 
 class BoundProcessor:
@@ -233,7 +234,10 @@ def install_timestep_capture(embedder: nn.Module, model: nn.Module, ctx: StepCon
             return None
         tau = ctx.kwargs.get("tau_sparse")
         if tau is None:
-            raise ValueError("self_attention_kwargs has no `tau_sparse` (prepare_*_self_attn_kwargs(..., tau_sparse=...))")
+            if ctx.needs_tau:
+                raise ValueError("self_attention_kwargs has no `tau_sparse` "
+                                 "(prepare_*_self_attn_kwargs(..., tau_sparse=...))")
+            tau = 0.0  # soft-mixture processors use the scores only; the dispatch lists go unused
         ctx.plan.compute(output, tau)
         ctx.captured = True
         return None

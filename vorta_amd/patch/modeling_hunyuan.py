@@ -70,6 +70,7 @@ def apply_vorta_transformer(model, train_router: bool = False, checkpoint_file: 
     logger.info(f"Model {model.__class__.__name__} ({model_dtype=}) is mounted with Router ({router_dtype=})")
 
     ctx = E.context_of(model)
+    ctx.needs_tau = not train_router
     E.clear_hooks(model)
     kw = dict(attn_processor_kwargs or {})
     kw.update(check_input=True)

@@ -29,6 +29,7 @@ def apply_vorta_transformer(model, train_router: bool = False, checkpoint_file: 
     embedding_dim = model.condition_embedder.time_proj.in_features
 
     ctx = E.context_of(model)
+    ctx.needs_tau = not train_router
     E.clear_hooks(model)
     kw = dict(attn_processor_kwargs or {})
     kw.update(check_input=True)
