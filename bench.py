@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--mix", default="uniform", choices=sorted(MIXES))
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"])
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
+    ap.add_argument("--sp-groups", type=int, default=int(os.environ.get("VORTA_SP_GROUPS", "1")),
+                    help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
+                         "overlaps the attention of another (1 = exchange, then attend; the measured default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-ceiling", action="store_true",
                     help="skip the torch.matmul (hipBLASLt) context measurement reported beside roofline.frac")
@@ -192,7 +195,8 @@ def main():
     else:
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
-                                            concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows)
+                                            concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
+                                            groups=args.sp_groups if (H // P) % args.sp_groups == 0 else 1)
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):
@@ -260,7 +264,8 @@ def main():
         "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
-                   "parallelism": "single GPU" if P == 1 else f"ulysses sp{P} (RCCL send/recv over xGMI)",
+                   "parallelism": "single GPU" if P == 1 else f"ulysses sp{P} (RCCL send/recv over xGMI)"
+                   + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else ""),
                    "experts": {"fused": "one fused grid per layer", "serial": "one launch per expert",
                                "concurrent": "experts on side streams"}[args.experts],
                    "step_algorithmic_pflop": round(step_flops / 1e15, 3),

@@ -114,6 +114,20 @@ def _engine_worker(rank, world, port, ret):
         t2 = torch.full((H, T, D), -2.0)
         lay.gather_heads(b2[0], o2, order2, t2)
         ok = ok and torch.equal(o2, shards[0]) and torch.equal(t2, texts[0])
+    # the overlapped form: two slot groups, identity "attention" per group (O = Q on that group's slots only)
+    from vorta_amd.ulysses import exchange_and_attend, slot_groups
+    order3 = balanced_head_order(experts, [7.0, 2.0, 1.0], P, groups=2)
+    assert sorted(order3) == list(range(H))
+    b3 = [lay.new_buffer().fill_(-1) for _ in range(4)]
+    seen = []
+
+    def attend(g0, g1, gi):
+        seen.append((g0, g1, gi))
+        lay.head_view(b3[3])[g0:g1].copy_(lay.head_view(b3[0])[g0:g1])
+
+    o3, t3 = torch.full((H, Sl, D), -2.0), torch.full((H, T, D), -2.0)
+    exchange_and_attend(lay, shards, b3, order3, texts, slot_groups(Hl, 2), attend, o3, t3)
+    ok = ok and seen == [(0, Hl // 2, 0), (Hl // 2, Hl, 1)] and torch.equal(o3, shards[0]) and torch.equal(t3, texts[0])
     # the same layout expressed with the oracle's reference maps: seq->head of the head-permuted shard
     ret[rank] = (bool(ok), order, shards[0].numpy(), keep, rm.numpy())
     dist.barrier()
@@ -136,6 +150,23 @@ def test_zero_copy_layout_round_trip(world):
         S = ref[r].shape[2]
         for i in range(ref[r].shape[1]):
             assert np.array_equal(hv[i][rm[:S]], ref[r][0, i])
+
+
+def test_balanced_head_order_with_slot_groups():
+    from vorta_amd.ulysses import balanced_head_order
+    rng = np.random.default_rng(3)
+    cost = [7.26, 1.82, 1.33]
+    for P, G in ((2, 2), (2, 3), (4, 2), (4, 3)):
+        e = rng.permutation([0] * 8 + [1] * 8 + [2] * 8)
+        plain, grouped = balanced_head_order(e, cost, P), balanced_head_order(e, cost, P, groups=G)
+        Hl = 24 // P
+        for j in range(P):  # same heads per rank as without groups; groups of a rank carry near-equal cost
+            assert sorted(grouped[j * Hl:(j + 1) * Hl]) == plain[j * Hl:(j + 1) * Hl]
+            n = Hl // G
+            loads = [sum(cost[e[h]] for h in grouped[j * Hl + g * n:j * Hl + (g + 1) * n]) for g in range(G)]
+            assert max(loads) - min(loads) <= max(cost)
+    with pytest.raises(AssertionError):
+        balanced_head_order([0] * 8, cost, 2, groups=3)
 
 
 def test_balanced_head_order():

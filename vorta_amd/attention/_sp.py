@@ -13,9 +13,10 @@ import torch
 from .. import ops
 from ..routed import HeadRouting, geometry_for, routed_attention
 from ..ulysses import SP_STATE
-from ..ulysses.engine import UlyssesLayout, balanced_head_order
+from ..ulysses.engine import UlyssesLayout, balanced_head_order, exchange_and_attend, slot_groups
 
 _LAYOUTS = {}
+SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
 
 
 def _layout(H, S, T, D, device, dtype):
@@ -60,22 +61,29 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
                             lowres_group_info.reduction_rate, q.device, row_map=lay.row_map)
         _, _, n_kv = geom.sta_tables(te)
         cost = [float(S + te) ** 2, float(geom.S_low + te) ** 2, float(S) * n_kv]
-    order = balanced_head_order(experts, cost, P)
+    # VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot
+    # groups, so the exchange of one group overlaps the attention of another
+    groups = SP_GROUPS if lay.Hl % SP_GROUPS == 0 else 1
+    order = balanced_head_order(experts, cost, P, groups)
     shards = [x[0, :, :Sl] for x in (q, k, v)]
     texts = [x[0, :, Sl:] for x in (q, k, v)] if T else None
-    lay.scatter_heads(shards, bufs[:3], order, texts)
     qv, kv, vv, ov = (lay.head_view(b) for b in bufs)
     me = SP_STATE.group_local_rank
     local = [experts[h] for h in order[me * lay.Hl:(me + 1) * lay.Hl]]
-    if dense_only:
-        rm = lay.row_map
-        ops.attn_fwd(qv, kv, vv, ov, n_q=S + T, n_kv=S + te, q_valid=S + te, q_rows=rm[:S + T], kv_rows=rm[:S + te])
-    else:
-        routed_attention(qv, kv, vv, HeadRouting.from_expert_ids(local, q.device), geom, model=model, text_len=T,
-                         text_valid=te, out=ov)
+    rm = lay.row_map
+
+    def attend(g0, g1, gi):
+        if dense_only:
+            ops.attn_fwd(qv[g0:g1], kv[g0:g1], vv[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
+                         q_rows=rm[:S + T], kv_rows=rm[:S + te])
+        else:
+            routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], HeadRouting.from_expert_ids(local[g0:g1], q.device), geom,
+                             model=model, text_len=T, text_valid=te, out=ov[g0:g1])
+
     # the received heads are written straight into the (1, N, H, D) result the output projection reads
     buf = torch.empty((1, N, H, D), dtype=q.dtype, device=q.device)
-    lay.gather_heads(bufs[3], buf[0, :Sl].transpose(0, 1), order, buf[0, Sl:].transpose(0, 1) if T else None)
+    exchange_and_attend(lay, shards, bufs, order, texts, slot_groups(lay.Hl, groups), attend,
+                        buf[0, :Sl].transpose(0, 1), buf[0, Sl:].transpose(0, 1) if T else None)
     return buf
 
 

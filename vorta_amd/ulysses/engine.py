@@ -24,20 +24,55 @@ import torch
 import torch.distributed as dist
 
 
-def balanced_head_order(experts: Sequence[int], cost_of_expert: Sequence[float], P: int) -> List[int]:
+def balanced_head_order(experts: Sequence[int], cost_of_expert: Sequence[float], P: int, groups: int = 1) -> List[int]:
     """Heads grouped by destination rank (rank j owns order[j*Hl:(j+1)*Hl]): exactly Hl heads per rank,
-    greedy longest-processing-time on the expert costs, ascending heads inside a rank. Deterministic, so
-    every rank computes the same order without communicating."""
+    greedy longest-processing-time on the expert costs.  Inside a rank the heads are ascending (groups = 1) or,
+    for the overlapped exchange, split the same way into `groups` equal slot groups of near-equal cost (ascending
+    inside a group).  Deterministic, so every rank computes the same order without communicating."""
     H = len(experts)
     assert H % P == 0, f"heads {H} must be divisible by the sequence-parallel size {P}"
     Hl = H // P
-    load = [0.0] * P
-    bins: List[List[int]] = [[] for _ in range(P)]
-    for h in sorted(range(H), key=lambda i: (-cost_of_expert[int(experts[i])], i)):
-        j = min((r for r in range(P) if len(bins[r]) < Hl), key=lambda r: (load[r], r))
-        bins[j].append(h)
-        load[j] += cost_of_expert[int(experts[h])]
-    return [h for b in bins for h in sorted(b)]
+    assert Hl % groups == 0, f"{Hl} heads per rank do not split into {groups} slot groups"
+
+    def lpt(heads, n_bins, size):
+        load = [0.0] * n_bins
+        bins: List[List[int]] = [[] for _ in range(n_bins)]
+        for h in sorted(heads, key=lambda i: (-cost_of_expert[int(experts[i])], i)):
+            j = min((r for r in range(n_bins) if len(bins[r]) < size), key=lambda r: (load[r], r))
+            bins[j].append(h)
+            load[j] += cost_of_expert[int(experts[h])]
+        return bins
+
+    order: List[int] = []
+    for b in lpt(range(H), P, Hl):
+        if groups == 1:
+            order += sorted(b)
+        else:
+            for g in lpt(b, groups, Hl // groups):
+                order += sorted(g)
+    return order
+
+
+def slot_groups(Hl: int, groups: int) -> List[tuple]:
+    n = Hl // groups
+    return [(g * n, (g + 1) * n) for g in range(groups)]
+
+
+def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, groups, attend, out_shard, out_text):
+    """One layer under sequence parallelism.  `groups` = slot ranges of the local heads; `attend(g0, g1, index)`
+    enqueues the attention over local head slots [g0, g1) of the layout buffers.  With one group this is
+    scatter -> attention -> gather.  With several, the exchange of group g+1 and the return of group g-1 are in
+    flight while group g computes (both run on the communicator's stream, the attention on the current one)."""
+    handles = lay.scatter_heads_start(shards, bufs[:3], head_order, texts, groups)
+    state = lay.gather_heads_begin(out_shard, head_order)
+    back = []
+    for gi, (g0, g1) in enumerate(groups):
+        lay._finish(handles[gi])
+        attend(g0, g1, gi)
+        back.append(lay.gather_heads_start(bufs[3], state, (g0, g1)))
+    for h in back:
+        lay._finish(h)
+    lay.gather_heads_end(bufs[3], state, out_text)
 
 
 def make_row_map(S: int, T: int, P: int, Hl: int, device) -> torch.Tensor:
@@ -80,15 +115,15 @@ class UlyssesLayout:
         # the process group is gloo but the tensors live on a GPU (tests / 1-GPU rehearsals); RCCL is direct.
         return self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
 
-    def _run(self, p2p):
-        """p2p: list of ("send"|"recv", tensor, peer)."""
+    def _start(self, p2p):
+        """Enqueue one group of point-to-point operations; returns a handle for `_finish`.
+        p2p: list of ("send"|"recv", tensor, peer).  RCCL: asynchronous (the transfer runs on the communicator's
+        stream, ordered after everything already enqueued on the current stream); gloo rehearsal: completes here."""
         if not p2p:
-            return
+            return None
         if not self._staged():
             ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._peer(j), self.group) for k, t, j in p2p]
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-            return
+            return ("works", dist.batch_isend_irecv(ops))
         host = [(k, t, t.detach().to("cpu") if k == "send" else torch.empty(t.shape, dtype=t.dtype), j) for k, t, j in p2p]
         ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, h, self._peer(j), self.group) for k, t, h, j in host]
         for r in dist.batch_isend_irecv(ops):
@@ -96,6 +131,17 @@ class UlyssesLayout:
         for k, t, h, j in host:
             if k == "recv":
                 t.copy_(h)
+        return None
+
+    @staticmethod
+    def _finish(handle):
+        """Make the current stream wait for a group started by `_start` (no host synchronisation under RCCL)."""
+        if handle is not None:
+            for r in handle[1]:
+                r.wait()
+
+    def _run(self, p2p):
+        self._finish(self._start(p2p))
 
     def _stage(self, key):
         """(H, Sl, D) staging buffers in head_order (one per tensor slot), allocated once per layout."""
@@ -121,9 +167,19 @@ class UlyssesLayout:
         straight from the shard when they already are (a run of consecutive heads of a contiguous shard),
         otherwise one gather pass (`index_select` into a staging buffer) orders all heads at once -- the
         projection output is a strided (S, H*D) view anyway, so this replaces the per-head `.contiguous()`."""
+        self._finish(self.scatter_heads_start(shards, bufs, head_order, texts)[0])
+
+    def scatter_heads_start(self, shards: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor],
+                            head_order: Sequence[int], texts: Optional[Sequence[torch.Tensor]] = None,
+                            groups: Optional[Sequence[Sequence[int]]] = None):
+        """`scatter_heads` split by local head slots: `groups` = [(slot0, slot1), ...] (default: one group with all
+        Hl slots).  One point-to-point group is started per slot group, in order; returns their handles, so the
+        attention over the slots of group g can be enqueued after `_finish(handles[g])` while later groups are still
+        in flight."""
         Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
         blk = Hl * Sl
-        p2p = []
+        groups = [(0, Hl)] if groups is None else [tuple(g) for g in groups]
+        srcs = []
         idx = None
         for t, (x, buf) in enumerate(zip(shards, bufs)):
             direct = x.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
@@ -137,18 +193,24 @@ class UlyssesLayout:
                 torch.index_select(x, 0, idx, out=src)
                 first = [j * Hl for j in range(P)]
             buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D).copy_(src[first[me]:first[me] + Hl])
-            for j in range(P):
-                if j != me:
-                    p2p.append(("send", src[first[j]:first[j] + Hl], j))
-            for j in range(P):
-                if j != me:
-                    p2p.append(("recv", buf[j * blk:(j + 1) * blk], j))
+            srcs.append((src, first, buf))
         if texts is not None and self.T:
             for t, buf in zip(texts, bufs):  # t: (H, T, D) replicated
                 for i in range(Hl):
                     r0 = self.rows_video + i * Sl
                     buf[r0:r0 + self.T].copy_(t[head_order[me * Hl + i]])
-        self._run(p2p)
+        handles = []
+        for g0, g1 in groups:
+            p2p = []
+            for src, first, buf in srcs:
+                for j in range(P):
+                    if j != me:
+                        p2p.append(("send", src[first[j] + g0:first[j] + g1], j))
+                for j in range(P):
+                    if j != me:
+                        p2p.append(("recv", buf[j * blk + g0 * Sl:j * blk + g1 * Sl], j))
+            handles.append(self._start(p2p))
+        return handles
 
     # ---- head shards -> sequence shards -------------------------------------------------------------
     def gather_heads(self, buf: torch.Tensor, out_shard: torch.Tensor, head_order: Sequence[int],
@@ -156,22 +218,39 @@ class UlyssesLayout:
         """inverse of scatter_heads for the attention output: out_shard (H, Sl, D), any strides.  One message per
         peer; received head blocks go straight into out_shard when their heads are a consecutive run of a
         contiguous out_shard, else through a staging buffer and one `index_copy_`."""
-        Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
-        blk = Hl * Sl
+        state = self.gather_heads_begin(out_shard, head_order)
+        self._finish(self.gather_heads_start(buf, state))
+        self.gather_heads_end(buf, state, out_text)
+
+    def gather_heads_begin(self, out_shard: torch.Tensor, head_order: Sequence[int]):
+        Hl, P = self.Hl, self.P
         direct = out_shard.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
         dst = out_shard if direct else self._stage(("g", 0))
         first = [self._run_of(head_order, j * Hl, Hl) if direct else j * Hl for j in range(P)]
+        return dict(out_shard=out_shard, order=list(head_order), direct=direct, dst=dst, first=first)
+
+    def gather_heads_start(self, buf: torch.Tensor, state, slots: Optional[Sequence[int]] = None):
+        """send the attention output of local head slots [slot0, slot1) (default: all) back; returns the handle"""
+        Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
+        blk = Hl * Sl
+        g0, g1 = (0, Hl) if slots is None else slots
+        dst, first = state["dst"], state["first"]
+        dst[first[me] + g0:first[me] + g1].copy_(buf[me * blk + g0 * Sl:me * blk + g1 * Sl].view(g1 - g0, Sl, self.D))
         p2p = []
-        dst[first[me]:first[me] + Hl].copy_(buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D))
         for j in range(P):
             if j != me:
-                p2p.append(("send", buf[j * blk:(j + 1) * blk], j))
+                p2p.append(("send", buf[j * blk + g0 * Sl:j * blk + g1 * Sl], j))
         for j in range(P):
             if j != me:
-                p2p.append(("recv", dst[first[j]:first[j] + Hl], j))
-        self._run(p2p)
-        if not direct:
-            out_shard.index_copy_(0, torch.as_tensor(list(head_order), device=out_shard.device), dst)
+                p2p.append(("recv", dst[first[j] + g0:first[j] + g1], j))
+        return self._start(p2p)
+
+    def gather_heads_end(self, buf: torch.Tensor, state, out_text: Optional[torch.Tensor] = None):
+        """after every slot group's handle was finished: un-permute (if staged) and all-gather the text rows"""
+        Hl, Sl = self.Hl, self.Sl
+        out_shard, head_order = state["out_shard"], state["order"]
+        if not state["direct"]:
+            out_shard.index_copy_(0, torch.as_tensor(head_order, device=out_shard.device), state["dst"])
         if out_text is not None and self.T:
             local = torch.stack([buf[self.rows_video + i * Sl: self.rows_video + i * Sl + self.T] for i in range(Hl)])
             parts = [torch.empty_like(local) for _ in range(self.P)]
@@ -193,7 +272,7 @@ class UlyssesRoutedAttention:
 
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
                  rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
-                 sliding_block_rows: int = 0):
+                 sliding_block_rows: int = 0, groups: int = 1):
         from ..routed import HeadRouting, RoutedGeometry
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
@@ -205,11 +284,12 @@ class UlyssesRoutedAttention:
                                    torch.device(device), row_map=self.lay.row_map)
         costs = [cost_of_expert["full"], cost_of_expert["lowres"], cost_of_expert["sliding"]]
         self.orders, self.routes = [], []
+        self.groups = slot_groups(self.lay.Hl, groups)  # > 1: exchange of one slot group overlaps another's attention
         for e in layer_experts:
-            order = balanced_head_order(e, costs, P)
+            order = balanced_head_order(e, costs, P, groups)
             self.orders.append(order)
             local = [int(e[h]) for h in order[rank * self.lay.Hl:(rank + 1) * self.lay.Hl]]
-            self.routes.append(HeadRouting.from_expert_ids(local, device))
+            self.routes.append([HeadRouting.from_expert_ids(local[g0:g1], device) for g0, g1 in self.groups])
         self.sets = []
         for i in range(n_sets):
             gen = torch.Generator(device=device).manual_seed(1234 + 97 * i + rank)
@@ -226,10 +306,12 @@ class UlyssesRoutedAttention:
     def layer(self, l: int):
         from ..routed import routed_attention
         shards, texts = self.sets[l % len(self.sets)]
-        order = self.orders[l]
-        self.lay.scatter_heads(shards, self.bufs[:3], order, texts)
         q, k, v, o = (self.lay.head_view(b) for b in self.bufs)
-        routed_attention(q, k, v, self.routes[l], self.geom, model=self.cfg["model"], text_len=self.cfg["text"],
-                         text_valid=self.te, out=o, concurrent=self.concurrent, fused=self.fused,
-                         sliding_block_rows=self.sliding_block_rows)
-        self.lay.gather_heads(self.bufs[3], self.out_shard, order, self.out_text)
+
+        def attend(g0, g1, gi):
+            routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], self.geom, model=self.cfg["model"],
+                             text_len=self.cfg["text"], text_valid=self.te, out=o[g0:g1], concurrent=self.concurrent,
+                             fused=self.fused, sliding_block_rows=self.sliding_block_rows)
+
+        exchange_and_attend(self.lay, shards, self.bufs, self.orders[l], texts, self.groups, attend, self.out_shard,
+                            self.out_text)
