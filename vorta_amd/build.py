@@ -15,8 +15,10 @@ LIB = os.path.join(CSRC, "libvorta_hip.so")
 SOURCES = ["api.hip", "attn_fwd.hip", "coreset.hip", "sta_tables.hip", "router.hip", "qk_norm_rope.hip", "mix.hip"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent fp32 adds of the softmax row sum into v_pk_add_f32 plus the
 # v_mov pairs to feed them -- more instructions on the VALU issue port that bounds the attention loop (+2 % without)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-I" + INCLUDE, "-I" + CSRC,
-         "-Wno-unused-result"]
+# -enable-post-misched=0: the post-RA scheduler re-orders the hand-interleaved MFMA / VALU / LDS stream of the attention
+# loop for the worse (+1.7 % on the fused layer kernel without it; measured A/B in one session)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-enable-post-misched=0",
+         "-I" + INCLUDE, "-I" + CSRC, "-Wno-unused-result"]
 
 
 def _newer(src, dst):
