@@ -301,7 +301,10 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   constexpr int QB = NW * 32;
   constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
   constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
-  constexpr int KPRE = 2;              // k-steps of K fragments read ahead of the softmax head
+#ifndef VORTA_KPRE
+#define VORTA_KPRE 2
+#endif
+  constexpr int KPRE = VORTA_KPRE;     // k-steps of K fragments read ahead of the softmax head
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
