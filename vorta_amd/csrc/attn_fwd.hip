@@ -499,25 +499,27 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #endif
 
   // Issue-order recipe for the step's basic block (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x400 transcendental,
-  // 0x002 VALU).  Score phase: per MFMA one K-fragment read, two exp, three plain VALU (sum, convert); PV phase: per
-  // MFMA the two transposed V reads and two VALU of the next block's row max.  With the post-RA scheduler off
-  // (build.py) the recipe is what the hardware sees: +1.1-1.4 % on the dense launch, +3.6-3.9 % on the table-driven
-  // (coreset, sliding) launches; coarser or finer groupings measured neutral or slower.  -DVORTA_SCHED=0 disables it.
+  // 0x002 VALU).  Score phase: per MFMA one K-fragment read, two exp, two plain VALU (the converts and half of the row
+  // sum); PV phase: per MFMA the two transposed V reads and four VALU (the rest of the row sum, the next block's row
+  // max).  The score phase is the issue-bound one (exp costs two slots), so everything that can wait moves under the PV
+  // MFMAs.  With the post-RA scheduler off (build.py) the recipe is what the hardware sees: +3.5 % on the dense launch
+  // and +4 % on the fused layer kernel against no recipe; a dozen other groupings measured between -3 % and +2 %.
+  // -DVORTA_SCHED=0 disables it.
 #ifndef VORTA_SCHED
-#define VORTA_SCHED 2
+#define VORTA_SCHED 1
 #endif
-#if VORTA_SCHED == 2
+#if VORTA_SCHED == 1
 #define SCHED_RECIPE()                                                            \
   _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                            \
   }                                                                               \
   _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
   }
 #else
 #define SCHED_RECIPE()
