@@ -205,7 +205,18 @@ def attn_fwd_batch(calls) -> None:
         built.append((a, ws, tag, flops))
     if not built:
         return
-    fusable = 1 < len(built) <= 4 and all(_plan(a)[0] == 256 and a.variant != 1 for a, _, _, _ in built)
+    ok = [_plan(a)[0] == 256 and a.variant != 1 for a, _, _, _ in built]
+    fusable = 1 < len(built) <= 4 and all(ok)
+    if not fusable and 2 <= sum(ok) <= 4 and sum(ok) < len(built):
+        # mixed workgroup sizes: fuse the 256-row launches, run the others on their own (in list order after them)
+        attn_fwd_batch_built([b for b, o in zip(built, ok) if o])
+        attn_fwd_batch_built([b for b, o in zip(built, ok) if not o], fuse=False)
+        return
+    attn_fwd_batch_built(built, fuse=fusable)
+
+
+def attn_fwd_batch_built(built, fuse: bool = True) -> None:
+    fusable = fuse and len(built) > 1
     if not fusable:
         for a, ws, tag, flops in built:
             if _timeline is not None:
