@@ -547,3 +547,20 @@ def test_routed_attention_random_configs(seed):
         assert np.abs(got[0, h] - ref[0, h]).max() <= ATOL_SAME[dtype], (desc, h)
     if T:
         assert (got[0, :, Sv + te:] == 0).all(), desc
+
+
+def test_mixed_block_sizes_in_one_layer():
+    """sliding launch on 128-row workgroups next to the fused 256-row launches of the other experts
+    (ops.attn_fwd_batch fuses what it can): same bits as the fully fused layer and as one launch per expert"""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    torch.manual_seed(3)
+    latent, tile, group = (6, 6, 8), (2, 3, 4), (2, 3, 2)
+    Sv, T, te, H = 6 * 6 * 8, 24, 17, 6
+    q, k, v = (torch.randn((1, H, Sv + T, 128), device=dev()).to(torch.bfloat16) for _ in range(3))
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
+    routing = HeadRouting.from_expert_ids([0, 1, 2, 2, 1, 0], dev())
+    kw = dict(model="hunyuan", text_len=T, text_valid=te)
+    fused = routed_attention(q, k, v, routing, geom, **kw)
+    mixed = routed_attention(q, k, v, routing, geom, sliding_block_rows=128, **kw)
+    serial = routed_attention(q, k, v, routing, geom, fused=False, **kw)
+    assert torch.equal(fused, mixed) and torch.equal(fused, serial)
