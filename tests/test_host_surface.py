@@ -167,3 +167,15 @@ def test_tile_layout_module_matches_reference_permutation(sp):
     assert torch.equal(untile_layout(tile_layout(x2, sp, tile, latent), sp, tile, latent), x2)
     with pytest.raises(ValueError):
         tile_layout(x, 1, (3, 3, 4), latent, head_dim=1)
+
+
+def test_integration_md_stub_matches_the_library():
+    """the ctypes struct a reference maintainer would paste has the layout of vorta_attn_args"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = text[text.index("_lib = None"):text.index("def dense_attention")]
+    ns = {"C": ctypes}
+    exec(code, ns)
+    from vorta_amd import _C
+    assert ctypes.sizeof(ns["_AttnArgs"]) == _C.lib().vorta_sizeof(1) == ctypes.sizeof(_C.AttnArgs)
+    assert [f[0] for f in ns["_AttnArgs"]._fields_] == [f[0] for f in _C.AttnArgs._fields_]
