@@ -300,3 +300,22 @@ def test_table_extents_are_checked_on_the_host():
                dict(q_rows=i32(200), dup_rows=i32(2, 10, 2))):  # per-slot duplicate lists for 2 of 3 slots
         with pytest.raises(ValueError):
             ops.attn_fwd(q, k, v, out, n_q=200, n_kv=100, **kw)
+
+
+def test_integration_md_stub_runs():
+    """the ctypes binding printed in INTEGRATION.md, executed as is (library path made absolute), gives the same
+    bits as the package's own launcher, including zeroed rows past the valid length"""
+    import os
+    from vorta_amd import _C, ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = text[text.index("# vorta/attention/_hip.py"):text.index("# hunyuan.py:170-176 becomes")]
+    code = code.replace('"libvorta_hip.so"', repr(_C.LIB_PATH))
+    ns = {}
+    exec(code, ns)
+    torch.manual_seed(0)
+    q, k, v = (torch.randn((1, 3, 300, 128), device=dev()).to(torch.bfloat16) for _ in range(3))
+    got = ns["dense_attention"](q, k, v, 280)
+    want = torch.empty_like(q)
+    ops.attn_fwd(q[0], k[0], v[0], want[0], n_q=300, n_kv=280, q_valid=280)
+    assert torch.equal(got, want) and torch.all(got[:, :, 280:] == 0)
