@@ -179,3 +179,23 @@ def test_integration_md_stub_matches_the_library():
     from vorta_amd import _C
     assert ctypes.sizeof(ns["_AttnArgs"]) == _C.lib().vorta_sizeof(1) == ctypes.sizeof(_C.AttnArgs)
     assert [f[0] for f in ns["_AttnArgs"]._fields_] == [f[0] for f in _C.AttnArgs._fields_]
+
+
+def test_torch_custom_ops_are_registered_with_shape_functions():
+    """torch.ops.vorta.*: schemas with declared mutations, fake (shape) functions usable without a GPU"""
+    import vorta_amd.torch_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    names = {"attn_fwd", "coreset_select", "sta_build_tables", "route_scores", "router_route", "qk_norm_rope", "mix_experts"}
+    assert names <= set(dir(torch.ops.vorta))
+    schema = str(torch.ops.vorta.attn_fwd.default._schema)
+    assert "Tensor(a3!) out" in schema and "Tensor? kv_rows=None" in schema and schema.endswith("-> ()")
+    assert "Tensor(a0!) x" in str(torch.ops.vorta.qk_norm_rope.default._schema)
+    with FakeTensorMode():
+        x = torch.empty((3, 8 * 6 * 8 + 5, 128), dtype=torch.bfloat16, device="cuda")
+        keep, drop = torch.ops.vorta.coreset_select(x, [8, 6, 8], [2, 3, 2], 5, tail_first=384, n_tail=5)
+        assert keep.shape == (3, 32 * 6 + 5) and drop.shape == (3, 32, 6) and keep.dtype == torch.int32
+        q_rows, kv_rows = torch.ops.vorta.sta_build_tables(x, [8, 6, 8], [2, 3, 4], [3, 3, 3], 4)
+        assert q_rows.shape == (384,) and kv_rows.shape[0] == 16
+        e, lists, counts = torch.ops.vorta.route_scores(torch.empty((1, 6, 3), device="cuda"), 0.3)
+        assert e.shape == (6,) and lists.shape == (3, 6) and counts.shape == (3,)
+        assert torch.ops.vorta.attn_fwd(x, x, x, torch.empty_like(x), 10, 10) is None
