@@ -264,7 +264,7 @@ def main():
         "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
-                   "parallelism": "single GPU" if P == 1 else f"ulysses sp{P} (RCCL send/recv over xGMI)"
+                   "parallelism": "single GPU" if P == 1 else f"ulysses sp{P} (RCCL all-to-all over xGMI)"
                    + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else ""),
                    "experts": {"fused": "one fused grid per layer", "serial": "one launch per expert",
                                "concurrent": "experts on side streams"}[args.experts],

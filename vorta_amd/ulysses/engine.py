@@ -1,4 +1,4 @@
-"""Zero-copy Ulysses sequence parallelism for the routed attention op (MI355X: RCCL send/recv over xGMI).
+"""Zero-copy Ulysses sequence parallelism for the routed attention op (MI355X: RCCL all-to-all over xGMI).
 
 Reference flow per tensor (vorta/ulysses/utils.py:61-91): transpose+contiguous -> all_to_all_single ->
 device sync -> transpose+contiguous, i.e. four extra HBM passes per tensor and a host stall, applied per
@@ -22,6 +22,12 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+# Transport of the head exchange.  "a2a" (default): one all_to_all_single per tensor whenever the chunks are in rank
+# order (always, once the heads went through the staging pass); "p2p": grouped send/recv for everything.  Slot-group
+# (overlapped) exchanges and shards sent straight from a permuted-but-contiguous source always use send/recv.
+TRANSPORT = __import__("os").environ.get("VORTA_SP_TRANSPORT", "a2a")
 
 
 def balanced_head_order(experts: Sequence[int], cost_of_expert: Sequence[float], P: int, groups: int = 1) -> List[int]:
@@ -143,6 +149,20 @@ class UlyssesLayout:
     def _run(self, p2p):
         self._finish(self._start(p2p))
 
+    def _start_a2a(self, pairs):
+        """One `all_to_all_single` per (input, output) pair -- the collective the reference uses
+        (vorta/ulysses/utils.py:47,79) -- on (P*n, D) row blocks whose P equal chunks are contiguous on both sides
+        (chunk j of the input goes to rank j, chunk j of the output comes from rank j; the own chunk is copied by the
+        collective).  Asynchronous under RCCL; returns a handle for `_finish`."""
+        if not self._staged():
+            return ("works", [dist.all_to_all_single(o, i, group=self.group, async_op=True) for i, o in pairs])
+        for i, o in pairs:
+            hi = i.detach().to("cpu")
+            ho = torch.empty(o.shape, dtype=o.dtype)
+            dist.all_to_all_single(ho, hi, group=self.group)
+            o.copy_(ho)
+        return None
+
     def _stage(self, key):
         """(H, Sl, D) staging buffers in head_order (one per tensor slot), allocated once per layout."""
         st = self.__dict__.setdefault("_stages", {})
@@ -192,13 +212,18 @@ class UlyssesLayout:
                 src = self._stage(("s", t))
                 torch.index_select(x, 0, idx, out=src)
                 first = [j * Hl for j in range(P)]
-            buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D).copy_(src[first[me]:first[me] + Hl])
             srcs.append((src, first, buf))
         if texts is not None and self.T:
             for t, buf in zip(texts, bufs):  # t: (H, T, D) replicated
                 for i in range(Hl):
                     r0 = self.rows_video + i * Sl
                     buf[r0:r0 + self.T].copy_(t[head_order[me * Hl + i]])
+        in_rank_order = all(first == [j * Hl for j in range(P)] for _, first, _ in srcs)
+        if TRANSPORT == "a2a" and groups == [(0, Hl)] and in_rank_order and P > 1:
+            # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides
+            return [self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs])]
+        for src, first, buf in srcs:
+            buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D).copy_(src[first[me]:first[me] + Hl])
         handles = []
         for g0, g1 in groups:
             p2p = []
@@ -235,6 +260,8 @@ class UlyssesLayout:
         blk = Hl * Sl
         g0, g1 = (0, Hl) if slots is None else slots
         dst, first = state["dst"], state["first"]
+        if TRANSPORT == "a2a" and (g0, g1) == (0, Hl) and first == [j * Hl for j in range(P)] and P > 1:
+            return self._start_a2a([(buf[:P * blk], dst.view(self.H * Sl, self.D))])
         dst[first[me] + g0:first[me] + g1].copy_(buf[me * blk + g0 * Sl:me * blk + g1 * Sl].view(g1 - g0, Sl, self.D))
         p2p = []
         for j in range(P):
