@@ -38,7 +38,7 @@ CONFIGS = {
     # BASELINE.json configs[1]
     "wan1.3b-81f": dict(model="wan", latent=(21, 30, 52), heads=12, layers=30, fwd_per_step=2, text=0, text_valid=0,
                         tile=(7, 6, 4), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
-    # BASELINE.json configs[4] geometry in bf16 (the fp8 path is not built yet)
+    # BASELINE.json configs[4] geometry; --dtype fp8 runs its fp8 MFMA path (bf16 is the same-box A/B arm)
     "wan14b-81f": dict(model="wan", latent=(21, 45, 80), heads=40, layers=40, fwd_per_step=2, text=0, text_valid=0,
                        tile=(7, 9, 8), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
     "wan14b-77f": dict(model="wan", latent=(20, 45, 80), heads=40, layers=40, fwd_per_step=2, text=0, text_valid=0,
@@ -52,6 +52,7 @@ MIXES = {"all-full": (1, 0, 0), "all-lowres": (0, 1, 0), "all-sliding": (0, 0, 1
          "sparse-heavy": (1 / 6, 1 / 3, 1 / 2)}
 
 PEAK_MFMA_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_MFMA_FP8_TFLOPS = 5000.0  # dense fp8 MFMA peak (same table; the 10 PF figure includes 2:1 sparsity)
 
 
 def layer_experts(cfg, mix, layer, heads=None):
@@ -118,7 +119,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="hunyuan-129f", choices=sorted(CONFIGS))
     ap.add_argument("--mix", default="uniform", choices=sorted(MIXES))
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp8"],
+                    help="fp8: bf16 inputs, converted to e4m3 inside the timed step (vorta_fp8_quantize_qkv), both "
+                         "contractions on the fp8 MFMA, bf16 output")
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
     ap.add_argument("--sp-groups", type=int, default=int(os.environ.get("VORTA_SP_GROUPS", "1")),
                     help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
@@ -162,6 +165,8 @@ def main():
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
 
     dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16
+    fp8 = cfg["dtype"] == "fp8"
+    peak = PEAK_MFMA_FP8_TFLOPS if fp8 else PEAK_MFMA_TFLOPS
     H, L, T, te = cfg["heads"], cfg["layers"], cfg["text"], cfg["text_valid"]
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
@@ -183,6 +188,8 @@ def main():
             gen = torch.Generator(device=dev).manual_seed(1234 + i)
             sets.append(tuple(torch.randn((1, H, S + T, 128), generator=gen, device=dev, dtype=dt) for _ in range(3)))
         out = torch.empty_like(sets[0][0])
+        # e4m3 operand buffers reused by every layer (the conversion itself runs per layer, inside the step)
+        f8buf = ops.fp8_quantize_qkv(*(x[0] for x in sets[0])) if fp8 else None
         if te:
             geom.sta_tables(te)  # built once per prompt, outside the step (pipeline_hunyuan.py:378-392)
 
@@ -191,8 +198,11 @@ def main():
                 for l in range(L):
                     q, k, v = sets[l % len(sets)]
                     routed_attention(q, k, v, routings[l], geom, model=cfg["model"], text_len=T, text_valid=te, out=out,
-                                     concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows)
+                                     concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
+                                     fp8=fp8, fp8_operands=f8buf)
     else:
+        if fp8:
+            raise SystemExit("--dtype fp8 with --gpus N>1 is not wired yet")
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
                                             concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
@@ -236,8 +246,8 @@ def main():
     dom = by_kernel[dom_sym]
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     roofline = {"bound": "mfma", "kernel": dom_sym,
-                "achieved": round(achieved, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
                 "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                 "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                 "share_of_step": round(dom["ms"] / (ms_per_step * args.steps), 3)}

@@ -31,9 +31,14 @@ extern "C" {
 #define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
 #define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
 
-#define VORTA_ABI_VERSION 1
+#define VORTA_ABI_VERSION 2 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); every v1 call is unchanged */
 
-typedef enum vorta_dtype { VORTA_BF16 = 0, VORTA_FP16 = 1, VORTA_FP32 = 2 /* vorta_route_scores only */ } vorta_dtype;
+typedef enum vorta_dtype {
+  VORTA_BF16 = 0,
+  VORTA_FP16 = 1,
+  VORTA_FP32 = 2,    /* vorta_route_scores only */
+  VORTA_FP8E4M3 = 3  /* OCP e4m3fn bytes: q/k/v of vorta_attn_fwd_fp8, output of vorta_fp8_quantize_qkv */
+} vorta_dtype;
 
 /* One (H,S,D) operand: element (h,s,d) lives at ptr + h*stride_h + s*stride_s + d. */
 typedef struct vorta_tensor {
@@ -118,6 +123,60 @@ int vorta_attn_plan(const vorta_attn_args* args, int32_t* block_rows, int64_t* n
  *   attn_fwd_kernel<T,NW> (plain) or attn_fwd_pipe_kernel<T,NW,KVTAB> */
 /* bytes of ws_o and ws_ml for a given launch (0,0 when n_splits <= 1) */
 int vorta_attn_workspace_bytes(const vorta_attn_args* args, uint64_t* ws_o_bytes, uint64_t* ws_ml_bytes);
+
+/*
+ * fp8 (e4m3) path -- BASELINE.json configs[4] "fp8 MFMA QK^T/PV path".  The reference has no fp8 code: this path serves
+ * the same three experts (wan.py:243-294, hunyuan.py:410-507) with both contractions on
+ * v_mfma_f32_32x32x64_f8f6f4 (2x the bf16 MFMA rate).  Two steps:
+ *
+ * vorta_fp8_quantize_qkv -- one pass over post-RoPE q,k,v (16-bit, (H,S,D) views) that writes e4m3 copies:
+ *     q8 = e4m3( q * qmul[h] ),  k8 = e4m3( k * kmul[h] ),  v8 = e4m3( v * vmul[h][d] )
+ *   qmul[h] * kmul[h] = qk_scale * log2(e): the softmax scale and the exp2 conversion are folded into the operands,
+ *   so q8 . k8 is the score in the exp2 domain and the kernel's softmax needs no multiply.  The split between q and k
+ *   balances their ranges: t = sqrt(amax_k / (c0 * amax_q)), qmul = c0 * t, kmul = 1 / t (amax over the head's tokens and
+ *   channels), which puts both maxima at sqrt(c0 * amax_q * amax_k) -- far inside e4m3's range (448), whose relative
+ *   precision (2^-4) does not depend on where in the normal range a value sits.  v is scaled per head and channel to
+ *   amax -> 240; v_descale[h][d] = amax_v[h][d] / 240 is applied to the output row in the attention epilogue.
+ *   Enqueues 3 launches (abs-max reduction, scales, convert); nothing is read back to the host.
+ *
+ * vorta_attn_fwd_fp8 / _batch_fp8 -- vorta_attn_fwd / _batch with q,k,v = e4m3 (args->dtype = VORTA_FP8E4M3, strides
+ *   in BYTES = elements, rows 16-byte aligned); `scale` is ignored (folded, above); the probabilities are re-packed
+ *   to e4m3 as P * 2^p_bias with a running reference point at most `defer` below the row max (p_bias + defer <= 8, so
+ *   P * 2^p_bias <= 256 < 448); row sums come from one more MFMA against a ones tile (the same rounded P that
+ *   multiplies V); the output (ext->out_dtype, bf16 / fp16) is o[d] * v_descale[head][d] / rowsum.
+ *   Every other field of vorta_attn_args means what it means for vorta_attn_fwd (row tables, groups, duplicates,
+ *   split keys, device-resident lengths).
+ */
+typedef struct vorta_fp8_quant_args {
+  uint32_t struct_size;
+  int32_t dtype;            /* input dtype: VORTA_BF16 / VORTA_FP16 */
+  int32_t head_dim, heads;  /* 128, H */
+  int32_t n_tokens;         /* rows of every head to convert */
+  float qk_scale;           /* softmax scale (1/sqrt(D) in the reference) */
+  vorta_tensor q, k, v;     /* inputs, (H,S,D) views, strides in elements */
+  vorta_tensor q8, k8, v8;  /* outputs, e4m3, strides in bytes; rows 16-byte aligned */
+  float* v_descale;         /* [heads][head_dim] out */
+  float* ws;                /* workspace, vorta_fp8_quant_ws_floats(heads, head_dim) floats: abs-max slots + multipliers */
+  int32_t flags;            /* bit0: v scaled per head instead of per (head, channel) */
+  int32_t reserved;
+} vorta_fp8_quant_args;
+
+int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim);
+int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* args, void* hip_stream);
+
+typedef struct vorta_attn_fp8_ext {
+  uint32_t struct_size;
+  int32_t out_dtype;           /* VORTA_BF16 / VORTA_FP16: element type of args->o */
+  const float* v_descale;      /* [..][head_dim], indexed by the head id (not the slot) */
+  int64_t v_descale_stride_h;  /* floats between heads (head_dim) */
+  float p_bias;                /* log2 bias of the e4m3 probabilities; 0 = default (5) */
+  float defer;                 /* deferred-rescale threshold in log2 units; 0 = default (3); p_bias + defer <= 8 */
+  int32_t flags;               /* bit0: row sums by VALU adds of the unrounded P instead of the ones-tile MFMA */
+  int32_t reserved;
+} vorta_attn_fp8_ext;
+
+int vorta_attn_fwd_fp8(const vorta_attn_args* args, const vorta_attn_fp8_ext* ext, void* hip_stream);
+int vorta_attn_fwd_batch_fp8(const vorta_attn_args* args, const vorta_attn_fp8_ext* ext, int32_t n, void* hip_stream);
 
 /*
  * vorta_coreset_select -- coreset_select.py:68-124 (ranking part) + :159-166 (scatter destinations).
@@ -262,7 +321,7 @@ int vorta_abi_version(void);
 const char* vorta_build_info(void); /* static string: arch, compiler */
 int vorta_last_hip_error(void);     /* last hipError_t seen by a failed launch in this thread */
 int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args, 5 norm_rope_args,
-                                       6 mix_args */
+                                       6 mix_args, 7 fp8_quant_args, 8 attn_fp8_ext */
 
 #ifdef __cplusplus
 }

@@ -389,3 +389,172 @@ def flops_lowres(S_low: int, t_eff: int, D: int = 128) -> float:
 
 def flops_sliding(S: int, tok: int, n_kv_tiles: int, t_eff: int, D: int = 128) -> float:
     return 4.0 * D * (S * (n_kv_tiles * tok + t_eff) + t_eff * (S + t_eff))
+
+
+# ----------------------------------------------------------------------------------------------- fp8 (e4m3) path
+# BASELINE.json configs[4] names an "fp8 MFMA QK^T/PV path"; the reference has no fp8 code, so there is nothing to
+# restate from it.  What follows restates THIS build's own definition of that path (include/vorta_hip.h:
+# vorta_fp8_quantize_qkv, vorta_attn_fwd_fp8) so the kernels can be checked rounding point for rounding point:
+# the operands are e4m3 values, the scores are exact, the probabilities are rounded to e4m3 at the same reference
+# points the kernel uses, everything else is float64.  With round_p=False the same code is plain softmax attention
+# on the dequantised operands (and is checked against `_softmax_attend` in tests/test_oracle_fp8.py).
+E4M3_MAX = 448.0
+
+
+def e4m3_round(x: np.ndarray) -> np.ndarray:
+    """Round to the nearest OCP e4m3fn value (ties to even), saturating at +-448.  Normal numbers have 3 mantissa
+    bits (spacing 2^(e-3), e >= -6); below 2^-6 the spacing is 2^-9."""
+    x = np.asarray(x, dtype=np.float64)
+    a = np.minimum(np.abs(x), E4M3_MAX)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    e = np.maximum(e, -6.0)
+    q = np.exp2(e - 3.0)
+    r = np.rint(a / q) * q  # np.rint rounds half to even
+    return np.copysign(np.minimum(r, E4M3_MAX), x)
+
+
+def e4m3_encode(x: np.ndarray) -> np.ndarray:
+    """float (already on the e4m3 grid or not) -> uint8 bit patterns (sign, 4-bit exponent bias 7, 3-bit mantissa)."""
+    r = e4m3_round(x)
+    a = np.abs(r)
+    with np.errstate(divide="ignore"):
+        e = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    sub = a < 2.0 ** -6
+    ebits = np.where(sub, 0, e + 7).astype(np.int64)
+    mant = np.where(sub, np.rint(a * 512.0), np.rint((a / np.exp2(e) - 1.0) * 8.0)).astype(np.int64)
+    return ((np.signbit(r).astype(np.int64) << 7) | (ebits << 3) | mant).astype(np.uint8)
+
+
+def e4m3_decode(b: np.ndarray) -> np.ndarray:
+    b = np.asarray(b).astype(np.int64)
+    s, e, m = b >> 7, (b >> 3) & 15, b & 7
+    v = np.where(e == 0, m * 2.0 ** -9, (1.0 + m / 8.0) * np.exp2(e - 7.0))
+    v = np.where((e == 15) & (m == 7), np.nan, v)
+    return np.where(s == 1, -v, v)
+
+
+def fp8_quantize_qkv(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: Optional[float] = None,
+                     v_per_head: bool = False) -> dict:
+    """include/vorta_hip.h vorta_fp8_quantize_qkv on (H,S,D) arrays holding bf16/fp16-representable values.
+    The multipliers are computed in float32 like the kernel (fp8_quant.hip: fp8_scales_kernel), the products too."""
+    f32 = np.float32
+    q, k, v = (np.asarray(a, dtype=f32) for a in (q, k, v))
+    D = q.shape[-1]
+    c0 = f32(f32(1.0 / np.sqrt(D) if scale is None else scale) * f32(1.4426950408889634))
+    mq, mk = np.abs(q).max((1, 2)), np.abs(k).max((1, 2))
+    t = np.ones_like(mq)
+    ok = (mq > 0) & (mk > 0)
+    t[ok] = np.sqrt((mk[ok] / (c0 * mq[ok]).astype(f32)).astype(f32)).astype(f32)
+    qmul, kmul = (c0 * t).astype(f32), (f32(1.0) / t).astype(f32)
+    mv = np.abs(v).max(1)  # (H,D)
+    if v_per_head:
+        mv = np.broadcast_to(mv.max(1, keepdims=True), mv.shape).copy()
+    with np.errstate(divide="ignore"):
+        vmul = np.where(mv > 0, f32(240.0) / mv, f32(0.0)).astype(f32)
+    v_descale = (mv / f32(240.0)).astype(f32)
+    clamp = lambda a: np.clip(a, -E4M3_MAX, E4M3_MAX)
+    q8 = e4m3_encode(clamp((q * qmul[:, None, None]).astype(f32)))
+    k8 = e4m3_encode(clamp((k * kmul[:, None, None]).astype(f32)))
+    v8 = e4m3_encode(clamp((v * vmul[:, None, :]).astype(f32)))
+    return dict(q8=q8, k8=k8, v8=v8, qmul=qmul, kmul=kmul, vmul=vmul, v_descale=v_descale)
+
+
+# relative slack of the kernel's fp32 arithmetic against this float64 restatement: the MFMA accumulates 128 products
+# in fp32 (flips were observed up to 5e-5 from a midpoint, tools/dbg/fp8_err.py) and v_exp_f32 is good to ~1 ulp
+_FP8_AMBIG = 1e-4
+
+
+def _fp8_flash_rows(Q: np.ndarray, K: np.ndarray, V: np.ndarray, blk_lo: int, blk_hi: int, p_bias: float, defer: float,
+                    round_p: bool, block: int = 64, ambiguous: Optional[np.ndarray] = None):
+    """One wave of the fp8 kernel (<= 32 query rows, all sharing the reference-point decisions) over key blocks
+    [blk_lo, blk_hi).  Q (n,D), K/V (n_kv,D) are decoded e4m3 values; Q . K is the score in the exp2 domain.
+    Returns unnormalised O (n,D), row sums l (n,) and reference points m (n,), all relative to 2^p_bias.
+    attn_fwd_fp8.hip: the first block fixes m at its row max; later a block whose offset row max exceeds `defer` for
+    ANY row of the wave moves every row's reference to max(its own block max, its reference).
+    `ambiguous` (n,) float, optional: accumulates, per row, the P' of every probability that lies within fp32 noise of an
+    e4m3 rounding midpoint (a correct kernel may round those the other way); set to +inf for the whole wave when a
+    block max is within noise of `defer` (the reference point itself may differ)."""
+    n_kv = K.shape[0]
+    z_all = Q @ K[blk_lo * block:min(blk_hi * block, n_kv)].T
+    n = Q.shape[0]
+    O = np.zeros((n, V.shape[1]))
+    l = np.zeros(n)
+    m = None
+    for j in range(blk_lo, blk_hi):
+        lo, hi = (j - blk_lo) * block, min((j - blk_lo + 1) * block, z_all.shape[1])
+        z = z_all[:, lo:hi]
+        if m is None:
+            m = z.max(1)
+        else:
+            mx = (z - m[:, None]).max(1)
+            if ambiguous is not None and (np.abs(mx - defer) < 1e-4).any():
+                ambiguous[:] = np.inf
+            if (mx > defer).any():
+                g = np.maximum(mx, 0.0)
+                a = np.exp2(-g)
+                O *= a[:, None]
+                l *= a
+                if ambiguous is not None:
+                    ambiguous *= a
+                m = m + g
+        P = np.exp2(z - m[:, None] + p_bias)
+        if round_p:
+            if ambiguous is not None:
+                near = e4m3_round(P * (1 + _FP8_AMBIG)) != e4m3_round(P * (1 - _FP8_AMBIG))
+                ambiguous += (P * near).sum(1)
+            P = e4m3_round(P)
+        l += P.sum(1)
+        O += P @ V[j * block:j * block + (hi - lo)]
+    return O, l, m
+
+
+def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray, v_descale: np.ndarray, *,
+                    n_q: int, n_kv: int, q_rows: Optional[np.ndarray] = None, q_row_offset: int = 0,
+                    q_group_len: int = 0, q_valid: Optional[int] = None, kv_rows: Optional[np.ndarray] = None,
+                    kv_row_offset: int = 0, dup_rows: Optional[np.ndarray] = None, n_dup_pos: int = 0, n_splits: int = 1,
+                    p_bias: float = 5.0, defer: float = 3.0, round_p: bool = True,
+                    ambiguous: Optional[np.ndarray] = None) -> None:
+    """include/vorta_hip.h vorta_attn_fwd_fp8 for ONE head: q,k,v (rows,D) decoded e4m3 values, `out` (rows,D) is
+    written in place (rows named by q_rows / dup_rows only).  kv_rows: (n_kv,) or (n_groups, n_kv).
+    `ambiguous` (rows,) float, optional: per output row, the total normalised probability of the keys whose e4m3
+    rounding is within fp32 noise of a midpoint (see `_fp8_flash_rows`; 0 for most rows, inf where a reference point
+    is in doubt).  Each of those may move by one e4m3 step (<= 2^-3 relative), so a correct kernel differs from this
+    restatement by at most 2^-3 * that * (|v| + |o|) on top of its accumulation error."""
+    q_valid = n_q if q_valid is None else q_valid
+    glen = q_group_len if q_group_len > 0 else n_q
+    n_groups = -(-n_q // glen)
+    nblk = -(-n_kv // 64)
+    bps = -(-nblk // n_splits)
+    for g in range(n_groups):
+        pos = np.arange(g * glen, min((g + 1) * glen, n_q))
+        rows = q_rows[pos] if q_rows is not None else q_row_offset + pos
+        if kv_rows is None:
+            kr = kv_row_offset + np.arange(n_kv)
+        else:
+            kr = (kv_rows[g] if kv_rows.ndim == 2 else kv_rows)[:n_kv]
+        Kg, Vg = k[kr], v[kr]
+        for w0 in range(0, len(pos), 32):  # one wave = 32 consecutive positions of the group
+            sl = slice(w0, min(w0 + 32, len(pos)))
+            Qw = q[rows[sl]]
+            parts, ambs = [], []
+            for s in range(n_splits):
+                if s * bps < nblk:
+                    ambs.append(np.zeros(Qw.shape[0]) if ambiguous is not None else None)
+                    parts.append(_fp8_flash_rows(Qw, Kg, Vg, s * bps, min((s + 1) * bps, nblk), p_bias, defer, round_p,
+                                                 ambiguous=ambs[-1]))
+            mm = np.max([p[2] for p in parts], axis=0)
+            O = sum(p[0] * np.exp2(p[2] - mm)[:, None] for p in parts)
+            l = sum(p[1] * np.exp2(p[2] - mm) for p in parts)
+            res = np.where((pos[sl] < q_valid)[:, None] & (l > 0)[:, None], O / np.where(l > 0, l, 1.0)[:, None], 0.0)
+            res = res * v_descale[None, :]
+            out[rows[sl]] = res
+            if ambiguous is not None:
+                amb = sum(a * np.exp2(p[2] - mm) for a, p in zip(ambs, parts)) / np.where(l > 0, l, 1.0)
+                ambiguous[rows[sl]] = amb
+            if dup_rows is not None:
+                for i, p_ in enumerate(pos[sl]):
+                    if p_ < n_dup_pos:
+                        out[dup_rows[p_]] = res[i]
+                        if ambiguous is not None:
+                            ambiguous[dup_rows[p_]] = amb[i]

@@ -1,0 +1,309 @@
+"""GPU parity of the fp8 (e4m3) path -- BASELINE.json configs[4] "fp8 MFMA QK^T/PV path" -- through the C ABI
+(vorta_fp8_quantize_qkv, vorta_attn_fwd_fp8, vorta_attn_fwd_batch_fp8).
+
+The reference has no fp8 code, so the gates are this build's own, stated here and in DESIGN.md:
+  gate (i)   kernel vs the oracle's emulator (oracle/vorta_oracle.py: fp8_attn_launch) on the SAME e4m3 operands,
+             with the probabilities rounded to e4m3 at the same reference points: the existing 16-bit tolerances
+             (tests/_util.py ATOL_SAME / RELF_SAME of the OUTPUT dtype) -- what is left is fp32 accumulation.
+             A probability within fp32 noise (1e-4 relative; flips observed up to 5e-5) of an e4m3 rounding midpoint may legitimately round the
+             other way; the emulator returns, per row, the normalised mass `a` of those probabilities, and the row's
+             tolerance grows by 2^-3 * a * 2 max|v| (each of them moving one e4m3 step); `a` is 0 for most rows and
+             ~1e-3 otherwise.  Waves whose reference point itself is in doubt (a block max within 1e-4 of `defer`) are
+             skipped (none in these tests but for a handful of rows);
+  gate (i')  kernel vs exact softmax attention on the dequantised operands (no probability rounding): the cost of
+             packing P to e4m3, bounded at rel. Frobenius <= 3e-2;
+  gate (ii)  operator PSNR >= 40 dB against the bf16 kernel on the 16-bit inputs, Wan-14B-81f geometry, each expert:
+             10 log10(R^2 / mse) with R = the data range max - min of the bf16 output (the convention of
+             skimage.metrics.peak_signal_noise_ratio / torchmetrics for float data).  The stricter figure with
+             R = max |output| (6 dB lower for a symmetric signal) is printed beside it and held above 39 dB.  The inputs
+             are white noise (no structure for the quantisation noise to average against): the worst case.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vorta_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+from _util import ATOL_SAME, RELF_SAME, dev, rel_fro, rounded, to_dev  # noqa: E402
+
+RELF_PACK = 3e-2  # gate (i')
+
+
+def _decoded(f8):
+    """the GPU's e4m3 operands as float64 (H,S,D) arrays + v_descale (H,D)"""
+    return (O.e4m3_decode(f8.q.cpu().numpy()), O.e4m3_decode(f8.k.cpu().numpy()), O.e4m3_decode(f8.v.cpu().numpy()),
+            f8.v_descale.cpu().numpy().astype(np.float64))
+
+
+def _vmax(v8, vd):
+    return float(np.abs(v8 * vd[:, None, :]).max())
+
+
+def _check(out, ref, dtype, amb, vmax):
+    """amb: the emulator's per-row normalised mass of probabilities within fp32 noise of a rounding midpoint (inf =
+    reference point in doubt); vmax = max |v * v_descale|"""
+    out = out.float().cpu().numpy().reshape(-1, ref.shape[-1])
+    ref = ref.reshape(-1, ref.shape[-1])
+    amb = amb.reshape(-1)
+    ok = np.isfinite(amb)
+    assert ok.mean() >= 0.9, f"{(~ok).sum()} of {ok.size} rows have a reference point in doubt"
+    out, ref, amb = out[ok], ref[ok], amb[ok]
+    tol = ATOL_SAME[dtype] + 0.125 * amb * 2 * vmax
+    err = np.abs(out - ref).max(1)
+    assert (err <= tol).all(), f"max|d|={err.max():.3e} at slack {amb[err.argmax()]:.2e} (tol {tol[err.argmax()]:.3e})"
+    assert np.median(amb) < 1e-2
+    rf = rel_fro(out, ref)
+    assert rf <= RELF_SAME[dtype] + 0.125 * float(np.sqrt((amb ** 2).mean())) * 4, f"relF={rf:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_quantizer_matches_oracle_bit_for_bit(dtype):
+    from vorta_amd import ops
+    rng = np.random.default_rng(0)
+    H, S = 3, 1500
+    q = rng.standard_normal((H, S, 128)) * np.array([0.5, 1.0, 6.0])[:, None, None]
+    k = rng.standard_normal((H, S, 128)) * np.array([2.0, 1.0, 0.3])[:, None, None]
+    v = rng.standard_normal((H, S, 128)) * np.linspace(0.05, 8.0, 128)
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    f8 = ops.fp8_quantize_qkv(qd, kd, vd)
+    torch.cuda.synchronize()
+    z = O.fp8_quantize_qkv(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype))
+    qm, km, vm = (t.cpu().numpy() for t in f8.multipliers())
+    assert (qm == z["qmul"]).all() and (km == z["kmul"]).all() and (vm == z["vmul"]).all()
+    assert (f8.v_descale.cpu().numpy() == z["v_descale"]).all()
+    for name, t in (("q8", f8.q), ("k8", f8.k), ("v8", f8.v)):
+        assert (t.cpu().numpy() == z[name]).all(), name
+    # strided inputs ((S,H,D) storage) give the same bytes
+    packed = torch.stack([qd, kd, vd]).permute(0, 2, 1, 3).contiguous()  # (3,S,H,D)
+    g8 = ops.fp8_quantize_qkv(*(packed[i].permute(1, 0, 2) for i in range(3)))
+    assert torch.equal(g8.q, f8.q) and torch.equal(g8.k, f8.k) and torch.equal(g8.v, f8.v)
+    # one scale per head for v
+    h8 = ops.fp8_quantize_qkv(qd, kd, vd, v_per_head=True)
+    zh = O.fp8_quantize_qkv(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), v_per_head=True)
+    assert (h8.v.cpu().numpy() == zh["v8"]).all() and (h8.v_descale.cpu().numpy() == zh["v_descale"]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("block_rows", [128, 256])
+@pytest.mark.parametrize("lsum_valu", [0, 1])
+def test_fp8_dense_ragged_vs_emulator(dtype, block_rows, lsum_valu):
+    from vorta_amd import ops
+    rng = np.random.default_rng(1)
+    H, Sq, Skv = 3, 333, 417
+    q, k, v = rng.standard_normal((H, Sq, 128)), rng.standard_normal((H, Skv, 128)), rng.standard_normal((H, Skv, 128))
+    n_kv, q_valid = 401, 300
+    pad = np.zeros((H, Skv - Sq, 128))
+    f8 = ops.fp8_quantize_qkv(to_dev(np.concatenate([q, pad], 1), dtype), to_dev(k, dtype), to_dev(v, dtype))
+    out = torch.full((H, Sq, 128), 7.0, dtype=dtype, device=dev())
+    ops.attn_fwd(f8.q[:, :Sq], f8.k, f8.v, out, n_q=Sq, n_kv=n_kv, q_valid=q_valid, block_rows=block_rows,
+                 v_descale=f8.v_descale, fp8_opts=dict(flags=lsum_valu))
+    torch.cuda.synchronize()
+    q8, k8, v8, vd = _decoded(f8)
+    ref, exact, amb = np.zeros((H, Sq, 128)), np.zeros((H, Sq, 128)), np.zeros((H, Sq))
+    for h in range(H):
+        if not lsum_valu:
+            O.fp8_attn_launch(q8[h], k8[h], v8[h], ref[h], vd[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, ambiguous=amb[h])
+        O.fp8_attn_launch(q8[h], k8[h], v8[h], exact[h], vd[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, round_p=False)
+    if not lsum_valu:  # the VALU row sum adds the UNrounded P: not what the emulator models; gate (i') only
+        _check(out, ref, dtype, amb, _vmax(v8, vd))
+    assert rel_fro(out.float().cpu().numpy(), exact) <= RELF_PACK
+    assert torch.all(out[:, q_valid:] == 0)
+
+
+def test_fp8_rescale_branch_and_long_keys():
+    """key norms grow along the sequence: the reference point of every wave moves several times"""
+    from vorta_amd import ops
+    dtype = torch.float16
+    rng = np.random.default_rng(2)
+    H, Sq, Skv = 2, 96, 2048
+    q = rng.standard_normal((H, Skv, 128))
+    k = rng.standard_normal((H, Skv, 128)) * np.linspace(0.3, 3.0, Skv)[None, :, None]
+    v = rng.standard_normal((H, Skv, 128))
+    f8 = ops.fp8_quantize_qkv(to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype))
+    out = torch.empty((H, Sq, 128), dtype=dtype, device=dev())
+    ops.attn_fwd(f8.q[:, :Sq], f8.k, f8.v, out, n_q=Sq, n_kv=Skv, v_descale=f8.v_descale)
+    q8, k8, v8, vd = _decoded(f8)
+    ref, amb = np.zeros((H, Sq, 128)), np.zeros((H, Skv))
+    moved = 0
+    for h in range(H):
+        O.fp8_attn_launch(q8[h], k8[h], v8[h], ref[h], vd[h], n_q=Sq, n_kv=Skv, ambiguous=amb[h])
+        _, _, m = O._fp8_flash_rows(q8[h, :32], k8[h], v8[h], 0, Skv // 64, 5.0, 3.0, True)
+        moved += int((m > (q8[h, :32] @ k8[h, :64].T).max(1)).sum())
+    assert moved > 0
+    _check(out, ref, dtype, amb[:, :Sq], _vmax(v8, vd))
+    # other (p_bias, defer) splits of the e4m3 range follow the emulator too
+    for pb, df in ((6.0, 2.0), (2.0, 6.0)):
+        ops.attn_fwd(f8.q[:, :Sq], f8.k, f8.v, out, n_q=Sq, n_kv=Skv, v_descale=f8.v_descale,
+                     fp8_opts=dict(p_bias=pb, defer=df))
+        amb[:] = False
+        for h in range(H):
+            O.fp8_attn_launch(q8[h], k8[h], v8[h], ref[h], vd[h], n_q=Sq, n_kv=Skv, p_bias=pb, defer=df, ambiguous=amb[h])
+        _check(out, ref, dtype, amb[:, :Sq], _vmax(v8, vd))
+    with pytest.raises(ValueError):
+        ops.attn_fwd(f8.q[:, :Sq], f8.k, f8.v, out, n_q=Sq, n_kv=Skv, v_descale=f8.v_descale,
+                     fp8_opts=dict(p_bias=6.0, defer=3.0))  # P' could reach 2^9 > 448
+
+
+@pytest.mark.parametrize("block_rows", [128, 256])
+def test_fp8_tables_groups_duplicates_heads(block_rows):
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(3)
+    H, rows = 4, 700
+    x = [rng.standard_normal((H, rows, 128)) for _ in range(3)]
+    f8 = ops.fp8_quantize_qkv(*(to_dev(a, dtype) for a in x))
+    n_q, glen, n_kv = 520, 200, 391  # 3 groups (200, 200, 120), own key list per group
+    q_rows = rng.permutation(rows)[:n_q].astype(np.int32)
+    kv_rows = np.stack([rng.permutation(rows)[:n_kv] for _ in range(3)]).astype(np.int32)
+    free = np.setdiff1d(np.arange(rows), q_rows)
+    dup = rng.permutation(free)[:2 * 60].reshape(60, 2).astype(np.int32)
+    heads = torch.tensor([3, 0, 2], dtype=torch.int32, device=dev())
+    count = torch.tensor([2], dtype=torch.int32, device=dev())
+    out = torch.zeros((H, rows, 128), dtype=dtype, device=dev())
+    ops.attn_fwd(f8.q, f8.k, f8.v, out, head_list=heads, n_heads_dev=count, n_q=n_q, q_group_len=glen, n_kv=n_kv,
+                 q_rows=torch.as_tensor(q_rows, device=dev()), kv_rows=torch.as_tensor(kv_rows, device=dev()),
+                 kv_rows_stride_g=n_kv, dup_rows=torch.as_tensor(dup, device=dev()), n_dup_pos=60,
+                 block_rows=block_rows, v_descale=f8.v_descale)
+    torch.cuda.synchronize()
+    q8, k8, v8, vd = _decoded(f8)
+    ref, amb = np.zeros((H, rows, 128)), np.zeros((H, rows))
+    for h in (3, 0):
+        O.fp8_attn_launch(q8[h], k8[h], v8[h], ref[h], vd[h], n_q=n_q, n_kv=n_kv, q_rows=q_rows, q_group_len=glen,
+                          kv_rows=kv_rows, dup_rows=dup, n_dup_pos=60, ambiguous=amb[h])
+    _check(out, ref, dtype, amb, _vmax(v8, vd))
+    assert torch.all(out[2] == 0) and torch.all(out[1] == 0)
+
+
+@pytest.mark.parametrize("n_splits", [3, 8])
+def test_fp8_split_keys(n_splits):
+    from vorta_amd import ops
+    dtype = torch.float16
+    rng = np.random.default_rng(4)
+    H, Sq, Skv = 2, 40, 3000
+    x = [rng.standard_normal((H, Skv, 128)) for _ in range(3)]
+    f8 = ops.fp8_quantize_qkv(*(to_dev(a, dtype) for a in x))
+    out = torch.empty((H, Skv, 128), dtype=dtype, device=dev())
+    ops.attn_fwd(f8.q, f8.k, f8.v, out, n_q=Sq, q_row_offset=100, q_valid=33, n_kv=2900, n_splits=n_splits,
+                 v_descale=f8.v_descale)
+    q8, k8, v8, vd = _decoded(f8)
+    ref, amb = np.zeros((H, Skv, 128)), np.zeros((H, Skv))
+    for h in range(H):
+        O.fp8_attn_launch(q8[h], k8[h], v8[h], ref[h], vd[h], n_q=Sq, q_row_offset=100, q_valid=33, n_kv=2900,
+                          n_splits=n_splits, ambiguous=amb[h])
+    _check(out[:, 100:140], ref[:, 100:140], dtype, amb[:, 100:140], _vmax(v8, vd))
+    assert torch.all(out[:, 133:140] == 0)
+
+
+def _emulate_routed(q16, k16, v16, f8, experts, geom, model, T, te, scale=None):
+    """the launches of vorta_amd/routed.py, one by one, through the oracle's emulator (tables from the GPU: they are
+    pinned against the oracle by tests/test_hip_experts.py)"""
+    from vorta_amd import ops
+    from vorta_amd.routed import _auto_splits
+    q8, k8, v8, vd = _decoded(f8)
+    H, N, _ = q8.shape
+    S = geom.S
+    out, amb = np.zeros((H, N, 128)), np.zeros((H, N))
+    hs = [[h for h in range(H) if experts[h] == e] for e in range(3)]
+    for h in hs[0]:
+        O.fp8_attn_launch(q8[h], k8[h], v8[h], out[h], vd[h], n_q=S + T, n_kv=S + te, q_valid=S + te, ambiguous=amb[h])
+    if hs[1]:
+        hl = torch.tensor(hs[1], dtype=torch.int32, device=dev())
+        keep_q, drop_q = ops.coreset_select(q16, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T, head_list=hl)
+        if model == "hunyuan":
+            keep_k, _ = ops.coreset_select(k16, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=te,
+                                           head_list=hl, want_drop=False)
+        else:
+            keep_k = keep_q
+        kq, kk, dq = keep_q.cpu().numpy(), keep_k.cpu().numpy(), drop_q.cpu().numpy()
+        for y, h in enumerate(hs[1]):
+            O.fp8_attn_launch(q8[h], k8[h], v8[h], out[h], vd[h], n_q=geom.S_low + T, n_kv=geom.S_low + te,
+                              q_valid=geom.S_low + te, q_rows=kq[y], kv_rows=kk[y], dup_rows=dq[y], n_dup_pos=geom.G,
+                              ambiguous=amb[h])
+    if hs[2]:
+        q_rows, kv_rows, n_kv = geom.sta_tables(te)
+        qr, kr = q_rows.cpu().numpy(), kv_rows.cpu().numpy()
+        for h in hs[2]:
+            O.fp8_attn_launch(q8[h], k8[h], v8[h], out[h], vd[h], n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=qr,
+                              kv_rows=kr, ambiguous=amb[h])
+            if T:
+                O.fp8_attn_launch(q8[h], k8[h], v8[h], out[h], vd[h], n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te,
+                                  n_splits=_auto_splits(len(hs[2]), T, S + te), ambiguous=amb[h])
+    return out, amb, _vmax(v8, vd)
+
+
+@pytest.mark.parametrize("model", ["hunyuan", "wan"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_fp8_routed_attention_vs_emulator_and_oracle(model, fused):
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.bfloat16
+    latent, tile, window, group = (9, 12, 16), (3, 6, 8), (3, 3, 3), (3, 3, 2)
+    H, T, te = 6, (64 if model == "hunyuan" else 0), (40 if model == "hunyuan" else 0)
+    S = latent[0] * latent[1] * latent[2]
+    rng = np.random.default_rng(5)
+    q, k, v = (rng.standard_normal((1, H, S + T, 128)) for _ in range(3))
+    experts = [0, 1, 2, 2, 1, 0]
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    from vorta_amd import ops
+    f8 = ops.fp8_quantize_qkv(qd[0], kd[0], vd[0])
+    out = routed_attention(qd, kd, vd, HeadRouting.from_expert_ids(experts, dev()), geom, model=model, text_len=T,
+                           text_valid=te, fp8=True, fused=fused, fp8_operands=f8)
+    torch.cuda.synchronize()
+    ref, amb, vmax = _emulate_routed(qd[0], kd[0], vd[0], f8, experts, geom, model, T, te)
+    _check(out[0], ref, dtype, amb, vmax)
+    if T:
+        assert torch.all(out[0, :, S + te:] == 0)
+    # against the golden-pinned fp64 oracle on the 16-bit inputs: the whole cost of the e4m3 path
+    gi = O.group_info(latent, group, 0.5)
+    full = O.routed_attention(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), np.array(experts), model=model,
+                              latent=latent, tile=tile, window=window, gi=gi, t_text=T, t_eff=te)[0]
+    o = out[0].float().cpu().numpy()
+    for h in range(H):
+        rf = rel_fro(o[h], full[h])
+        assert rf < 0.12, (h, experts[h], rf)
+    # same routing through device-resident head lists
+    from vorta_amd import ops as _ops
+    sc = torch.zeros((1, H, 3), device=dev())
+    for h, e in enumerate(experts):
+        sc[0, h, e] = 1.0
+    _, lists, counts = _ops.route_scores(sc, 0.3)
+    out2 = routed_attention(qd, kd, vd, HeadRouting.from_device(lists, counts), geom, model=model, text_len=T,
+                            text_valid=te, fp8=True, fused=fused)
+    assert torch.equal(out2, out)
+
+
+def _psnr(x, ref):
+    """(PSNR over the data range max - min, PSNR over max |ref|, relative rms error)"""
+    x, ref = x.float(), ref.float()
+    mse = torch.mean((x - ref) ** 2).item()
+    rng, peak = (ref.max() - ref.min()).item(), ref.abs().max().item()
+    f = lambda r: 10.0 * math.log10(r * r / max(mse, 1e-30))
+    return f(rng), f(peak), math.sqrt(mse / torch.mean(ref ** 2).item())
+
+
+def test_fp8_operator_psnr_wan14b_81f_geometry():
+    """gate (ii): every expert at BASELINE configs[4]'s geometry (Wan-2.1 14B 81x720x1280: S = 75 600, tile (7,9,8),
+    coreset window (3,3,2)), fp8 against the bf16 kernels on the same bf16 inputs"""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.bfloat16
+    latent, tile, window, group = (21, 45, 80), (7, 9, 8), (3, 3, 3), (3, 3, 2)
+    S = latent[0] * latent[1] * latent[2]
+    H = 3
+    gen = torch.Generator(device=dev()).manual_seed(1234)
+    q, k, v = (torch.randn((1, H, S, 128), generator=gen, device=dev(), dtype=dtype) for _ in range(3))
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    routing = HeadRouting.from_expert_ids([0, 1, 2], dev())
+    ref = routed_attention(q, k, v, routing, geom, model="wan")
+    out = routed_attention(q, k, v, routing, geom, model="wan", fp8=True)
+    torch.cuda.synchronize()
+    names = ["full", "coreset", "sliding-tile"]
+    table = {names[h]: _psnr(out[0, h], ref[0, h]) for h in range(H)}
+    print("fp8 vs bf16 operator, Wan-14B-81f geometry (PSNR over data range dB, PSNR over max|x| dB, rel. rms error):",
+          {n: tuple(round(x, 4) for x in p) for n, p in table.items()})
+    assert not torch.isnan(out).any()
+    for n, (p_range, p_peak, rel) in table.items():
+        assert p_range >= 40.0 and p_peak >= 39.0 and rel <= 0.06, (n, p_range, p_peak, rel)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--sdpa", action="store_true")
     ap.add_argument("--variants", default="1,2")  # 1 plain, 2 pipelined
     ap.add_argument("--rounds", type=int, default=1)
+    ap.add_argument("--fp8", default="", help="comma list of vorta_attn_fp8_ext flag values to time the e4m3 kernel with (e.g. 0,1)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     dev = torch.device("cuda:0")
@@ -46,6 +47,18 @@ def main():
                 ms = timeit(lambda: ops.attn_fwd(q, k, v, o, n_q=a.S, n_kv=a.S, block_rows=br, variant=var), a.iters)
                 print(f"vorta_attn_fwd S={a.S} H={a.H} {a.dtype} block_rows={br} variant={var} no_xcd_remap={remap}: "
                       f"{ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s", flush=True)
+    if a.fp8:
+        f8 = ops.fp8_quantize_qkv(q, k, v)
+        for rnd in range(a.rounds):
+            for br in ([a.block_rows] if a.block_rows else [256, 128]):
+                for fl in [int(x) for x in a.fp8.split(",")]:
+                    ms = timeit(lambda: ops.attn_fwd(f8.q, f8.k, f8.v, o, n_q=a.S, n_kv=a.S, block_rows=br,
+                                                     v_descale=f8.v_descale, fp8_opts=dict(flags=fl)), a.iters)
+                    print(f"vorta_attn_fwd_fp8 S={a.S} H={a.H} out {a.dtype} block_rows={br} flags={fl}: "
+                          f"{ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s", flush=True)
+        ms = timeit(lambda: ops.fp8_quantize_qkv(q, k, v, out=f8), a.iters)
+        gb = 3 * q.numel() * 5 / 1e9
+        print(f"vorta_fp8_quantize_qkv: {ms:.3f} ms  {gb/ms:.2f} TB/s (5 B per element)", flush=True)
     if a.sdpa:
         import torch.nn.functional as F
         q4, k4, v4 = q[None], k[None], v[None]

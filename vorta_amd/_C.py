@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvorta_hip.so")
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
-VORTA_BF16, VORTA_FP16 = 0, 1
-ABI_VERSION = 1
+VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3 = 0, 1, 2, 3
+ABI_VERSION = 2
 
 _i32, _i64, _u32, _f32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
 
@@ -85,12 +85,32 @@ class MixArgs(C.Structure):
     ]
 
 
+class Fp8QuantArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32),
+        ("n_tokens", _i32), ("qk_scale", _f32),
+        ("q", Tensor), ("k", Tensor), ("v", Tensor), ("q8", Tensor), ("k8", Tensor), ("v8", Tensor),
+        ("v_descale", _vp), ("ws", _vp), ("flags", _i32), ("reserved", _i32),
+    ]
+
+
+class AttnFp8Ext(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("out_dtype", _i32), ("v_descale", _vp), ("v_descale_stride_h", _i64),
+        ("p_bias", _f32), ("defer", _f32), ("flags", _i32), ("reserved", _i32),
+    ]
+
+
 # every symbol include/vorta_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "vorta_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "vorta_attn_fwd_batch": (C.c_int, [C.POINTER(AttnArgs), _i32, _vp]),
     "vorta_attn_plan": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),
     "vorta_attn_workspace_bytes": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vorta_fp8_quant_ws_floats": (C.c_int, [_i32, _i32]),
+    "vorta_fp8_quantize_qkv": (C.c_int, [C.POINTER(Fp8QuantArgs), _vp]),
+    "vorta_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _vp]),
+    "vorta_attn_fwd_batch_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _i32, _vp]),
     "vorta_coreset_select": (C.c_int, [C.POINTER(CoresetArgs), _vp]),
     "vorta_sta_table_sizes": (C.c_int, [C.POINTER(StaArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "vorta_sta_build_tables": (C.c_int, [C.POINTER(StaArgs), _vp]),
@@ -137,7 +157,8 @@ def lib():
         fn.argtypes = args
     if h.vorta_abi_version() != ABI_VERSION:
         raise VortaHipError(f"ABI mismatch: library {h.vorta_abi_version()} vs binding {ABI_VERSION}")
-    for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs, MixArgs)):
+    for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs, MixArgs, Fp8QuantArgs,
+                                AttnFp8Ext)):
         if h.vorta_sizeof(which) != C.sizeof(st):
             raise VortaHipError(f"struct layout mismatch for {st.__name__}: "
                                 f"C {h.vorta_sizeof(which)} vs ctypes {C.sizeof(st)}")

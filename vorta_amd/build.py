@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libvorta_hip.so")
-SOURCES = ["api.hip", "attn_fwd.hip", "coreset.hip", "sta_tables.hip", "router.hip", "qk_norm_rope.hip", "mix.hip"]
+SOURCES = ["api.hip", "attn_fwd.hip", "attn_fwd_fp8.hip", "fp8_quant.hip", "coreset.hip", "sta_tables.hip", "router.hip",
+           "qk_norm_rope.hip", "mix.hip"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent fp32 adds of the softmax row sum into v_pk_add_f32 plus the
 # v_mov pairs to feed them -- more instructions on the VALU issue port that bounds the attention loop (+2 % without)
 # -enable-post-misched=0: the post-RA scheduler re-orders the hand-interleaved MFMA / VALU / LDS stream of the attention
@@ -25,28 +26,35 @@ def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags=None, suffix: str = "") -> str:
+    """Compile the sources and link the library.  Experimental flags (`extra_flags`, or VORTA_EXTRA_FLAGS in the
+    environment) never touch the product library: they require a `suffix` (VORTA_BUILD_SUFFIX) and produce
+    csrc/libvorta_hip<suffix>.so from objects of their own (load it with VORTA_HIP_LIB for a same-session A/B)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("VORTA_EXTRA_FLAGS", "").split()  # experiments only (e.g. -DVORTA_SCHED=1)
-    force = force or bool(extra)
+    extra = list(extra_flags) if extra_flags is not None else os.environ.get("VORTA_EXTRA_FLAGS", "").split()
+    suffix = suffix or os.environ.get("VORTA_BUILD_SUFFIX", "")
+    if extra and not suffix:
+        raise SystemExit("VORTA_EXTRA_FLAGS needs VORTA_BUILD_SUFFIX: experimental flags are never built into "
+                         "libvorta_hip.so itself")
+    lib = LIB if not suffix else os.path.join(CSRC, f"libvorta_hip{suffix}.so")
     deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(INCLUDE, "vorta_hip.h")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", f"{suffix}.o"))
         if force or _newer(src, obj) or any(_newer(d, obj) for d in deps):
             cmd = [hipcc] + FLAGS + extra + ["-c", src, "-o", obj]
             if verbose:
                 print("[vorta_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(obj)
-    if force or any(_newer(o, LIB) for o in objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or any(_newer(o, lib) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print("[vorta_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv or bool(os.environ.get("VORTA_BUILD_SUFFIX")))

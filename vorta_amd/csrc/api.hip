@@ -25,6 +25,8 @@ extern "C" int vorta_sizeof(int which) {
     case 4: return (int)sizeof(vorta_router_args);
     case 5: return (int)sizeof(vorta_norm_rope_args);
     case 6: return (int)sizeof(vorta_mix_args);
+    case 7: return (int)sizeof(vorta_fp8_quant_args);
+    case 8: return (int)sizeof(vorta_attn_fp8_ext);
     default: return -1;
   }
 }

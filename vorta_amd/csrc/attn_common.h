@@ -36,6 +36,16 @@ struct Params {
   float defer_log2;  // online-softmax rescale is skipped while the row max grows by <= this (log2 units)
 };
 
+constexpr int MAX_SEGMENTS = 4;  // launches fused into one grid (vorta_attn_fwd_batch)
+struct MultiParams {
+  Params seg[MAX_SEGMENTS];
+  int start[MAX_SEGMENTS + 1];  // first workgroup of each segment; start[n] = grid size
+  int n;
+};
+
+// attn_fwd.hip: argument validation + launch geometry (in_esize = bytes per q/k/v element)
+int fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize);
+
 template <typename T> struct MF;
 template <> struct MF<__bf16> {
   using v8 = bf16x8; using v4 = bf16x4;

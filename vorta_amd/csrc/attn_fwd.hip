@@ -735,12 +735,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
 // are dispatched in segment order, longest key loops first, so the tail of one expert (a launch holds only a
 // few waves of workgroups per CU-set, fewer still under sequence parallelism) is filled by the next expert's
 // workgroups instead of idling until a kernel boundary.
-constexpr int MAX_SEGMENTS = 4;
-struct MultiParams {
-  Params seg[MAX_SEGMENTS];
-  int start[MAX_SEGMENTS + 1];  // first workgroup of each segment; start[n] = grid size
-  int n;
-};
 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParams mp) {
@@ -823,17 +817,23 @@ int launch(const Params& p, hipStream_t st, bool pipe) {
   return VORTA_OK;
 }
 
-int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
+}  // namespace
+
+// argument validation + launch geometry, shared with the fp8 kernels (attn_fwd_fp8.hip): in_esize = bytes per q/k/v
+// element (2: bf16/fp16, 1: e4m3); the output is always 16-bit
+int vorta_attn::fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize) {
   if (!a || a->struct_size != sizeof(vorta_attn_args)) return VORTA_EINVAL;
-  if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
+  if (in_esize == 2 ? (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) : a->dtype != VORTA_FP8E4M3) return VORTA_EUNSUPPORTED;
   if (a->head_dim != D) return VORTA_EUNSUPPORTED;
   if (a->n_heads < 0 || a->n_q < 0 || a->n_kv < 0) return VORTA_EINVAL;
   if (a->n_heads == 0 || a->n_q == 0) { block_rows = 0; p.n_groups = 0; p.blocks_per_group = 0; p.n_heads = 0; return VORTA_OK; }
   if (a->n_kv == 0) return VORTA_EINVAL;  // softmax over nothing is undefined in the reference too
   if (!a->q.ptr || !a->k.ptr || !a->v.ptr || !a->o.ptr) return VORTA_EINVAL;
   const vorta_tensor* ts[4] = {&a->q, &a->k, &a->v, &a->o};
-  for (auto t : ts) {
-    if (((uintptr_t)t->ptr & 15) || (t->stride_s % 8) || (t->stride_h % 8) || t->stride_s < D) return VORTA_EINVAL;
+  for (int i = 0; i < 4; ++i) {
+    const vorta_tensor* t = ts[i];
+    const int al = 16 / (i < 3 ? in_esize : 2);  // elements per 16 bytes
+    if (((uintptr_t)t->ptr & 15) || (t->stride_s % al) || (t->stride_h % al) || t->stride_s < D) return VORTA_EINVAL;
   }
   if (a->n_splits < 1 || a->n_splits > 1024) return VORTA_EINVAL;
   if (!(a->scale > 0.f)) return VORTA_EINVAL;  // the online-softmax thresholds assume a positive scale
@@ -842,17 +842,17 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   if (a->dup_rows && (a->n_dup < 0 || a->n_dup_pos < 0 || a->n_dup_pos > a->n_q)) return VORTA_EINVAL;
   if (a->block_rows != 0 && a->block_rows != 128 && a->block_rows != 256) return VORTA_EINVAL;
   if (a->variant < 0 || a->variant > 2) return VORTA_EINVAL;
-  if (a->variant != 1 && (a->k.stride_s * 2 >= (1 << 24) || a->v.stride_s * 2 >= (1 << 24))) return VORTA_EUNSUPPORTED;
+  if (a->variant != 1 && (a->k.stride_s * in_esize >= (1 << 24) || a->v.stride_s * in_esize >= (1 << 24))) return VORTA_EUNSUPPORTED;
   // the pipelined kernel addresses K/V rows with 32-bit buffer offsets (24-bit row x 24-bit stride, 2 GiB window per
   // head): checked here for contiguous key ranges; with a kv_rows table the caller guarantees it (vorta_hip.h)
   if (a->variant != 1 && !a->kv_rows) {
     const int64_t last = (int64_t)a->kv_row_offset + a->n_kv;
-    const int64_t ss = (a->k.stride_s > a->v.stride_s ? a->k.stride_s : a->v.stride_s) * 2;
+    const int64_t ss = (a->k.stride_s > a->v.stride_s ? a->k.stride_s : a->v.stride_s) * in_esize;
     if (last >= (1 << 24) || last * ss > 0x7fffffffll) return VORTA_EUNSUPPORTED;
   }
   p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr; p.o = (char*)a->o.ptr;
-  p.q_sh = a->q.stride_h * 2; p.k_sh = a->k.stride_h * 2; p.v_sh = a->v.stride_h * 2; p.o_sh = a->o.stride_h * 2;
-  p.q_ss = a->q.stride_s * 2; p.k_ss = a->k.stride_s * 2; p.v_ss = a->v.stride_s * 2; p.o_ss = a->o.stride_s * 2;
+  p.q_sh = a->q.stride_h * in_esize; p.k_sh = a->k.stride_h * in_esize; p.v_sh = a->v.stride_h * in_esize; p.o_sh = a->o.stride_h * 2;
+  p.q_ss = a->q.stride_s * in_esize; p.k_ss = a->k.stride_s * in_esize; p.v_ss = a->v.stride_s * in_esize; p.o_ss = a->o.stride_s * 2;
   p.head_list = a->head_list; p.n_heads_dev = a->n_heads_dev; p.n_heads = a->n_heads;
   p.n_q = a->n_q; p.q_group_len = a->q_group_len > 0 ? a->q_group_len : a->n_q;
   p.q_row_offset = a->q_row_offset; p.q_valid = a->q_valid;
@@ -881,6 +881,9 @@ int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) {
   return VORTA_OK;
 }
 
+namespace {
+using namespace vorta_attn;
+int fill_params(const vorta_attn_args* a, Params& p, int& block_rows) { return vorta_attn::fill_params(a, p, block_rows, 2); }
 }  // namespace
 
 extern "C" int vorta_attn_workspace_bytes(const vorta_attn_args* a, uint64_t* ws_o_bytes, uint64_t* ws_ml_bytes) {
@@ -896,7 +899,7 @@ extern "C" int vorta_attn_plan(const vorta_attn_args* a, int32_t* block_rows_out
                                int32_t* kernel_id_out) {
   Params p{};
   int block_rows = 0;
-  int rc = fill_params(a, p, block_rows);
+  int rc = vorta_attn::fill_params(a, p, block_rows, (a && a->dtype == VORTA_FP8E4M3) ? 1 : 2);  // the fp8 kernels share the launch geometry
   if (rc != VORTA_OK) return rc;
   if (block_rows_out) *block_rows_out = block_rows;
   if (kernel_id_out) {
@@ -912,7 +915,6 @@ extern "C" int vorta_attn_fwd_batch(const vorta_attn_args* args, int32_t n, void
   MultiParams mp{};
   int64_t total = 0;
   int dtype = -1, m = 0;
-  const vorta_attn_args* live[MAX_SEGMENTS];
   for (int i = 0; i < n; ++i) {
     Params p{};
     int block_rows = 0;
@@ -926,7 +928,6 @@ extern "C" int vorta_attn_fwd_batch(const vorta_attn_args* args, int32_t n, void
     p.xcd_remap = 0;
     mp.seg[m] = p;
     mp.start[m] = (int)total;
-    live[m] = &args[i];
     total += (int64_t)p.n_groups * p.blocks_per_group * p.n_heads * p.n_splits;
     if (total > 0x7fffffff) return VORTA_EINVAL;
     ++m;
@@ -951,7 +952,6 @@ extern "C" int vorta_attn_fwd_batch(const vorta_attn_args* args, int32_t n, void
       if (e != hipSuccess) return vorta_set_hip_error(e);
     }
   }
-  (void)live;
   return VORTA_OK;
 }
 

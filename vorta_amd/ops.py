@@ -14,6 +14,7 @@ import torch
 from . import _C
 
 _DT = {torch.bfloat16: _C.VORTA_BF16, torch.float16: _C.VORTA_FP16}
+FP8_STORAGE = torch.uint8  # e4m3 bytes travel as uint8 tensors (no arithmetic is ever done on them in torch)
 
 
 class Timeline:
@@ -91,14 +92,33 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
                dup_rows: Optional[torch.Tensor] = None, n_dup_pos: int = 0,
                scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1,
                n_kv_dev: Optional[torch.Tensor] = None, q_valid_dev: Optional[torch.Tensor] = None,
-               variant: int = 0, tag: str = "", flops: float = 0.0):
-    """Fill a vorta_attn_args; returns (args, workspace tensors to keep alive until the launch is enqueued)."""
+               variant: int = 0, tag: str = "", flops: float = 0.0,
+               v_descale: Optional[torch.Tensor] = None, fp8_opts: Optional[dict] = None):
+    """Fill a vorta_attn_args; returns (args, workspace tensors to keep alive until the launch is enqueued).
+    q,k,v of dtype uint8 = e4m3 operands from `fp8_quantize_qkv` (then `v_descale` is required and `out` is 16-bit):
+    the args carry `_ext`, the vorta_attn_fp8_ext of the fp8 entry points."""
     _require_gpu(q, k, v, out)
-    if q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype == out.dtype):
+    fp8 = q.dtype == FP8_STORAGE
+    if fp8:
+        if not (k.dtype == v.dtype == FP8_STORAGE) or out.dtype not in _DT:
+            raise ValueError("fp8 attention takes e4m3 (uint8) q,k,v and a bf16 / fp16 output")
+        if v_descale is None or v_descale.dtype != torch.float32 or v_descale.dim() != 2 or v_descale.shape[1] != q.shape[-1] \
+                or not v_descale.is_contiguous():
+            raise ValueError("fp8 attention needs v_descale: contiguous float32 (heads, D) from fp8_quantize_qkv")
+    elif q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype == out.dtype):
         raise ValueError("q,k,v,out must share dtype bf16 or fp16")
     a = _C.AttnArgs()
     a.struct_size = C.sizeof(_C.AttnArgs)
-    a.dtype = _DT[q.dtype]
+    a.dtype = _C.VORTA_FP8E4M3 if fp8 else _DT[q.dtype]
+    a._ext = None
+    if fp8:
+        ext = _C.AttnFp8Ext()
+        ext.struct_size = C.sizeof(_C.AttnFp8Ext)
+        ext.out_dtype = _DT[out.dtype]
+        ext.v_descale, ext.v_descale_stride_h = v_descale.data_ptr(), v_descale.stride(0)
+        o = fp8_opts or FP8_OPTS
+        ext.p_bias, ext.defer, ext.flags = float(o.get("p_bias", 0.0)), float(o.get("defer", 0.0)), int(o.get("flags", 0))
+        a._ext = ext
     a.head_dim = q.shape[-1]
     a.q, a.k, a.v, a.o = _tensor(q), _tensor(k), _tensor(v), _tensor(out)
     if n_heads is None:
@@ -147,12 +167,15 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     a.block_rows = block_rows
     a.n_splits = n_splits
     a.n_kv_dev, a.q_valid_dev = _ptr(n_kv_dev), _ptr(q_valid_dev)
-    a.variant = variant or DEFAULT_VARIANT
+    a.variant = 0 if fp8 else (variant or DEFAULT_VARIANT)
     if a.variant != 1:
         # the pipelined kernel's 32-bit K/V offsets (vorta_hip.h): beyond a 2 GiB window per head, or 2^24 rows, use
         # the plain HIP kernel (64-bit addressing) instead
+        esz = 1 if fp8 else 2
         for t in (k, v):
-            if t.shape[1] >= (1 << 24) or t.shape[1] * t.stride(1) * 2 > 0x7fffffff or t.stride(1) * 2 >= (1 << 24):
+            if t.shape[1] >= (1 << 24) or t.shape[1] * t.stride(1) * esz > 0x7fffffff or t.stride(1) * esz >= (1 << 24):
+                if fp8:
+                    raise ValueError("fp8 attention addresses K/V rows with 32-bit offsets: a head must fit a 2 GiB window")
                 a.variant = 1
     a.reserved = NO_XCD_REMAP
     ws = None
@@ -165,11 +188,22 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     return a, ws
 
 
+def _launch_one(a):
+    if a._ext is not None:
+        _C.check(_C.lib().vorta_attn_fwd_fp8(C.byref(a), C.byref(a._ext), _stream()), "vorta_attn_fwd_fp8")
+    else:
+        _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+
+
 def _plan(a) -> Tuple[int, int, str]:
     br, nwg, kid = C.c_int32(), C.c_int64(), C.c_int32()
     _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg), C.byref(kid)), "vorta_attn_plan")
     tname = "_Float16" if a.dtype == _C.VORTA_FP16 else "__bf16"
     nw, kk = kid.value // 16, kid.value % 16
+    if a._ext is not None:
+        tname = "_Float16" if a._ext.out_dtype == _C.VORTA_FP16 else "__bf16"
+        return br.value, nwg.value, (f"attn8_kernel<{tname},{nw},{'true' if kk & 2 else 'false'},"
+                                     f"{'false' if a._ext.flags & 1 else 'true'}>")
     sym = (f"attn_fwd_pipe_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>" if kk & 1
            else f"attn_fwd_kernel<{tname},{nw}>")
     return br.value, nwg.value, sym
@@ -184,11 +218,11 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
         _, nwg, sym = _plan(a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+        _launch_one(a)
         e1.record()
         _timeline.records.append((tag, sym, nwg, flops, e0, e1))
         return
-    _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+    _launch_one(a)
     # `ws` may be released now: the caching allocator is stream ordered and the launch is on this stream
 
 
@@ -205,7 +239,7 @@ def attn_fwd_batch(calls) -> None:
         built.append((a, ws, tag, flops))
     if not built:
         return
-    ok = [_plan(a)[0] == 256 and a.variant != 1 for a, _, _, _ in built]
+    ok = [_plan(a)[0] == 256 and a.variant != 1 and not (a._ext is not None and a._ext.flags & 1) for a, _, _, _ in built]
     fusable = 1 < len(built) <= 4 and all(ok)
     if not fusable and 2 <= sum(ok) <= 4 and sum(ok) < len(built):
         # mixed workgroup sizes: fuse the 256-row launches, run the others on their own (in list order after them)
@@ -223,23 +257,83 @@ def attn_fwd_batch_built(built, fuse: bool = True) -> None:
                 _, nwg, sym = _plan(a)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+                _launch_one(a)
                 e1.record()
                 _timeline.records.append((tag, sym, nwg, flops, e0, e1))
             else:
-                _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
+                _launch_one(a)
         return
     arr = (_C.AttnArgs * len(built))(*[a for a, _, _, _ in built])
+    ext = built[0][0]._ext  # one operand set per layer: every fused launch shares v_descale and the options
+    if any((a._ext is None) != (ext is None) for a, _, _, _ in built):
+        raise ValueError("a fused grid is either all fp8 or all 16-bit")
+
+    def go():
+        if ext is not None:
+            _C.check(_C.lib().vorta_attn_fwd_batch_fp8(arr, C.byref(ext), len(built), _stream()), "vorta_attn_fwd_batch_fp8")
+        else:
+            _C.check(_C.lib().vorta_attn_fwd_batch(arr, len(built), _stream()), "vorta_attn_fwd_batch")
+
     if _timeline is not None:
-        tname = "_Float16" if built[0][0].dtype == _C.VORTA_FP16 else "__bf16"
+        if ext is not None:
+            sym = f"attn8_multi_kernel<{'_Float16' if ext.out_dtype == _C.VORTA_FP16 else '__bf16'}>"
+        else:
+            sym = f"attn_fwd_multi_kernel<{'_Float16' if built[0][0].dtype == _C.VORTA_FP16 else '__bf16'}>"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _C.check(_C.lib().vorta_attn_fwd_batch(arr, len(built), _stream()), "vorta_attn_fwd_batch")
+        go()
         e1.record()
-        _timeline.records.append(("+".join(t for _, _, t, _ in built), f"attn_fwd_multi_kernel<{tname}>",
+        _timeline.records.append(("+".join(t for _, _, t, _ in built), sym,
                                   sum(_plan(a)[1] for a, _, _, _ in built), sum(f for _, _, _, f in built), e0, e1))
         return
-    _C.check(_C.lib().vorta_attn_fwd_batch(arr, len(built), _stream()), "vorta_attn_fwd_batch")
+    go()
+
+
+FP8_OPTS: dict = {}  # process-wide defaults of the fp8 kernels' options (p_bias, defer, flags); experiments only
+
+
+class Fp8Operands:
+    """e4m3 copies of one layer's q,k,v (uint8 storage, same (H,S,D) geometry) + the per-channel v descale."""
+    __slots__ = ("q", "k", "v", "v_descale", "ws")
+
+    def __init__(self, q, k, v, v_descale, ws):
+        self.q, self.k, self.v, self.v_descale, self.ws = q, k, v, v_descale, ws
+
+    def multipliers(self):
+        """(qmul (H,), kmul (H,), vmul (H,D)) as written by the scales kernel (device tensors; tests / diagnostics)."""
+        H, D = self.v_descale.shape
+        base = 2 * H + H * D
+        return self.ws[base:base + H], self.ws[base + H:base + 2 * H], self.ws[base + 2 * H:base + 2 * H + H * D].view(H, D)
+
+
+def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, *,
+                     out: Optional[Fp8Operands] = None, v_per_head: bool = False) -> Fp8Operands:
+    """vorta_fp8_quantize_qkv: (H,S,D) bf16/fp16 views -> e4m3 copies (contiguous (H,S,D) uint8) with the softmax scale
+    and log2(e) folded into q/k.  `out` = a previous result to overwrite (same shapes)."""
+    _require_gpu(q, k, v)
+    if q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype):
+        raise ValueError("q,k,v must share dtype bf16 or fp16")
+    if not (q.shape == k.shape == v.shape) or q.dim() != 3:
+        raise ValueError("fp8_quantize_qkv takes (H,S,D) views of equal shape")
+    H, S, D = q.shape
+    dev = q.device
+    nws = _C.lib().vorta_fp8_quant_ws_floats(H, D)
+    if nws < 0:
+        raise ValueError(f"fp8_quantize_qkv: unsupported head_dim {D}")
+    if out is None:
+        out = Fp8Operands(*(torch.empty((H, S, D), dtype=FP8_STORAGE, device=dev) for _ in range(3)),
+                          torch.empty((H, D), dtype=torch.float32, device=dev),
+                          torch.empty(nws, dtype=torch.float32, device=dev))
+    a = _C.Fp8QuantArgs()
+    a.struct_size = C.sizeof(_C.Fp8QuantArgs)
+    a.dtype, a.head_dim, a.heads, a.n_tokens = _DT[q.dtype], D, H, S
+    a.qk_scale = (1.0 / math.sqrt(D)) if scale is None else scale
+    a.q, a.k, a.v = _tensor(q), _tensor(k), _tensor(v)
+    a.q8, a.k8, a.v8 = _tensor(out.q), _tensor(out.k), _tensor(out.v)
+    a.v_descale, a.ws = out.v_descale.data_ptr(), out.ws.data_ptr()
+    a.flags = 1 if v_per_head else 0
+    _C.check(_C.lib().vorta_fp8_quantize_qkv(C.byref(a), _stream()), "vorta_fp8_quantize_qkv")
+    return out
 
 
 def coreset_select(x: torch.Tensor, latent: Sequence[int], group: Sequence[int], n_keep: int, *,

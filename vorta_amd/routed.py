@@ -117,7 +117,8 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                      geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
                      out: Optional[torch.Tensor] = None, scale: Optional[float] = None,
                      concurrent: bool = False, fused: bool = True, sliding_block_rows: int = 0,
-                     expert_outs: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+                     expert_outs: Optional[Sequence[torch.Tensor]] = None, fp8: bool = False,
+                     fp8_operands: Optional[ops.Fp8Operands] = None) -> torch.Tensor:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
     hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383.
@@ -127,7 +128,10 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     concurrent=True instead enqueues the coreset and sliding-tile experts on two side HIP streams (forked from and joined
     back into the current stream with events): the experts are independent, so the tail of one launch (a few
     hundred workgroups on 256 CUs when only H/P heads are local) is filled by the next expert's workgroups.
-    expert_outs: one output tensor per expert instead of `out` (heads may then appear under several experts)."""
+    expert_outs: one output tensor per expert instead of `out` (heads may then appear under several experts).
+    fp8=True: both contractions in e4m3 (BASELINE.json configs[4]; no reference counterpart): q,k,v are converted once
+    per call (vorta_fp8_quantize_qkv, or `fp8_operands` to reuse buffers) and every expert launch reads the e4m3
+    copies; the coreset ranking still reads the 16-bit q/k (coreset_select.py:98-105 ranks in the input dtype)."""
     if q.dim() == 4 and q.shape[0] != 1:
         # hunyuan.py:168 asserts batch 1; Wan's CFG runs two batch-1 forwards (pipeline_wan.py:322-344)
         raise AssertionError(f"Batch size {q.shape[0]} is not supported by routed_attention.")
@@ -153,6 +157,9 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         return routing.counts_host[e] if routing.counts_host is not None else 0
 
     base = dict(q=q3, k=k3, v=v3, scale=scale)
+    if fp8:
+        f8 = ops.fp8_quantize_qkv(q3, k3, v3, scale, out=fp8_operands)
+        base = dict(q=f8.q, k=f8.k, v=f8.v, scale=scale, v_descale=f8.v_descale)
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     def expert_full():
