@@ -52,20 +52,24 @@ struct MultiParams8 {
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
 
 __device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
+#ifdef VORTA_DIAG_NOMFMA  // timing diagnostic (wrong results): no matrix instructions at all
+  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+#else
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // cbsz = blgp = 0: e4m3 x e4m3, no block scale
+#endif
 }
 
 template <typename TO> struct OutT;
 template <> struct OutT<__bf16> { using v4 = bf16x4; };
 template <> struct OutT<_Float16> { using v4 = f16x4; };
 
-#ifndef VORTA_RING8
-#define VORTA_RING8 2
-#endif
+// LDS: K ring of 2 tiles, V ring of 3 tiles (8 KiB each).
+constexpr int K_SLOTS = 2, V_SLOTS = 3;
+constexpr int SMEM8 = (K_SLOTS + V_SLOTS) * TILE8;
 
-template <typename TO, int NW, bool KVTAB, int NS, bool LMFMA>
+template <typename TO, int NW, bool KVTAB, bool LMFMA>
 __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__ smem, const int wg) {
-  static_assert(NS == 2 || NS == 3, "ring depth");
   const Params& p = pp.p;
   using O4 = typename OutT<TO>::v4;
   constexpr int QB = NW * 32;
@@ -137,11 +141,11 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     if constexpr (KVTAB) dst_[i_] = kv_rows[pos_];                                \
     else dst_[i_] = p.kv_row_offset + pos_;                                       \
   }
-#define DMA_K(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
-      k_rsrc, (LDS_AS void*)(smem + (par_) * TILE8 + (CH * wave + i_) * 1024), 16,                                 \
+#define DMA_K(slot_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(  \
+      k_rsrc, (LDS_AS void*)(smem + (slot_) * TILE8 + (CH * wave + i_) * 1024), 16,                                \
       (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + k_col[i_], 0, 0, 0);
-#define DMA_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
-      v_rsrc, (LDS_AS void*)(smem + (NS + (par_)) * TILE8 + (CH * wave + i_) * 1024), 16,                          \
+#define DMA_V(slot_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(  \
+      v_rsrc, (LDS_AS void*)(smem + (K_SLOTS + (slot_)) * TILE8 + (CH * wave + i_) * 1024), 16,                    \
       (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
 
   // ---- LDS read addresses ----
@@ -151,16 +155,16 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int c = 0; c < 2; ++c) k_rd[ks][c] = r32 * ROWB8 + (((4 * ks + 2 * hh + c) ^ ((r32 >> 1) & 7)) << 4);
-  // V^T fragment (A operand, rows = channels): 16-lane group g = (half hh, channel half dsub); lane pp of the group
-  // addresses 8 bytes of key row  16 n + 4 hh + (tt & 3) + 8 (tt >> 2),  tt = pp >> 1,  at channel 32 dt + 16 dsub +
-  // 8 (pp & 1), and receives channel 32 dt + 16 dsub + pp of the group's 8 key rows = k-slots 8 n .. 8 n + 7
+  // V^T fragment (A operand, rows = channels): 16-lane group g = (half hh, channel half dsub); lane pq of the group
+  // addresses 8 bytes of key row  16 n + 4 hh + (tt & 3) + 8 (tt >> 2),  tt = pq >> 1,  at channel 32 dt + 16 dsub +
+  // 8 (pq & 1), and receives channel 32 dt + 16 dsub + pq of the group's 8 key rows = k-slots 8 n .. 8 n + 7
   int v_rd[4];
   {
     const int dsub = (lane >> 4) & 1, pq = lane & 15, tt = pq >> 1;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      v_rd[dt] = NS * TILE8 + (4 * hh + (tt & 3) + 8 * (tt >> 2)) * ROWB8 + ((dt ^ ((tt >> 1) & 3)) << 5) + 16 * dsub +
-                 8 * (pq & 1);
+      v_rd[dt] = K_SLOTS * TILE8 + (4 * hh + (tt & 3) + 8 * (tt >> 2)) * ROWB8 + ((dt ^ ((tt >> 1) & 3)) << 5) +
+                 16 * dsub + 8 * (pq & 1);
   }
 
   f32x16 o[4];
@@ -171,9 +175,11 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   f32x16 lacc;  // LMFMA: every register = sum of P' over the keys so far (ones-tile MFMA); else lacc[0] = partial sum of this lane
 #pragma unroll
   for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
-  i32x8 ones;   // e4m3 1.0 = 0x38
+  // the ones tile of the row-sum MFMA in fp4 (e2m1 1.0 = 0b0010): the A operand then takes 4 registers instead of 8
+  // (the instruction reads only the first 4 of the 8 it is given; B stays e4m3)
+  i32x8 ones;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = 0x38383838;
+  for (int i = 0; i < 8; ++i) ones[i] = 0x22222222;
   asm volatile("" : "+v"(ones));
   // Online softmax in the exp2 domain.  m_run = reference point of the row (at most `defer` below its running max);
   // the score MFMAs start from minit = p_bias - m_run, so they deliver z - m_run + p_bias and P' = exp2 of that.
@@ -184,35 +190,106 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) minit[i] = 0.f;
   float mx_cur = -1e30f;  // row max of the current block's offset scores
-  i32x8 pb_;              // packed probabilities of the current block (B operand of the PV MFMAs)
+  i32x8 pb_;              // packed probabilities of the block whose PV product is next (B operand of the PV MFMAs)
 #pragma unroll
   for (int i = 0; i < 8; ++i) pb_[i] = 0;
 
-#define KFRAG(dst_, par_, t_, ks_)                                                 \
+#ifdef VORTA_DIAG_NOLDSRD  // timing diagnostic (wrong results): fragments are never read from LDS
+#define KFRAG(dst_, slot_, t_, ks_) dst_ = qf[ks_];
+#else
+#define KFRAG(dst_, slot_, t_, ks_)                                                \
   {                                                                               \
-    const i32x4 lo_ = *(const i32x4*)(smem + (par_) * TILE8 + (t_) * 32 * ROWB8 + k_rd[ks_][0]); \
-    const i32x4 hi_ = *(const i32x4*)(smem + (par_) * TILE8 + (t_) * 32 * ROWB8 + k_rd[ks_][1]); \
+    const i32x4 lo_ = *(const i32x4*)(smem + (slot_) * TILE8 + (t_) * 32 * ROWB8 + k_rd[ks_][0]); \
+    const i32x4 hi_ = *(const i32x4*)(smem + (slot_) * TILE8 + (t_) * 32 * ROWB8 + k_rd[ks_][1]); \
     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { dst_[e_] = lo_[e_]; dst_[4 + e_] = hi_[e_]; } \
   }
-#define QK(d0_, d1_, par_)                                                        \
+#endif
+#define KFRAGS0(slot_)                                                            \
+  i32x8 kf00_, kf10_;                                                             \
+  KFRAG(kf00_, slot_, 0, 0)                                                       \
+  KFRAG(kf10_, slot_, 1, 0)
+#define KFRAGS1(slot_)                                                            \
+  i32x8 kf01_, kf11_;                                                             \
+  KFRAG(kf01_, slot_, 0, 1)                                                       \
+  KFRAG(kf11_, slot_, 1, 1)
+#ifdef VORTA_DIAG_NODEP  // timing diagnostic (wrong results): the MFMAs do not wait for the fragment reads
+#define QK_FRAGS(d0_, d1_)                                                        \
   {                                                                               \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) {                         \
-      i32x8 k0_, k1_;                                                             \
-      KFRAG(k0_, par_, 0, ks_)                                                    \
-      KFRAG(k1_, par_, 1, ks_)                                                    \
-      d0_ = mfma8(k0_, qf[ks_], ks_ == 0 ? minit : d0_);                          \
-      d1_ = mfma8(k1_, qf[ks_], ks_ == 0 ? minit : d1_);                          \
-    }                                                                             \
+    d0_ = mfma8(qf[0], qf[0], minit);                                             \
+    d1_ = mfma8(qf[1], qf[0], minit);                                             \
+    d0_ = mfma8(qf[0], qf[1], d0_);                                               \
+    d1_ = mfma8(qf[1], qf[1], d1_);                                               \
+    asm volatile("" :: "v"(kf00_), "v"(kf10_), "v"(kf01_), "v"(kf11_));           \
   }
-  // the next block's scores from K fragments that are already in registers (all four are read at the top of the step,
-  // ahead of the rare mask / rescale branches: their LDS latency is covered before the first MFMA issues)
-#define QK_PRE(d0_, d1_)                                                          \
+#else
+#define QK_FRAGS(d0_, d1_)                                                        \
   {                                                                               \
     d0_ = mfma8(kf00_, qf[0], minit);                                             \
     d1_ = mfma8(kf10_, qf[0], minit);                                             \
     d0_ = mfma8(kf01_, qf[1], d0_);                                               \
     d1_ = mfma8(kf11_, qf[1], d1_);                                               \
   }
+#endif
+#ifdef VORTA_DIAG_NOMFMA
+#define ONES_MFMA_(a_, b_, c_) mfma8(a_, b_, c_)
+#else
+#define ONES_MFMA_(a_, b_, c_) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c_, 4, 0, 0, 0, 0, 0)
+#endif
+#ifdef VORTA_DIAG_NODEP
+#define PVA_(dt_) qf[(dt_) & 1]
+#define PVKEEP_() asm volatile("" :: "v"(vf_[0]), "v"(vf_[1]), "v"(vf_[2]), "v"(vf_[3]));
+#else
+#define PVA_(dt_) vf_[dt_]
+#define PVKEEP_()
+#endif
+#ifdef VORTA_DIAG_NOLDSRD
+#define VFRAG(dt_, slot_) vf_[dt_] = qf[(dt_) & 1];
+#else
+#define VFRAG(dt_, slot_)                                                         \
+  _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                              \
+    const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                      \
+        (LDS_AS i32x2*)(smem + (slot_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8));   \
+    vf_[dt_][2 * n_] = t_[0]; vf_[dt_][2 * n_ + 1] = t_[1];                       \
+  }
+#endif
+  // the fragments of the first two channel tiles are requested ahead of the part (before the rare branches), those of
+  // the other two under the first two MFMAs -- 16 live fragment registers instead of 32
+#define VFRAGS_HEAD(slot_) i32x8 vf_[4]; VFRAG(0, slot_) VFRAG(1, slot_)
+#define PV_FRAGS(slot_)                                                           \
+  {                                                                               \
+    VFRAG(2, slot_)                                                               \
+    VFRAG(3, slot_)                                                               \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) o[dt_] = mfma8(PVA_(dt_), pb_, o[dt_]); \
+    PVKEEP_()                                                                     \
+    if constexpr (LMFMA) lacc = ONES_MFMA_(ones, pb_, lacc);                      \
+  }
+#if defined(VORTA_DIAG_NOEXP)
+#define EXP_BLOCK(c0_, c1_)
+#else
+#define EXP_BLOCK(c0_, c1_)                                                       \
+  {                                                                               \
+    float lsum_ = 0.f;                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+      c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                  \
+      c1_[i_] = __builtin_amdgcn_exp2f(c1_[i_]);                                  \
+      if constexpr (!LMFMA) lsum_ += c0_[i_] + c1_[i_];                           \
+    }                                                                             \
+    if constexpr (!LMFMA) lacc[0] += lsum_;                                       \
+  }
+#endif
+  // v_cvt_pk_fp8_f32 writes half of its destination and keeps the other half: feed it the stale word of the previous
+  // block instead of a zero (the second convert overwrites the rest)
+#if defined(VORTA_DIAG_NOCVT)
+#define PACK_BLOCK(c0_, c1_) asm volatile("" : "+v"(pb_) : "v"(c0_), "v"(c1_));
+#else
+#define PACK_BLOCK(c0_, c1_)                                                      \
+  _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                              \
+    pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_], c0_[4 * w_ + 1], pb_[w_], false); \
+    pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_ + 2], c0_[4 * w_ + 3], pb_[w_], true); \
+    pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_], c1_[4 * w_ + 1], pb_[4 + w_], false); \
+    pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_ + 2], c1_[4 * w_ + 3], pb_[4 + w_], true); \
+  }
+#endif
 #define ROW_MAX(dst_, a_, b_)                                                      \
   {                                                                               \
     float mx_ = a_[0];                                                            \
@@ -224,6 +301,9 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   // answered by a SIGNED-INTEGER max over the float bit patterns (order-preserving for the non-negative floats, and
   // any negative result reads as "not above"): v_max3_i32 needs no canonicalising v_max x,x of the MFMA outputs,
   // and two chains halve the dependent latency.  (-inf of masked keys is a negative integer; there are no NaNs.)
+#if defined(VORTA_DIAG_NOMAX)
+#define ROW_MAX_POS(dst_, a_, b_) asm volatile("" :: "v"(a_), "v"(b_));
+#else
 #define ROW_MAX_POS(dst_, a_, b_)                                                  \
   {                                                                               \
     int m0_ = imax3(__float_as_int(a_[0]), __float_as_int(a_[1]), __float_as_int(a_[2])); \
@@ -237,189 +317,210 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m0_, false, false); \
     dst_ = __int_as_float(max((int)r_[0], (int)r_[1]));                           \
   }
-  // move the reference point of the row up by g_ (>= 0)
-#define RAISE_REF(g_, c0_, c1_)                                                   \
-  {                                                                               \
-    const float alpha_ = __builtin_amdgcn_exp2f(-(g_));                           \
-    _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                           \
-      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;     \
-    if constexpr (LMFMA) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) lacc[i_] *= alpha_; } \
-    else lacc[0] *= alpha_;                                                       \
-    m_run += (g_);                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= (g_); c1_[i_] -= (g_); minit[i_] = pbias - m_run; } \
-    asm volatile("" : "+v"(minit));                                               \
+#endif
+#define MASK_TAIL(c0_, c1_, jabs_)                                                \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                             \
+    const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                           \
+    if ((jabs_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                        \
+    if ((jabs_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                   \
   }
-#define STAGE_DMA(kfree_, vfree_, j_)                                             \
-  DMA_K(kfree_)                                                                   \
-  DMA_V(vfree_)                                                                   \
+  // requests of a step: K(j+2) into the slot K(j) left, V(j+1) into the slot V(j-2) left; both are read in the next
+  // step (V(j+1) by role Y), so the end-of-step wait covers both
+#if defined(VORTA_DIAG_NODMA)
+#define STAGE_DMA(kw_, vw_, jabs_)
+#else
+#define STAGE_DMA(kw_, vw_, jabs_)                                                \
+  DMA_K(kw_)                                                                      \
+  DMA_V(vw_)                                                                      \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
-  ROWS_OF(rowK, (j_) + NS + 1)                                                    \
+  ROWS_OF(rowK, (jabs_) + 3)                                                      \
   __builtin_amdgcn_sched_barrier(0);
+#endif
 #if defined(VORTA_DIAG_NOBAR)  // timing diagnostics only (results are wrong): no workgroup barrier / no wait at all
 #define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #elif defined(VORTA_DIAG_NOSYNC)
 #define STEP_SYNC() asm volatile("" ::: "memory");
 #else
-#define STEP_SYNC()                                                               \
-  {                                                                               \
-    if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-    else if constexpr (CH == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-  }
+#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 #ifndef VORTA_SCHED8
 #define VORTA_SCHED8 1
 #endif
-  // Issue-order recipe (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x400 transcendental, 0x002 VALU).
-  // Score phase (4 MFMAs of 64 cycles): the 32 exp2 and the 16 packs of this block beside them (every PV MFMA needs
-  // the whole packed block, so nothing of it can wait); PV phase (4 + 1 MFMAs): the transposed V reads and the next
-  // block's row max.
+  // Issue-order recipe (sched_group_barrier: 0x008 MFMA, 0x100 DS read) of the PV half of the matrix part: 5 MFMAs
+  // with the fragment reads of the later ones (V channel tiles 2,3; k-step 0 of the next K block) under the earlier
+  // ones; the score half follows (its k-step-1 fragments are requested first).
 #if VORTA_SCHED8 == 1
-  // the V fragment reads (16 x ds_read_b64_tr_b8) are issued under the last two score MFMAs, two MFMAs (128 cycles)
-  // ahead of the first PV MFMA: an LDS read issued right before its MFMA exposes its latency on every one of them
-#define SCHED_RECIPE()                                                            \
-  _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x400, 8, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
-  }                                                                               \
-  _Pragma("unroll") for (int g_ = 0; g_ < 2; ++g_) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x400, 8, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                            \
-  }                                                                               \
-  _Pragma("unroll") for (int g_ = 0; g_ < 5; ++g_) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                            \
-  }
+#define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
+#define SCHED_M()                                                                 \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 2)                                                     \
+  SG_(0x008, 1) SG_(0x100, 2)                                                     \
+  SG_(0x008, 1)
 #else
-#define SCHED_RECIPE()
+#define SCHED_M()
 #endif
-#define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, vfree_, j_)                       \
+#ifndef VORTA_PRIO8
+#define VORTA_PRIO8 1  /* s_setprio around the matrix part (the partner wave is in its VALU part then) */
+#endif
+#if VORTA_PRIO8
+#define PRIO_HI() __builtin_amdgcn_s_setprio(2);
+#define PRIO_LO() __builtin_amdgcn_s_setprio(0);
+#else
+#define PRIO_HI()
+#define PRIO_LO()
+#endif
+  // The two waves of a SIMD (wave w and w + NW/2 of the workgroup) take turns on its pipes: while one runs its matrix
+  // part -- 9 MFMAs back to back: O += V^T P^T and the row sums of one block, the scores of a later one -- the other
+  // runs its VALU part -- the 32 exp2 and 16 packs of a block (quarter-rate ops: ~9 cycles of SIMD issue each,
+  // tools/probe_overlap.hip) and a row max.  Both parts take ~600 cycles, so the matrix pipe and the VALU are busy
+  // together all the time.  (With both waves in the same part at the same time the SIMD's issue is by age: the older
+  // wave takes the matrix pipe, the younger waits, and their VALU parts end up exposed one after the other --
+  // measured 48 % MFMA utilisation, every VALU instruction removed from the loop came off the run time in full.)
+  //   step j, waves < NW/2 :   matrix(j)  then  valu(block j; max of block j+1)
+  //   step j, waves >= NW/2:   valu(block j-1; max of block j)  then  matrix(j)
+  //   matrix(j) = PV(j-1) + row sums, [mask the tail of block j], [move the reference point for block j], QK(j+1)
+  // The matrix part is the same code for both roles; the VALU part is the same code on swapped score buffers.  Both
+  // roles see the same reference points (the decision for block j looks at max(j) against the reference after block
+  // j-1) and run the same barriers.
+  //   kw_/kr_: K slots written (K(j+2)) / read (K(j+1));  vw_/vr_: V slots written (V(j+1)) / read (V(j-1)).
+  //   c = scores of block j (offset by the reference point), n = scores of block j+1 (written by the matrix part).
+#define VALU_PART(e0_, e1_, m0_, m1_)                                             \
   {                                                                               \
-    STAGE_DMA(kcur_, vfree_, j_)                                                  \
+    EXP_BLOCK(e0_, e1_)                                                           \
+    PACK_BLOCK(e0_, e1_)                                                          \
+    ROW_MAX_POS(mx_cur, m0_, m1_)                                                 \
+  }
+#define MATRIX_PART(c0_, c1_, n0_, n1_, kr_, vr_, jabs_)                          \
+  {                                                                               \
+    PRIO_HI()                                                                     \
+    VFRAGS_HEAD(vr_)                                                              \
+    PV_FRAGS(vr_)                                                                 \
+    KFRAGS0(kr_)                                                                  \
+    SCHED_M()                                                                     \
+    /* last, partial key block: mask its tail, exact row max (once per workgroup) */ \
+    if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(c0_, c1_, jabs_) ROW_MAX(mx_cur, c0_, c1_) } \
+    /* deferred rescale: the reference point moves only when some row of the wave outgrew it by more than `defer`; */ \
+    /* O and the row sums follow AFTER block j-1 went in at the old reference                                        */ \
+    if (!__all(mx_cur <= thr)) {                                                  \
+      const float g_ = fmaxf(mx_cur - pbias, 0.f);                                \
+      const float alpha_ = __builtin_amdgcn_exp2f(-g_);                           \
+      m_run += g_;                                                                \
+      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                         \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;   \
+      if constexpr (LMFMA) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) lacc[i_] *= alpha_; } \
+      else lacc[0] *= alpha_;                                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= g_; c1_[i_] -= g_; minit[i_] = pbias - m_run; } \
+      asm volatile("" : "+v"(minit));                                             \
+    }                                                                             \
+    KFRAGS1(kr_)                                                                  \
+    QK_FRAGS(n0_, n1_)                                                            \
+    PRIO_LO()                                                                     \
+  }
+#define STEP(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_)                       \
+  {                                                                               \
+    STAGE_DMA(kw_, vw_, jabs_)                                                    \
     if (wave_active) {                                                            \
-      i32x8 kf00_, kf10_, kf01_, kf11_;                                           \
-      KFRAG(kf00_, knext_, 0, 0)                                                  \
-      KFRAG(kf10_, knext_, 1, 0)                                                  \
-      KFRAG(kf01_, knext_, 0, 1)                                                  \
-      KFRAG(kf11_, knext_, 1, 1)                                                  \
-      if ((j_) * KVB + KVB > n_kv) {                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
-          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
-          if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
-          if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
-        }                                                                         \
-        ROW_MAX(mx_cur, c0_, c1_)                                                 \
-      }                                                                           \
-      if (!__all(mx_cur <= thr)) {                                                \
-        const float g_ = fmaxf(mx_cur - pbias, 0.f);                              \
-        RAISE_REF(g_, c0_, c1_)                                                   \
-      }                                                                           \
-      QK_PRE(n0_, n1_) /* block j+1 (harmless values past the end) */             \
-      float lsum_ = 0.f;                                                          \
-      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
-        c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                \
-        c1_[i_] = __builtin_amdgcn_exp2f(c1_[i_]);                                \
-        if constexpr (!LMFMA) lsum_ += c0_[i_] + c1_[i_];                         \
-      }                                                                           \
-      if constexpr (!LMFMA) lacc[0] += lsum_;                                     \
-      /* v_cvt_pk_fp8_f32 writes half of its destination and keeps the other half: feed it the stale word of */ \
-      /* the previous block instead of a zero (the second convert overwrites the rest)                        */ \
-      _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                          \
-        pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_], c0_[4 * w_ + 1], pb_[w_], false); \
-        pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_ + 2], c0_[4 * w_ + 3], pb_[w_], true); \
-        pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_], c1_[4 * w_ + 1], pb_[4 + w_], false); \
-        pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_ + 2], c1_[4 * w_ + 3], pb_[4 + w_], true); \
-      }                                                                           \
-      i32x8 vf_[4];                                                               \
-      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
-        _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                        \
-          const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                \
-              (LDS_AS i32x2*)(smem + (kcur_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8)); \
-          vf_[dt_][2 * n_] = t_[0]; vf_[dt_][2 * n_ + 1] = t_[1];                 \
-        }                                                                         \
-      }                                                                           \
-      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) o[dt_] = mfma8(vf_[dt_], pb_, o[dt_]); \
-      if constexpr (LMFMA) lacc = mfma8(ones, pb_, lacc);                         \
-      ROW_MAX_POS(mx_cur, n0_, n1_)                                               \
-      SCHED_RECIPE()                                                              \
+      if (role_y) VALU_PART(n0_, n1_, c0_, c1_)                                   \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      MATRIX_PART(c0_, c1_, n0_, n1_, kr_, vr_, jabs_)                            \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      if (!role_y) VALU_PART(c0_, c1_, n0_, n1_)                                  \
     }                                                                             \
     STEP_SYNC()                                                                   \
   }
 
-  if (blk0 < blk1) {
+  const int nsteps = blk1 - blk0;
+#if defined(VORTA_DIAG_ALLX)
+  const bool role_y = false;
+#else
+  const bool role_y = NW == 8 && wave >= NW / 2;  // wave-uniform
+#endif
+  if (nsteps > 0) {
+    // ---- prologue: K(0), V(0), K(1); the scores of block 0 fix the reference point ----
     ROWS_OF(rowK, blk0)
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     DMA_K(0)
     DMA_V(0)
     ROWS_OF(rowK, blk0 + 1)
     DMA_K(1)
-    if constexpr (NS == 3) {
-      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-      DMA_V(1)
-      ROWS_OF(rowK, blk0 + 2)
-      DMA_K(2)
-    }
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-    ROWS_OF(rowK, blk0 + NS)
+    ROWS_OF(rowK, blk0 + 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave_active) {
-      QK(sA0, sA1, 0)  // seed 0: plain scores of the first block
-      if (blk0 * KVB + KVB > n_kv) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (blk0 * KVB + row >= n_kv) sA0[i] = -INFINITY;
-          if (blk0 * KVB + 32 + row >= n_kv) sA1[i] = -INFINITY;
-        }
-      }
+      KFRAGS0(0)
+      KFRAGS1(0)
+      QK_FRAGS(sA0, sA1)  // seed 0: plain scores of the first block
+      if (blk0 * KVB + KVB > n_kv) { MASK_TAIL(sA0, sA1, blk0) }
       ROW_MAX(mx_cur, sA0, sA1)
       // the first block fixes the reference point at its true row max (it always holds a valid key)
       m_run = mx_cur;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { sA0[i] += pbias - m_run; sA1[i] += pbias - m_run; minit[i] = pbias - m_run; }
       asm volatile("" : "+v"(minit));
-      mx_cur = pbias;
     }
-    __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot
-  }
-  if constexpr (NS == 2) {
-    for (int blk = blk0; blk < blk1; blk += 2) {
-      STEP(sA0, sA1, sB0, sB1, 0, 1, 1, blk)
-      if (blk + 1 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 1, 0, 0, blk + 1)
+    __syncthreads();  // every wave has read K(0) before its slot is overwritten
+    {  // step 0: no PV yet -- the scores of block 1, then (first role) the VALU part of block 0
+      STAGE_DMA(0, 1, blk0)
+      if (wave_active) {
+        KFRAGS0(1)
+        KFRAGS1(1)
+        QK_FRAGS(sB0, sB1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!role_y) VALU_PART(sA0, sA1, sB0, sB1)
+      }
+      STEP_SYNC()
     }
-  } else {
-    for (int blk = blk0; blk < blk1; blk += 6) {
-      STEP(sA0, sA1, sB0, sB1, 0, 1, 2, blk)
-      if (blk + 1 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 1, 2, 0, blk + 1)
-      if (blk + 2 >= blk1) break;
-      STEP(sA0, sA1, sB0, sB1, 2, 0, 1, blk + 2)
-      if (blk + 3 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 0, 1, 2, blk + 3)
-      if (blk + 4 >= blk1) break;
-      STEP(sA0, sA1, sB0, sB1, 1, 2, 0, blk + 4)
-      if (blk + 5 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 2, 0, 1, blk + 5)
+    // K slots cycle with period 2, V slots with period 3, score roles with period 2: unrolled by 6
+    for (int jj = 1; jj < nsteps; jj += 6) {
+      STEP(sB0, sB1, sA0, sA1, 1, 0, 2, 0, blk0 + jj)
+      if (jj + 1 >= nsteps) break;
+      STEP(sA0, sA1, sB0, sB1, 0, 1, 0, 1, blk0 + jj + 1)
+      if (jj + 2 >= nsteps) break;
+      STEP(sB0, sB1, sA0, sA1, 1, 0, 1, 2, blk0 + jj + 2)
+      if (jj + 3 >= nsteps) break;
+      STEP(sA0, sA1, sB0, sB1, 0, 1, 2, 0, blk0 + jj + 3)
+      if (jj + 4 >= nsteps) break;
+      STEP(sB0, sB1, sA0, sA1, 1, 0, 0, 1, blk0 + jj + 4)
+      if (jj + 5 >= nsteps) break;
+      STEP(sA0, sA1, sB0, sB1, 0, 1, 1, 2, blk0 + jj + 5)
+    }
+    // ---- drain: the second role still owes the VALU part of the last block; then PV of the last block ----
+    if (wave_active) {
+      if (role_y) {
+        if ((nsteps - 1) & 1) { EXP_BLOCK(sB0, sB1) PACK_BLOCK(sB0, sB1) }
+        else { EXP_BLOCK(sA0, sA1) PACK_BLOCK(sA0, sA1) }
+      }
+      const int vs = (nsteps - 1) % V_SLOTS;
+      VFRAGS_HEAD(vs)
+      PV_FRAGS(vs)
     }
   }
 #undef KFRAG
-#undef QK
-#undef QK_PRE
+#undef KFRAGS0
+#undef KFRAGS1
+#undef QK_FRAGS
+#undef VFRAG
+#undef VFRAGS_HEAD
+#undef PV_FRAGS
+#undef EXP_BLOCK
+#undef PACK_BLOCK
 #undef ROW_MAX
 #undef ROW_MAX_POS
-#undef RAISE_REF
+#undef MASK_TAIL
 #undef STEP
+#undef VALU_PART
+#undef MATRIX_PART
+#undef PRIO_HI
+#undef PRIO_LO
 #undef STAGE_DMA
 #undef STEP_SYNC
 #undef ROWS_OF
 #undef DMA_K
 #undef DMA_V
-#undef SCHED_RECIPE
+#undef SCHED_M
+#undef SG_
 
   if (!wave_active) return;
   // ---------------- epilogue ----------------
@@ -481,25 +582,24 @@ __device__ __forceinline__ int xcd_order(int b, int n) {
 template <typename TO, int NW, bool KVTAB, bool LMFMA>
 __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const Params8 pp) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int NS = NW == 8 ? VORTA_RING8 : 2;
-  __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE8];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM8];
   const int wg = pp.p.xcd_remap ? xcd_order(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  attn8_body<TO, NW, KVTAB, NS, LMFMA>(pp, smem, wg);
+  attn8_body<TO, NW, KVTAB, LMFMA>(pp, smem, wg);
 #endif
 }
 
 template <typename TO>
 __global__ __launch_bounds__(512, 2) void attn8_multi_kernel(const MultiParams8 mp) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __shared__ __attribute__((aligned(16))) char smem[2 * VORTA_RING8 * TILE8];
+  __shared__ __attribute__((aligned(16))) char smem[SMEM8];
   const int b = blockIdx.x;
   int s = 0;
 #pragma unroll
   for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
   const Params8& pp = mp.seg[s];
   const int wg = xcd_order(b - mp.start[s], mp.start[s + 1] - mp.start[s]);
-  if (pp.p.kv_rows) attn8_body<TO, 8, true, VORTA_RING8, true>(pp, smem, wg);
-  else attn8_body<TO, 8, false, VORTA_RING8, true>(pp, smem, wg);
+  if (pp.p.kv_rows) attn8_body<TO, 8, true, true>(pp, smem, wg);
+  else attn8_body<TO, 8, false, true>(pp, smem, wg);
 #endif
 }
 
