@@ -113,6 +113,8 @@ def cpu_baseline(cfg, mix, step_flops):
 
 
 def main():
+    # the host driver only supports dmabuf IPC: must be in the environment before HIP / HSA initialise
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -155,7 +157,6 @@ def main():
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

@@ -160,15 +160,84 @@ def test_hunyuan_token_replace_uses_first_timestep_embedding_and_descriptor_is_c
     assert torch.equal(out[4][0].to(dev()), block.router(calls[0]))
     assert not torch.equal(block.router(calls[0]), block.router(calls[1]))
     ctx = E.context_of(model)
-    desc = next(iter(ctx.descriptor_cache.values()))
+    desc = ctx.descriptor_cache["entry"][3]
     assert desc.text_seq_length == T and desc.text_seq_length_no_pad == TE
     model(**inp, return_dict=False, self_attention_kwargs=_hy_kwargs())
-    assert next(iter(ctx.descriptor_cache.values())) is desc  # same prompt tensor: no rebuild, no host read
+    assert ctx.descriptor_cache["entry"][3] is desc  # same prompt tensor: no rebuild, no host read
     h.remove()
     with pytest.raises(NotImplementedError):
         model(**inp, self_attention_kwargs=_hy_kwargs(), return_losses=True)
     with pytest.raises(ValueError):
         model(**inp)
+
+
+def test_hunyuan_descriptor_follows_the_prompt_not_the_address():
+    """two prompts with different valid text lengths through one patched model; the first prompt's mask is freed before
+    the second is created, so the allocator may hand out the same address (a cache keyed on data_ptr served
+    prompt 1's valid length to prompt 2)"""
+    from vorta_amd.patch import _engine as E
+    from vorta.attention import create_sliding_tile_attn_mask_func
+    model = _hy_model(seed=9)
+    ctx = E.context_of(model)
+    inp = _hy_inputs()
+    model(**inp, return_dict=False, self_attention_kwargs=_hy_kwargs())
+    assert ctx.descriptor_cache["entry"][3].text_seq_length_no_pad == TE
+    ptr = inp["encoder_attention_mask"].data_ptr()
+    del inp["encoder_attention_mask"]
+    # worst case: nothing holds the old mask any more (the entry normally does), so its address is free for reuse
+    ctx.descriptor_cache["entry"] = (None,) + ctx.descriptor_cache["entry"][1:]
+    te2 = 5
+    mask2 = torch.zeros((1, T), device=dev())
+    mask2[:, :te2] = 1
+    inp["encoder_attention_mask"] = mask2
+    out = model(**inp, return_dict=False, self_attention_kwargs=_hy_kwargs())[0]
+    assert ctx.descriptor_cache["entry"][0] is mask2 and ctx.descriptor_cache["entry"][3].text_seq_length_no_pad == te2
+    want = create_sliding_tile_attn_mask_func(latent_shape=LATENT, window_size=WINDOW, tile_size=TILE, text_seq_length=T,
+                                              text_seq_length_no_pad=te2, device=dev())
+    ref = model(**inp, return_dict=False, self_attention_kwargs=dict(_hy_kwargs(), flex_attn_mask_func=want))[0]
+    assert torch.equal(out, ref)
+    print("mask address reused by the allocator:", mask2.data_ptr() == ptr)
+    # in-place edits of the same tensor are seen through its version counter
+    mask2[:, :8] = 1
+    model(**inp, return_dict=False, self_attention_kwargs=_hy_kwargs())
+    assert ctx.descriptor_cache["entry"][3].text_seq_length_no_pad == 8
+
+
+def test_wan_rope_table_follows_the_frequency_tensor_not_its_address():
+    """480x832 then 832x480 in one process: equal shapes, different contents, and the freed table's address is reused"""
+    from vorta_amd.attention.wan import _cos_sin
+    rope = M.MiniWanRope()
+    def table(f, h, w):
+        return rope(torch.zeros((1, 4, f, h, w), device=dev()))
+    f1 = table(4, 6, 8)
+    c1, s1 = _cos_sin(f1)
+    assert _cos_sin(f1)[0] is c1  # the blocks of one forward share the entry
+    ptr = f1.data_ptr()
+    del f1
+    import vorta_amd.attention.wan as wan
+    wan._ROPE_CACHE["entry"] = (None,) + wan._ROPE_CACHE["entry"][1:]
+    f2 = table(4, 8, 6)
+    c2, s2 = _cos_sin(f2)
+    flat = f2.reshape(-1, f2.shape[-1])
+    assert torch.equal(c2, flat.real.float().repeat_interleave(2, dim=1))
+    assert torch.equal(s2, flat.imag.float().repeat_interleave(2, dim=1))
+    assert not torch.equal(c2, c1)
+    print("frequency table address reused by the allocator:", f2.data_ptr() == ptr)
+
+
+def test_hunyuan_dense_mask_shapes():
+    """L = valid keys from a [B,1,1,N] key mask (diffusers 0.33) or one row of a [B,1,N,N] / [B,N,N] mask; other
+    shapes are refused"""
+    from vorta_amd.attention.hunyuan import _valid_keys
+    N, L = 40, 29
+    key = torch.zeros((1, 1, 1, N), dtype=torch.bool, device=dev())
+    key[..., :L] = True
+    assert int(_valid_keys(key)) == L
+    assert int(_valid_keys(key.expand(1, 1, N, N))) == L
+    assert int(_valid_keys(key[0].expand(1, N, N))) == L
+    assert int(_valid_keys(key.float())) == L
+    with pytest.raises(ValueError):
+        _valid_keys(torch.ones((1, 1, 3, N), device=dev()))
 
 
 def test_hunyuan_native_attention_patch_matches_all_dense_routing():

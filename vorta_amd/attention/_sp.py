@@ -16,6 +16,7 @@ from ..ulysses import SP_STATE
 from ..ulysses.engine import UlyssesLayout, balanced_head_order, exchange_and_attend, slot_groups
 
 _LAYOUTS = {}
+_ROUTINGS = {}  # (local expert ids, device) -> HeadRouting: the device tables are built once per distinct local mix
 SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
 
 
@@ -25,6 +26,18 @@ def _layout(H, S, T, D, device, dtype):
         lay = UlyssesLayout(H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, device, dtype, SP_STATE.group)
         _LAYOUTS[key] = (lay, [lay.new_buffer() for _ in range(4)])
     return _LAYOUTS[key]
+
+
+def _routing(local_experts: tuple, device) -> HeadRouting:
+    """HeadRouting.from_expert_ids builds a CPU tensor and copies it to the device (a host stall per layer on the
+    sequence-parallel path): cached per distinct local expert tuple (at most 3^(H/P) of them, a handful in practice)."""
+    key = (local_experts, str(device))
+    r = _ROUTINGS.get(key)
+    if r is None:
+        if len(_ROUTINGS) > 4096:
+            _ROUTINGS.clear()
+        r = _ROUTINGS[key] = HeadRouting.from_expert_ids(list(local_experts), device)
+    return r
 
 
 def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_sparse: Optional[float], *, model: str,
@@ -43,7 +56,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
         te = T
         if attention_mask is not None:  # host read, as hunyuan.py:169; the mask covers the global video (reference's
             # patched forward, modeling_hunyuan.py:86-88) or the local shard (stock diffusers forward)
-            te = int(attention_mask.sum().item()) - (attention_mask.shape[-1] - T)
+            from .hunyuan import _valid_keys
+            te = int(_valid_keys(attention_mask).item()) - (attention_mask.shape[-1] - T)
     elif experts_host is not None:  # dispatched by the step's route plan: no device read in this layer
         experts = list(experts_host)
         te = text_valid
@@ -77,7 +91,7 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
             ops.attn_fwd(qv[g0:g1], kv[g0:g1], vv[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
                          q_rows=rm[:S + T], kv_rows=rm[:S + te])
         else:
-            routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], HeadRouting.from_expert_ids(local[g0:g1], q.device), geom,
+            routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], _routing(tuple(local[g0:g1]), q.device), geom,
                              model=model, text_len=T, text_valid=te, out=ov[g0:g1])
 
     # the received heads are written straight into the (1, N, H, D) result the output projection reads

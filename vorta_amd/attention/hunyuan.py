@@ -47,6 +47,19 @@ def fused_norm_rope(x: torch.Tensor, norm, rope: Optional[Tuple[torch.Tensor, to
     return x
 
 
+def _valid_keys(attention_mask: torch.Tensor) -> torch.Tensor:
+    """Number of valid keys L (int32, shape (1,), on the device) from the reference's attention mask
+    (hunyuan.py:169 `attention_mask.squeeze().sum()` on the diffusers 0.33 [B,1,1,N] key mask).  Other diffusers versions
+    hand a [B,N,N] / [B,1,N,N] mask: one query row is reduced then, anything else is refused instead of silently
+    attending padded text."""
+    N = attention_mask.shape[-1]
+    rows = attention_mask.numel() // (attention_mask.shape[0] * N)
+    if rows not in (1, N):
+        raise ValueError(f"unsupported attention_mask shape {tuple(attention_mask.shape)}: expected [B,1,1,N] or [B,(1,)N,N]")
+    row = attention_mask.reshape(attention_mask.shape[0], rows, N)[0, 0]
+    return row.sum(dtype=torch.int32).reshape(1)
+
+
 class HunyuanVideoFlashAttnProcessor:
     """Dense attention for every head: the --native_attention path (hunyuan.py:35-238)."""
 
@@ -121,7 +134,7 @@ class HunyuanVideoFlashAttnProcessor:
         # the reference reads this on the host as well (hunyuan.py:169 `attention_mask.squeeze().sum()`).  The mask
         # spans [video | text]: the global video under the reference's patched forward (modeling_hunyuan.py:86-88),
         # the local shard under the stock diffusers forward -- either way its video part is all ones.
-        return int(attention_mask.sum().item()) - (attention_mask.shape[-1] - T)
+        return int(_valid_keys(attention_mask).item()) - (attention_mask.shape[-1] - T)
 
     def _dense(self, q, k, v, attention_mask, T):
         B = q.shape[0]
@@ -131,7 +144,7 @@ class HunyuanVideoFlashAttnProcessor:
             return sp_attention(q, k, v, T, None, None, model="hunyuan", attention_mask=attention_mask)
         buf, out = self._new_out(q)
         # L = attention_mask.sum() stays on the device: no host sync (the reference syncs at hunyuan.py:169)
-        L = attention_mask.sum(dtype=torch.int32).reshape(1)
+        L = _valid_keys(attention_mask)
         N = q.shape[2]
         ops.attn_fwd(q[0], k[0], v[0], out[0], n_q=N, n_kv=N, q_valid=N, n_kv_dev=L, q_valid_dev=L)
         return buf

@@ -24,16 +24,17 @@ _ROPE_CACHE = {}
 
 
 def _cos_sin(freqs: torch.Tensor):
-    """complex frequencies (1,1,S,D/2) -> fp32 (cos, sin) of shape (S,D) with each value repeated for its pair;
-    cached per frequency tensor (it is built once per run, modeling_wan.py:242-262)."""
-    key = (freqs.data_ptr(), tuple(freqs.shape), freqs._version)
-    hit = _ROPE_CACHE.get(key)
-    if hit is None:
-        f = freqs.reshape(-1, freqs.shape[-1])
-        hit = (f.real.float().repeat_interleave(2, dim=1).contiguous(), f.imag.float().repeat_interleave(2, dim=1).contiguous())
-        _ROPE_CACHE.clear()
-        _ROPE_CACHE[key] = hit
-    return hit
+    """complex frequencies (1,1,S,D/2) -> fp32 (cos, sin) of shape (S,D) with each value repeated for its pair.
+    One entry, keyed on the frequency tensor OBJECT (held by the entry: a freed tensor's address is routinely reused
+    for the next forward's table, e.g. 480x832 then 832x480 give equal shapes and different contents) and its version:
+    the 30-40 blocks of one forward share the tensor (modeling_wan.py:242-262), the next forward builds a new one."""
+    hit = _ROPE_CACHE.get("entry")
+    if hit is not None and hit[0] is freqs and hit[1] == freqs._version:
+        return hit[2]
+    f = freqs.reshape(-1, freqs.shape[-1])
+    cs = (f.real.float().repeat_interleave(2, dim=1).contiguous(), f.imag.float().repeat_interleave(2, dim=1).contiguous())
+    _ROPE_CACHE["entry"] = (freqs, freqs._version, cs)
+    return cs
 
 
 class WanAttnProcessor2_0:

@@ -56,5 +56,25 @@ def build(force: bool = False, verbose: bool = True, extra_flags=None, suffix: s
     return lib
 
 
+def kernel_resources(source: str):
+    """Compile one source to gfx950 assembly with the product flags and return, per kernel symbol, the register /
+    spill / scratch / LDS figures of its code-object metadata (works without a GPU)."""
+    import re
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call([hipcc] + FLAGS + ["-S", "--cuda-device-only", os.path.join(CSRC, source), "-o", out])
+        text = open(out).read()
+    meta = text[text.index("amdhsa.kernels"):]
+    res = {}
+    for block in meta.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        get = lambda key: int(re.search(key + r":\s+(\d+)", block).group(1))
+        res[name] = dict(vgpr=get(r"\.vgpr_count"), vgpr_spill=get(r"\.vgpr_spill_count"), sgpr_spill=get(r"\.sgpr_spill_count"),
+                         scratch=get(r"\.private_segment_fixed_size"), lds=get(r"\.group_segment_fixed_size"))
+    return res
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv or bool(os.environ.get("VORTA_BUILD_SUFFIX")))

@@ -304,7 +304,9 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #ifndef VORTA_KPRE
 #define VORTA_KPRE 2
 #endif
-  constexpr int KPRE = VORTA_KPRE;     // k-steps of K fragments read ahead of the softmax head
+  // k-steps of K fragments read ahead of the softmax head; the 128-row body with a key table keeps two row ids per lane
+  // on top of that and spilled 5 VGPRs at depth 2 (24 B of scratch): one step there
+  constexpr int KPRE = (NW == 4 && KVTAB && VORTA_KPRE > 1) ? 1 : VORTA_KPRE;
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;

@@ -43,17 +43,18 @@ def _complete_kwargs(model, args, kwargs, sak: Dict[str, Any]) -> Dict[str, Any]
     if mask is None:
         raise ValueError(f"cannot build the sliding-tile descriptor: forward got no `encoder_attention_mask` ({names})")
     ctx = E.context_of(model)
-    key = (mask.data_ptr(), mask._version, tuple(mask.shape), tuple(sak["latent_shape"]), tuple(sak["window_size"]),
-           tuple(sak["tile_size"]))
-    desc = ctx.descriptor_cache.get(key)
-    if desc is None:
-        ctx.descriptor_cache.clear()
-        desc = create_sliding_tile_attn_mask_func(
-            latent_shape=sak["latent_shape"], window_size=sak["window_size"], tile_size=sak["tile_size"],
-            text_seq_length=mask.shape[1],
-            text_seq_length_no_pad=int(mask.sum(dim=1, dtype=torch.int)[0].item()),  # adhoc: batch_size>1
-            device=mask.device)
-        ctx.descriptor_cache[key] = desc
+    # One entry, keyed on the mask OBJECT (kept alive by the entry, so its address cannot be handed to the next
+    # prompt's mask while we still trust it) and its version counter; the geometry is part of the key too.
+    geo = (tuple(mask.shape), tuple(sak["latent_shape"]), tuple(sak["window_size"]), tuple(sak["tile_size"]))
+    hit = ctx.descriptor_cache.get("entry")
+    if hit is not None and hit[0] is mask and hit[1] == mask._version and hit[2] == geo:
+        return dict(sak, flex_attn_mask_func=hit[3])
+    desc = create_sliding_tile_attn_mask_func(
+        latent_shape=sak["latent_shape"], window_size=sak["window_size"], tile_size=sak["tile_size"],
+        text_seq_length=mask.shape[1],
+        text_seq_length_no_pad=int(mask.sum(dim=1, dtype=torch.int)[0].item()),  # adhoc: batch_size>1
+        device=mask.device)
+    ctx.descriptor_cache["entry"] = (mask, mask._version, geo, desc)
     return dict(sak, flex_attn_mask_func=desc)
 
 
