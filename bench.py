@@ -128,6 +128,11 @@ def main():
     ap.add_argument("--sp-groups", type=int, default=int(os.environ.get("VORTA_SP_GROUPS", "1")),
                     help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
                          "overlaps the attention of another (1 = exchange, then attend; the measured default)")
+    ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
+                    help="on ONE GPU: the work rank 0 of a P-way Ulysses run does per step -- its H/P heads over the whole "
+                         "sequence through the zero-copy receive layout, the send-side staging passes and the un-permute "
+                         "of the output included, the transfers themselves left out.  The step still covers the whole sequence, so "
+                         "`value` is an upper bound of the P-GPU throughput; not a BASELINE line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-ceiling", action="store_true",
                     help="skip the torch.matmul (hipBLASLt) context measurement reported beside roofline.frac")
@@ -181,6 +186,11 @@ def main():
         f, per_head = algorithmic_flops(cfg, e)
         step_flops += f * cfg["fwd_per_step"]
 
+    emu = args.emulate_rank
+    if emu:
+        if world != 1 or fp8:
+            raise SystemExit("--emulate-rank runs on one GPU, 16-bit")
+        P = emu
     if P == 1:
         geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], dev)
         routings = [HeadRouting.from_expert_ids(e, dev) for e in layer_ids]
@@ -207,7 +217,8 @@ def main():
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
                                             concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
-                                            groups=args.sp_groups if (H // P) % args.sp_groups == 0 else 1)
+                                            groups=args.sp_groups if (H // P) % args.sp_groups == 0 else 1,
+                                            loopback=bool(emu))
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):
@@ -269,18 +280,21 @@ def main():
         "metric": "video_tokens_per_sec (routed-attention denoising step, HunyuanVideo 720p 129f)"
         if args.config == "hunyuan-129f" else f"video_tokens_per_sec (routed-attention denoising step, {args.config})",
         "value": round(tokens / (ms_per_step * 1e-3), 1), "unit": "video_tokens/s",
+        **({"emulated_rank_of": emu, "note": "one rank's compute of a %d-GPU Ulysses step on one GPU (no transfers): an "
+            "upper bound of the %d-GPU value, not a measurement of it" % (emu, emu)} if emu else {}),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "backend": (backend if world > 1 else None),
         "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
-                   "parallelism": "single GPU" if P == 1 else f"ulysses sp{P} (RCCL all-to-all over xGMI)"
+                   "parallelism": "single GPU" if P == 1 else (f"rank 0 of ulysses sp{P}, emulated on one GPU, no transfers"
+                                                               if emu else f"ulysses sp{P} (RCCL all-to-all over xGMI)")
                    + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else ""),
                    "experts": {"fused": "one fused grid per layer", "serial": "one launch per expert",
                                "concurrent": "experts on side streams"}[args.experts],
                    "step_algorithmic_pflop": round(step_flops / 1e15, 3),
-                   "step_tflops_per_gpu": round(step_flops / (ms_per_step * 1e-3) / 1e12 / world, 1)},
+                   "step_tflops_per_gpu": round(step_flops / (ms_per_step * 1e-3) / 1e12 / (emu or world), 1)},
         "roofline": roofline,
         "per_launch": per_tag,
     }
@@ -308,7 +322,7 @@ def main():
             roofline["library_gemm_tflops"] = None
             roofline["library_gemm_error"] = f"{type(exc).__name__}: {exc}"[:200]
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not emu:
             res["cpu_baseline"] = cpu_baseline(cfg, args.mix, step_flops)
         print(json.dumps(res), flush=True)
     if world > 1:

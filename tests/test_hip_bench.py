@@ -43,3 +43,18 @@ def test_bench_two_rank_rehearsal():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = _line(r.stdout)
     assert KEYS <= set(j) and j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+
+
+def test_bench_emulated_rank_and_fp8_lines():
+    """--emulate-rank P: one rank's share of a P-way Ulysses step on one GPU (loopback layout, no transfers);
+    --dtype fp8: the e4m3 path (quantiser inside the step)."""
+    r = subprocess.run([sys.executable, "bench.py", "--config", "tiny", "--steps", "1", "--warmup", "1", "--emulate-rank", "4",
+                        "--no-gemm-ceiling"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["emulated_rank_of"] == 4 and j["n_gpus"] == 1 and "emulated" in j["config"]["parallelism"] and "cpu_baseline" not in j
+    r = subprocess.run([sys.executable, "bench.py", "--config", "tiny", "--steps", "1", "--warmup", "1", "--dtype", "fp8",
+                        "--no-gemm-ceiling", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["dtype"] == "fp8" and j["roofline"]["peak"] == 5000.0 and j["roofline"]["kernel"].startswith("attn8_")

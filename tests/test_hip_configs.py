@@ -44,25 +44,22 @@ def test_config0_wan13b_49f_native_attention():
     assert (out2.float() - const.float()).abs().max().item() <= 2e-2
 
 
-def _sampled_expert_checks(model, latent, tile, group, H, experts, dtype, seed, text=(0, 0)):
-    """Routed op at full size; per expert compare sampled query rows with the oracle run on the key/query lists the
-    kernels used (tables are bit-exact vs the reference at small size), plus the structural properties."""
+def _verify_samples(model, geom, q, k, v, experts, rows_of, dtype, seed, text=(0, 0)):
+    """Per expert: sampled query rows against the oracle run on the key / query lists the kernels used (the tables are
+    bit-exact vs the reference at small size), plus the structural properties.  q,k,v: (1,H,S+T,128) in TOKEN order;
+    rows_of(h, token_ids) -> the kernel's output rows of head h for those tokens (whatever layout it wrote them in)."""
     from vorta_amd import ops
-    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
-    S = latent[0] * latent[1] * latent[2]
-    T, te = text
-    q, k, v = (_rand((1, H, S + T, 128), seed + i, dtype) for i in range(3))
-    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
-    out = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, model=model, text_len=T,
-                           text_valid=te)
+    S, (T, te) = geom.S, text
+    latent, group = geom.latent, geom.group
     gen = torch.Generator().manual_seed(seed)
     tol = ATOL_SAME[dtype]
     f64 = lambda t: t.double().cpu().numpy()
+    got = lambda h, ids: rows_of(h, torch.as_tensor(ids).to(dev()).long()).float().cpu().numpy()
     h_full, h_low, h_sl = (experts.index(e) for e in (0, 1, 2))
     # full expert: sampled rows vs dense oracle
     rows = torch.randint(0, S, (32,), generator=gen)
     ref = O.dense_attention(f64(q[0, h_full, rows]), f64(k[0, h_full, :S + te]), f64(v[0, h_full, :S + te]))
-    assert np.abs(out[0, h_full, rows.to(dev())].float().cpu().numpy() - ref).max() <= tol
+    assert np.abs(got(h_full, rows) - ref).max() <= tol
     # coreset expert: rows of the packed sequence vs dense oracle over the kept keys; dropped margins == their centre
     keep_q, drop_q = ops.coreset_select(q[0, h_low:h_low + 1], latent, group, geom.n_keep, tail_first=S, n_tail=T)
     keep_k = keep_q if model == "wan" else ops.coreset_select(k[0, h_low:h_low + 1], latent, group, geom.n_keep,
@@ -71,17 +68,43 @@ def _sampled_expert_checks(model, latent, tile, group, H, experts, dtype, seed, 
     pos = torch.randint(0, geom.S_low, (32,), generator=gen)
     qr = keep_q[0].cpu()[pos].long()
     ref = O.dense_attention(f64(q[0, h_low, qr]), f64(k[0, h_low, kk]), f64(v[0, h_low, kk]))
-    assert np.abs(out[0, h_low, qr.to(dev())].float().cpu().numpy() - ref).max() <= tol
+    assert np.abs(got(h_low, qr) - ref).max() <= tol
     centres = keep_q[0, :geom.G].long()
-    assert torch.equal(out[0, h_low][drop_q[0].long()], out[0, h_low][centres][:, None].expand(-1, drop_q.shape[-1], -1))
-    # sliding expert: sampled rows vs dense oracle over the tile's key list
-    q_rows, kv_rows, _ = geom.sta_tables(te)
+    sub = torch.randint(0, geom.G, (4096,), generator=gen).to(dev())
+    dr = drop_q[0][sub].long()
+    assert torch.equal(rows_of(h_low, dr.reshape(-1)).reshape(dr.shape + (128,)),
+                       rows_of(h_low, centres[sub])[:, None].expand(-1, dr.shape[-1], -1))
+    # sliding expert: sampled rows vs dense oracle over the tile's key list (token-order tables of the plain geometry)
+    plain = geom if geom.row_map is None else None
+    if plain is None:
+        from vorta_amd.routed import RoutedGeometry
+        plain = RoutedGeometry(geom.latent, geom.tile, geom.window, geom.group, geom.rate, dev())
+    q_rows, kv_rows, _ = plain.sta_tables(te)
     pos = torch.randint(0, S, (24,), generator=gen)
     for p in pos.tolist():
         keys = kv_rows[p // geom.tok].long()
         r = int(q_rows[p])
         ref = O.dense_attention(f64(q[0, h_sl, r:r + 1]), f64(k[0, h_sl, keys]), f64(v[0, h_sl, keys]))
-        assert np.abs(out[0, h_sl, r].float().cpu().numpy() - ref[0]).max() <= tol
+        assert np.abs(got(h_sl, [r]) - ref).max() <= tol
+    if T:  # text queries: valid ones attend every valid key (all three experts), padded ones are exactly zero
+        trow = torch.arange(S, S + te)
+        for h, keys in ((h_full, torch.arange(S + te)), (h_sl, torch.arange(S + te)),
+                        (h_low, kk.cpu())):
+            ref = O.dense_attention(f64(q[0, h, trow]), f64(k[0, h, keys]), f64(v[0, h, keys]))
+            assert np.abs(got(h, trow) - ref).max() <= tol, h
+            assert torch.all(rows_of(h, torch.arange(S + te, S + T, device=dev())) == 0)
+
+
+def _sampled_expert_checks(model, latent, tile, group, H, experts, dtype, seed, text=(0, 0), fp8=False):
+    """Routed op at full size, then `_verify_samples`."""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    S = latent[0] * latent[1] * latent[2]
+    T, te = text
+    q, k, v = (_rand((1, H, S + T, 128), seed + i, dtype) for i in range(3))
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
+    out = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, model=model, text_len=T,
+                           text_valid=te)
+    _verify_samples(model, geom, q, k, v, list(experts), lambda h, ids: out[0, h, ids], dtype, seed, text)
     return out
 
 
@@ -104,3 +127,66 @@ def test_reference_native_geometry_hunyuan_117f():
     experts = [0, 1, 2]
     _sampled_expert_checks("hunyuan", (30, 45, 80), (6, 9, 8), (2, 3, 2), 3, experts, torch.float16, seed=300,
                            text=(256, 77))
+
+
+def test_config2_hunyuan_129f_routed_fp16_as_benched():
+    """BASELINE configs[2] exactly as bench.py runs its first layer: H = 24, S = 118 800 + 256/96 text, fp16, the
+    'uniform' mix with bench.py's layer-0 head -> expert draw, the experts as ONE fused grid."""
+    import bench
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    cfg = bench.CONFIGS["hunyuan-129f"]
+    experts = [int(e) for e in bench.layer_experts(cfg, "uniform", 0)]
+    assert len(experts) == 24 and [experts.count(e) for e in range(3)] == [8, 8, 8]
+    dtype = torch.float16
+    S, T, te = 33 * 45 * 80, cfg["text"], cfg["text_valid"]
+    q, k, v = (_rand((1, 24, S + T, 128), 400 + i, dtype) for i in range(3))
+    geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], dev())
+    tl = ops.Timeline()
+    ops.set_timeline(tl)
+    try:
+        out = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, model="hunyuan", text_len=T,
+                               text_valid=te)
+    finally:
+        ops.set_timeline(None)
+    assert [r[1] for r in tl.records] == ["attn_fwd_multi_kernel<_Float16>"]  # the kernel the bench line reports
+    _verify_samples("hunyuan", geom, q, k, v, experts, lambda h, ids: out[0, h, ids], dtype, 401, (T, te))
+    # a second head of every expert (the last one routed to it)
+    last = [len(experts) - 1 - experts[::-1].index(e) for e in range(3)]
+    swapped = list(experts)
+    for e in range(3):
+        first = experts.index(e)
+        swapped[first], swapped[last[e]] = -1, e  # make `index(e)` find the last head of the expert
+    _verify_samples("hunyuan", geom, q, k, v, swapped, lambda h, ids: out[0, h, ids], dtype, 402, (T, te))
+
+
+def test_config3_one_rank_of_eight_at_full_size():
+    """BASELINE configs[3]: HunyuanVideo 129f under 8-way Ulysses.  What ONE rank holds after the exchange -- 3 heads x the
+    whole sequence, laid out as 8 received chunks of (3, S/8, D) + the replicated text -- is built here without any
+    communication (as test_zero_copy_ulysses_layout_on_one_gpu does at S = 384) and attended in place through `row_map`;
+    sampled rows of every expert are checked against the oracle."""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    from vorta_amd.ulysses import UlyssesLayout
+    dtype = torch.float16
+    H, P, rank = 24, 8, 5
+    latent, tile, group = (33, 45, 80), (11, 9, 8), (3, 3, 2)
+    S, T, te = 33 * 45 * 80, 256, 96
+    lay = UlyssesLayout(H, S, T, 128, P, rank, dev(), dtype)
+    Hl, Sl = lay.Hl, lay.Sl
+    assert (Hl, Sl) == (3, 14850)
+    q, k, v = (_rand((1, Hl, S + T, 128), 500 + i, dtype) for i in range(3))  # the rank's heads, token order
+    bufs = []
+    for x in (q, k, v):
+        b = lay.new_buffer().zero_()
+        for src in range(P):  # chunk received from rank `src`: its S/8 tokens of each of my 3 heads
+            b[src * Hl * Sl:(src + 1) * Hl * Sl] = x[0, :, src * Sl:(src + 1) * Sl].reshape(Hl * Sl, 128)
+        for i in range(Hl):
+            b[lay.rows_video + i * Sl: lay.rows_video + i * Sl + T] = x[0, i, S:]
+        bufs.append(b)
+    obuf = lay.new_buffer().zero_()
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev(), row_map=lay.row_map)
+    experts = [2, 0, 1]
+    routed_attention(*(lay.head_view(b) for b in bufs), HeadRouting.from_expert_ids(experts, dev()), geom,
+                     model="hunyuan", text_len=T, text_valid=te, out=lay.head_view(obuf))
+    ov, rm = lay.head_view(obuf), lay.row_map.long()
+    _verify_samples("hunyuan", geom, q, k, v, experts, lambda h, ids: ov[h][rm[ids]], dtype, 501, (T, te))

@@ -440,7 +440,7 @@ def _sp_pipe_worker(rank, world, port, ret):
     full, s_full = pipe(**args, generator=gen.manual_seed(4))
     SP_STATE.setup_sp_group(world)
     part, s_part = pipe(**args, generator=gen.manual_seed(4))
-    # every rank ends with the whole video (all_gather over frames, pipeline_hunyuan.py:453-454)
+    # every rank ends with the whole video (the reference all-gathers frame shards, pipeline_hunyuan.py:453-454)
     ret[rank] = (float(np.abs(part - full).max()), float(np.abs(full).max()),
                  all(torch.equal(a, b) for x, y in zip(s_full, s_part) for a, b in zip(x, y)))
     # no generator: the ranks agree on a seed (pipeline_hunyuan.py:76-83)
@@ -452,9 +452,62 @@ def _sp_pipe_worker(rank, world, port, ret):
     SP_STATE.cleanup()
 
 
+def _sp_pipe_odd_frames_worker(rank, world, port, ret):
+    """3 latent frames on 2 ranks: the reference's frame shard refuses this (pipeline_hunyuan.py:367-369 needs
+    frames % P == 0); the token-level shard cuts the 144 tokens into 2 x 72"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vorta.patch import _pipeline as P
+    from vorta.patch.pipeline_hunyuan import vorta_pipeline_call
+    from vorta.patch.utils import prepare_hunyuan_self_attn_kwargs
+    from vorta_amd.ulysses import SP_STATE
+
+    class Pipe(M.MiniHunyuanPipeline):
+        pass
+
+    P.register_pipeline_class(Pipe)
+    Pipe.__call__ = vorta_pipeline_call
+    lat = (3, 6, 8)
+    kw = prepare_hunyuan_self_attn_kwargs(dict(latent_shape=lat, window_size=WINDOW, tile_size=(1, 3, 4),
+                                               lowres_window_size=(3, 3, 2), lowres_reduction_rate=0.5), dev(), TAU)
+    model = _hy_model(seed=9)
+    pipe = Pipe(model, dev())
+    gen = torch.Generator(device=dev())
+    inp = _hy_pipe_inputs()
+    inp.update(height=lat[1], width=lat[2], num_frames=lat[0])
+    args = dict(inp, output_type="latent", return_dict=False, self_attention_kwargs=kw, return_routing_scores=True)
+    full, s_full = pipe(**args, generator=gen.manual_seed(4))
+    SP_STATE.setup_sp_group(world)
+    part, s_part = pipe(**args, generator=gen.manual_seed(4))
+    ret[rank] = (float((part - full).abs().max()), float(full.abs().max()), tuple(part.shape) == (1, 4) + lat,
+                 all(torch.equal(a, b) for x, y in zip(s_full, s_part) for a, b in zip(x, y)))
+    dist.barrier()
+    SP_STATE.cleanup()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_hunyuan_pipeline_token_shard_takes_any_frame_count(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_sp_pipe_odd_frames_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        for r in range(world):
+            err, mag, shape_ok, same_scores = ret[r]
+            assert err <= 2e-2 * max(mag, 1.0) and shape_ok and same_scores, (r, ret[r])
+
+
 def test_hunyuan_pipeline_under_sequence_parallel_rehearsal():
-    """2 ranks sharing the one GPU (gloo, host-staged transport): frame-sharded latents, global rotary table through
-    the stock rope, local attention mask from the stock forward, gathered video == single process."""
+    """2 ranks sharing the one GPU (gloo, host-staged transport): whole latents on every rank, token-sharded inside the
+    transformer, global rotary table and attention mask from the stock forward, video == single process."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:

@@ -54,7 +54,7 @@ def _comm_worker(rank, world, port, ret):
     SP_STATE.cleanup()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_collectives_match_reference_maps(world):
     ret = mp.Manager().dict()
     mp.spawn(_comm_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
@@ -68,10 +68,10 @@ def _tag(h, s, d):
 def _engine_worker(rank, world, port, ret):
     _init(rank, world, port)
     from vorta_amd.ulysses import UlyssesLayout, balanced_head_order
-    H, S, T, D, P = 8, 24 * world, 5, 4, world
+    H, S, T, D, P = max(8, 2 * world), 24 * world, 5, 4, world
     lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.float32)
     Hl, Sl = lay.Hl, lay.Sl
-    experts = [0, 2, 1, 1, 0, 2, 2, 1] if world == 2 else [0, 1, 2, 0, 1, 2, 1, 1]
+    experts = ([0, 2, 1, 1, 0, 2, 2, 1] if world == 2 else [0, 1, 2, 0, 1, 2, 1, 1]) * (H // 8)
     order = balanced_head_order(experts, [7.0, 2.0, 1.0], P)
     hs = torch.arange(H).view(H, 1, 1)
     ss = (torch.arange(Sl) + rank * Sl).view(1, Sl, 1)
@@ -134,7 +134,7 @@ def _engine_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_zero_copy_layout_round_trip(world):
     ret = mp.Manager().dict()
     mp.spawn(_engine_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
@@ -181,3 +181,80 @@ def test_balanced_head_order():
         assert max(loads) - min(loads) < 1e-9  # 8/8/8 splits evenly for P | 8
     with pytest.raises(AssertionError):
         balanced_head_order([0] * 12, cost, 8)
+
+
+# ------------------------------------------------------------------ token-level shard of the pipeline call
+class _PerTokenProcessor:
+    """stands in for the attention processors on the CPU: per-token arithmetic + this rank's rows of the GLOBAL rotary
+    table (narrowed exactly as the real processors narrow it, hunyuan.py:89-95) -- so a wrong shard, a local rotary
+    table or a missing gather all change the result"""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, image_rotary_emb=None):
+        from vorta_amd.ulysses import SP_STATE, shrink_dim
+        cos = shrink_dim(image_rotary_emb[0], dim=0) if SP_STATE.enabled else image_rotary_emb[0]
+        assert cos.shape[0] == hidden_states.shape[1]
+        assert attention_mask.shape[-1] == cos.shape[0] * (SP_STATE.sp_size if SP_STATE.enabled else 1) + encoder_hidden_states.shape[1]
+        pos = cos.float().mean(-1)[None, :, None].to(hidden_states.dtype)
+        return torch.tanh(hidden_states) + pos, torch.tanh(encoder_hidden_states)
+
+
+def _token_shard_worker(rank, world, port, ret):
+    _init(rank, world, port)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _mini_diffusers as M
+    from vorta_amd.patch import _engine as E
+    from vorta_amd.patch import _pipeline as P
+    from vorta_amd.patch.pipeline_hunyuan import sp_pipeline_call
+    from vorta_amd.ulysses import SP_STATE
+
+    class Pipe(M.MiniHunyuanPipeline):
+        pass
+
+    P.register_pipeline_class(Pipe)
+    Pipe.__call__ = sp_pipeline_call
+    torch.manual_seed(0)
+    model = M.MiniHunyuanTransformer()
+    E.context_of(model)
+    E.clear_hooks(model)
+    for block in list(model.transformer_blocks) + list(model.single_transformer_blocks):
+        E.set_processor(block.attn, _PerTokenProcessor())
+    E.install_sp_rope(model.rope, model)
+    E.install_token_shard(model, model.transformer_blocks[0], model.norm_out)
+    pipe = Pipe(model, "cpu")
+    frames, h, w = 33, 2, 4  # 33 latent frames (129-frame video): no rank count but 1, 3, 11, 33 divides them
+    g = torch.Generator().manual_seed(1)
+    T = 6
+    mask = torch.zeros((1, T))
+    mask[:, :4] = 1
+    args = dict(prompt_embeds=torch.randn((1, T, 24), generator=g), pooled_prompt_embeds=torch.randn((1, 16), generator=g),
+                prompt_attention_mask=mask, height=h, width=w, num_frames=frames, num_inference_steps=2,
+                output_type="latent", return_dict=False)
+    full = pipe(**args, generator=torch.Generator().manual_seed(7))[0]
+    SP_STATE.setup_sp_group(world)
+    part = pipe(**args, generator=torch.Generator().manual_seed(7))[0]
+    err = float((part - full).abs().max())
+    # without a generator the ranks agree on a seed (pipeline_hunyuan.py:76-83)
+    a = pipe(**args)[0]
+    gathered = [torch.empty_like(a) for _ in range(world)]
+    dist.all_gather(gathered, a)
+    refused = False
+    try:  # 33 * 2 * 4 = 264 tokens: 16 ranks would not divide them -- here: make the count odd
+        pipe(**dict(args, height=1, width=1, num_frames=world + 1), generator=torch.Generator().manual_seed(7))
+    except ValueError:
+        refused = True
+    ret[rank] = (err, float(full.abs().max()), tuple(part.shape), all(torch.equal(gathered[0], x) for x in gathered), refused)
+    dist.barrier()
+    SP_STATE.cleanup()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_pipeline_token_shard_33_frames(world):
+    """the pipeline call under sequence parallelism with a frame count no rank count divides: every rank keeps the whole
+    latent, the transformer cuts and re-joins its token sequence (vorta_amd/patch/_engine.py: install_token_shard)"""
+    ret = mp.Manager().dict()
+    mp.spawn(_token_shard_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        err, mag, shape, same_seed, refused = ret[r]
+        assert err <= 1e-5 * max(mag, 1.0), (r, err)
+        assert shape == (1, 4, 33, 2, 4) and same_seed and refused

@@ -425,7 +425,7 @@ def _g9_worker(rank, world, port, ret):
 def g9_ulysses():
     import torch.multiprocessing as mp
     out = {}
-    for world, port in ((2, 29611), (4, 29612)):
+    for world, port in ((2, 29611), (4, 29612), (8, 29613)):
         mgr = mp.Manager()
         ret = mgr.dict()
         mp.spawn(_g9_worker, args=(world, port, ret), nprocs=world, join=True)

@@ -114,6 +114,7 @@ class StepContext:
     descriptor_cache: Dict[Any, Any] = field(default_factory=dict)
     forwards: int = 0
     needs_tau: bool = True       # hard top-1 dispatch (Eval processors); False for the soft mixture (Train)
+    sp_token_shard: bool = False  # pipeline calls: the model gets the WHOLE latent and shards its token sequence itself
 
 
 class BoundProcessor:
@@ -252,8 +253,10 @@ def install_sp_rope(rope: nn.Module, model: nn.Module, frame_dim: int = 2) -> No
     only reads the SHAPE and device of its input, so a zero-stride stand-in of the global shape gives the same
     table without touching the module."""
 
+    ctx = context_of(model)
+
     def pre(module, args):
-        if not SP_STATE.enabled or not args:
+        if not SP_STATE.enabled or not args or ctx.sp_token_shard:  # token shard: the input already is the global latent
             return None
         x = args[0]
         shape = list(x.shape)
@@ -262,3 +265,43 @@ def install_sp_rope(rope: nn.Module, model: nn.Module, frame_dim: int = 2) -> No
         return (ghost,) + tuple(args[1:])
 
     add_hook(model, rope.register_forward_pre_hook(pre))
+
+
+def install_token_shard(model: nn.Module, first_block: nn.Module, gather_before: nn.Module) -> None:
+    """Token-level sequence-parallel shard INSIDE the transformer (replaces the frame shard of
+    pipeline_hunyuan.py:367-369 for pipeline calls).  The reference shards the latent FRAMES, which refuses every frame
+    count P does not divide (129 frames -> 33 latent frames: P = 2, 4, 8 all fail) -- while the token count divides
+    (S = 118 800 = 8 x 14 850).  In token mode (`ctx.sp_token_shard`, set by the pipeline call) every rank keeps the
+    whole latent; the stock forward embeds it, builds the global rotary table and the global attention mask as in the
+    single-process case; the token sequence is cut to this rank's contiguous chunk [r S/P, (r+1) S/P) at the first
+    block's input and concatenated again (all-gather along tokens) in front of `gather_before` (the output norm).  The
+    blocks in between see exactly what they see under a frame shard: a contiguous S/P chunk + the replicated text."""
+    from ..ulysses import all_gather
+    ctx = context_of(model)
+
+    def _swap(args, kwargs, fn):
+        if "hidden_states" in kwargs:
+            kwargs = dict(kwargs, hidden_states=fn(kwargs["hidden_states"]))
+            return args, kwargs
+        return (fn(args[0]),) + tuple(args[1:]), kwargs
+
+    def cut(module, args, kwargs):
+        if not (SP_STATE.enabled and ctx.sp_token_shard):
+            return None
+        P, r = SP_STATE.sp_size, SP_STATE.group_local_rank
+
+        def f(x):
+            S = x.shape[1]
+            if S % P:
+                raise ValueError(f"{S} video tokens do not divide over {P} sequence-parallel ranks")
+            n = S // P
+            return x[:, r * n:(r + 1) * n]
+        return _swap(args, kwargs, f)
+
+    def join(module, args, kwargs):
+        if not (SP_STATE.enabled and ctx.sp_token_shard):
+            return None
+        return _swap(args, kwargs, lambda x: all_gather(x.contiguous(), dim=1))
+
+    add_hook(model, first_block.register_forward_pre_hook(cut, with_kwargs=True))
+    add_hook(model, gather_before.register_forward_pre_hook(join, with_kwargs=True))

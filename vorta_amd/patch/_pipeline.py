@@ -4,9 +4,9 @@ The reference re-states the whole diffusers pipeline `__call__` to change four t
 sequence-parallel group (pipeline_hunyuan.py:76-83), a frame shard of the initial latents per rank (:366-369),
 `self_attention_kwargs` / `return_routing_scores` passed to every transformer forward (:410-423) and an all-gather
 of the latents before decoding (:450-461).  Here the stock `__call__` runs unchanged: the two keyword values reach the
-transformer through its step context (vorta_amd/patch/_engine.py), the latent shard is applied by wrapping
-`prepare_latents` for the duration of the call, and under sequence parallelism the stock call stops at
-`output_type="latent"` so the gather + decode happen here.
+transformer through its step context (vorta_amd/patch/_engine.py); under sequence parallelism the latent stays whole
+on every rank and the transformer shards its TOKEN sequence itself (_engine.install_token_shard: any frame count
+works, where the reference's frame shard refuses 33 latent frames on 2, 4 or 8 ranks), so the stock call decodes too.
 """
 from __future__ import annotations
 
@@ -15,7 +15,7 @@ from typing import Any, Callable, Dict, Optional
 
 import torch
 
-from ..ulysses import SP_STATE, all_gather
+from ..ulysses import SP_STATE, all_gather  # noqa: F401  (all_gather: seed agreement)
 from . import _engine as E
 from .outputs import VideoPipelineOutput
 
@@ -74,33 +74,20 @@ def run(pipe, args, kwargs, *, decode: Callable, self_attention_kwargs: Optional
         ctx.default_return_routing_scores = bool(return_routing_scores)
         ctx.collected, ctx.last_token = [], None
         ctx.step_token = lambda: getattr(pipe, "_current_timestep", None)
-    stock_prepare = None
-    if sp:
-        stock_prepare = pipe.prepare_latents
-        P, r = SP_STATE.sp_size, SP_STATE.group_local_rank
-
-        def prepare_shard(*a, **k):
-            latents = stock_prepare(*a, **k)  # (b, c, frames, h, w): contiguous frame chunk per rank (:367-369)
-            if latents.shape[2] % P:
-                raise ValueError(f"{latents.shape[2]} latent frames do not divide over {P} sequence-parallel ranks")
-            n = latents.shape[2] // P
-            return latents[:, :, r * n:(r + 1) * n]
-
-        pipe.prepare_latents = prepare_shard
-        params["output_type"] = "latent"
+    # Sequence parallelism: every rank carries the whole latent through the stock loop (same seed -> same latents, the
+    # scheduler step is deterministic and tiny) and the transformer shards its TOKEN sequence itself
+    # (_engine.install_token_shard).  The reference shards latent frames here (pipeline_hunyuan.py:367-369) and gathers
+    # them before decoding (:457-458), which refuses 33 latent frames (129-frame video) on 2, 4 or 8 ranks; the token
+    # count of every BASELINE configuration divides by 8.
+    ctx.sp_token_shard = bool(sp)
     params["return_dict"] = False
     try:
         out = orig(pipe, **params)
     finally:
-        if stock_prepare is not None:
-            del pipe.prepare_latents  # the instance attribute; the class method shows again
+        ctx.sp_token_shard = False
         if routed:
             ctx.default_kwargs, ctx.default_return_routing_scores, ctx.step_token = None, False, None
     video = out[0]
-    if sp:
-        latents = all_gather(video, dim=2)
-        video = latents if output_type == "latent" else decode(pipe, latents, output_type)
-        pipe.maybe_free_model_hooks()
     scores = ctx.collected if (routed and return_routing_scores) else None
     if routed:
         ctx.collected, ctx.last_token = [], None

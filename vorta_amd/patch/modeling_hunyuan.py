@@ -91,6 +91,7 @@ def apply_vorta_transformer(model, train_router: bool = False, checkpoint_file: 
     E.install_forward_protocol(model, ctx, _complete_kwargs)
     E.install_timestep_capture(model.time_text_embed.timestep_embedder, model, ctx)
     E.install_sp_rope(model.rope, model)
+    E.install_token_shard(model, model.transformer_blocks[0], model.norm_out)
     if checkpoint_file is not None:
         load_router_checkpoint(checkpoint_file, model)
     return model
@@ -104,4 +105,5 @@ def apply_sp_flashattn_transformer(model):
     for block in _blocks(model):
         E.set_processor(block.attn, HunyuanVideoFlashAttnProcessor())
     E.install_sp_rope(model.rope, model)
+    E.install_token_shard(model, model.transformer_blocks[0], model.norm_out)
     return model

@@ -49,6 +49,7 @@ def apply_vorta_transformer(model, train_router: bool = False, checkpoint_file: 
     E.install_forward_protocol(model, ctx)
     E.install_timestep_capture(model.condition_embedder.time_embedder, model, ctx)
     E.install_sp_rope(model.rope, model)
+    E.install_token_shard(model, model.blocks[0], model.norm_out)
     if checkpoint_file is not None:
         load_router_checkpoint(checkpoint_file, model)
     return model
@@ -62,4 +63,5 @@ def apply_sp_flashattn_transformer(model):
         E.set_processor(block.attn1, WanAttnProcessor2_0())
         E.set_processor(block.attn2, WanAttnProcessor2_0())
     E.install_sp_rope(model.rope, model)
+    E.install_token_shard(model, model.blocks[0], model.norm_out)
     return model

@@ -104,6 +104,10 @@ class UlyssesLayout:
         self.rows_total = self.rows_video + self.Hl * self.Sl  # text region keeps the head stride Sl
         self.device, self.dtype, self.group = torch.device(device), dtype, group
         self.row_map = make_row_map(S, T, P, self.Hl, device)
+        # loopback: every pass of the exchange that runs on THIS rank's GPU (staging gathers, own-chunk copies, text
+        # rows, the attention on the received layout, the un-permute) with the transfers themselves left out -- one
+        # rank's compute at P > 1 on a single GPU (bench.py --emulate-rank); remote chunks keep what the buffers held
+        self.loopback = False
 
     def new_buffer(self) -> torch.Tensor:
         return torch.empty((self.rows_total, self.D), dtype=self.dtype, device=self.device)
@@ -119,13 +123,13 @@ class UlyssesLayout:
     def _staged(self) -> bool:
         # rehearsal transport: gloo cannot send/recv device memory, so stage through the host.  Only used when
         # the process group is gloo but the tensors live on a GPU (tests / 1-GPU rehearsals); RCCL is direct.
-        return self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
+        return (not self.loopback) and self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
 
     def _start(self, p2p):
         """Enqueue one group of point-to-point operations; returns a handle for `_finish`.
         p2p: list of ("send"|"recv", tensor, peer).  RCCL: asynchronous (the transfer runs on the communicator's
         stream, ordered after everything already enqueued on the current stream); gloo rehearsal: completes here."""
-        if not p2p:
+        if not p2p or self.loopback:
             return None
         if not self._staged():
             ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._peer(j), self.group) for k, t, j in p2p]
@@ -154,6 +158,11 @@ class UlyssesLayout:
         (vorta/ulysses/utils.py:47,79) -- on (P*n, D) row blocks whose P equal chunks are contiguous on both sides
         (chunk j of the input goes to rank j, chunk j of the output comes from rank j; the own chunk is copied by the
         collective).  Asynchronous under RCCL; returns a handle for `_finish`."""
+        if self.loopback:  # the own chunk is what the collective would have copied locally
+            n = pairs[0][0].shape[0] // self.P
+            for i, o in pairs:
+                o[self.rank * n:(self.rank + 1) * n].copy_(i[self.rank * n:(self.rank + 1) * n])
+            return None
         if not self._staged():
             return ("works", [dist.all_to_all_single(o, i, group=self.group, async_op=True) for i, o in pairs])
         for i, o in pairs:
@@ -281,7 +290,9 @@ class UlyssesLayout:
         if out_text is not None and self.T:
             local = torch.stack([buf[self.rows_video + i * Sl: self.rows_video + i * Sl + self.T] for i in range(Hl)])
             parts = [torch.empty_like(local) for _ in range(self.P)]
-            if self.P > 1 and self._staged():
+            if self.loopback:
+                parts = [local] * self.P
+            elif self.P > 1 and self._staged():
                 hp = [torch.empty(local.shape, dtype=local.dtype) for _ in range(self.P)]
                 dist.all_gather(hp, local.cpu(), group=self.group)
                 parts = [h.to(local.device) for h in hp]
@@ -299,7 +310,7 @@ class UlyssesRoutedAttention:
 
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
                  rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
-                 sliding_block_rows: int = 0, groups: int = 1):
+                 sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False):
         from ..routed import HeadRouting, RoutedGeometry
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
@@ -307,6 +318,7 @@ class UlyssesRoutedAttention:
         self.concurrent, self.fused, self.sliding_block_rows = concurrent, fused, sliding_block_rows
         self.te = cfg["text_valid"]
         self.lay = UlyssesLayout(H, S, T, 128, P, rank, device, dtype, group)
+        self.lay.loopback = loopback
         self.geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"],
                                    torch.device(device), row_map=self.lay.row_map)
         costs = [cost_of_expert["full"], cost_of_expert["lowres"], cost_of_expert["sliding"]]
@@ -325,6 +337,9 @@ class UlyssesRoutedAttention:
             texts = [torch.randn((H, T, 128), generator=tg, device=device, dtype=dtype) for _ in range(3)] if T else None
             self.sets.append((shards, texts))
         self.bufs = [self.lay.new_buffer() for _ in range(4)]  # q, k, v, o
+        if loopback:  # the chunks no peer will fill: finite values of the same distribution
+            for b in self.bufs[:3]:
+                b.normal_()
         self.out_shard = torch.empty((H, self.lay.Sl, 128), dtype=dtype, device=device)
         self.out_text = torch.empty((H, T, 128), dtype=dtype, device=device) if T else None
         if self.te or cfg["model"] == "wan":
