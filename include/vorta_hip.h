@@ -108,6 +108,15 @@ typedef struct vorta_attn_args {
                       key block ahead, K/V tiles by LDS-DMA, softmax folded into the score MFMA
                       (attn_fwd_pipe_kernel<T,NW,KVTAB>) */
   int32_t reserved;
+  /* Optional query groups of DIFFERENT lengths (ABI 2): one row per workgroup, device int32 [n_q_blocks][3] =
+   * (group g, first position, end position) with end - first <= block_rows (which must then be given, 128 or 256).
+   * q_group_len is ignored; group g still reads the key list kv_rows + g*kv_rows_stride_g.  Used by the sliding-tile
+   * expert: query tiles whose clamped windows coincide (sliding_attn_flex.py:118-120 clamps the window centre, so the
+   * two outermost tiles of a dimension see the same keys) are merged into one group, and the group is cut into full
+   * workgroups instead of every 792-token tile ending in a 24-row one. */
+  const int32_t* q_block_table;
+  int32_t n_q_blocks;
+  int32_t reserved2;
 } vorta_attn_args;
 
 int vorta_attn_fwd(const vorta_attn_args* args, void* hip_stream);

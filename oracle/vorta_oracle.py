@@ -514,7 +514,8 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
                     q_group_len: int = 0, q_valid: Optional[int] = None, kv_rows: Optional[np.ndarray] = None,
                     kv_row_offset: int = 0, dup_rows: Optional[np.ndarray] = None, n_dup_pos: int = 0, n_splits: int = 1,
                     p_bias: float = 5.0, defer: float = 3.0, round_p: bool = True,
-                    ambiguous: Optional[np.ndarray] = None) -> None:
+                    ambiguous: Optional[np.ndarray] = None,
+                    q_group_bounds: Optional[Sequence[Tuple[int, int]]] = None) -> None:
     """include/vorta_hip.h vorta_attn_fwd_fp8 for ONE head: q,k,v (rows,D) decoded e4m3 values, `out` (rows,D) is
     written in place (rows named by q_rows / dup_rows only).  kv_rows: (n_kv,) or (n_groups, n_kv).
     `ambiguous` (rows,) float, optional: per output row, the total normalised probability of the keys whose e4m3
@@ -523,11 +524,12 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
     restatement by at most 2^-3 * that * (|v| + |o|) on top of its accumulation error."""
     q_valid = n_q if q_valid is None else q_valid
     glen = q_group_len if q_group_len > 0 else n_q
-    n_groups = -(-n_q // glen)
+    if q_group_bounds is None:  # equal groups; else [start, end) of every group (vorta_attn_args.q_block_table)
+        q_group_bounds = [(g * glen, min((g + 1) * glen, n_q)) for g in range(-(-n_q // glen))]
     nblk = -(-n_kv // 64)
     bps = -(-nblk // n_splits)
-    for g in range(n_groups):
-        pos = np.arange(g * glen, min((g + 1) * glen, n_q))
+    for g, (g0, g1) in enumerate(q_group_bounds):
+        pos = np.arange(g0, g1)
         rows = q_rows[pos] if q_rows is not None else q_row_offset + pos
         if kv_rows is None:
             kr = kv_row_offset + np.arange(n_kv)

@@ -319,3 +319,32 @@ def test_integration_md_stub_runs():
     want = torch.empty_like(q)
     ops.attn_fwd(q[0], k[0], v[0], want[0], n_q=300, n_kv=280, q_valid=280)
     assert torch.equal(got, want) and torch.all(got[:, :, 280:] == 0)
+
+
+@pytest.mark.parametrize("block_rows", [128, 256])
+def test_query_groups_of_different_lengths(block_rows):
+    """vorta_attn_args.q_block_table: one (group, first, end) row per workgroup; groups of 700, 40 and 300 positions, each
+    with its own key list"""
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(11)
+    H, rows, n_kv = 2, 1400, 333
+    x = [rng.standard_normal((H, rows, 128)) for _ in range(3)]
+    q, k, v = (to_dev(a, dtype) for a in x)
+    bounds = [(0, 700), (700, 740), (740, 1040)]
+    q_rows = rng.permutation(rows)[:1040].astype(np.int32)
+    kv_rows = np.stack([rng.permutation(rows)[:n_kv] for _ in bounds]).astype(np.int32)
+    table = np.array([(g, p, min(p + block_rows, b)) for g, (a, b) in enumerate(bounds) for p in range(a, b, block_rows)],
+                     dtype=np.int32)
+    out = torch.zeros((H, rows, 128), dtype=dtype, device=dev())
+    ops.attn_fwd(q, k, v, out, n_q=1040, n_kv=n_kv, q_rows=torch.as_tensor(q_rows, device=dev()),
+                 kv_rows=torch.as_tensor(kv_rows, device=dev()), kv_rows_stride_g=n_kv, block_rows=block_rows,
+                 q_block_table=torch.as_tensor(table, device=dev()), n_key_lists=3)
+    torch.cuda.synchronize()
+    r = [rounded(a, dtype) for a in x]
+    ref = np.zeros((H, rows, 128))
+    for g, (a, b) in enumerate(bounds):
+        ref[:, q_rows[a:b]] = O.dense_attention(r[0][:, q_rows[a:b]], r[1][:, kv_rows[g]], r[2][:, kv_rows[g]])
+    check(out, ref, dtype)
+    with pytest.raises(ValueError):
+        ops.attn_fwd(q, k, v, out, n_q=1040, n_kv=n_kv, q_block_table=torch.as_tensor(table, device=dev()), n_key_lists=3)

@@ -564,3 +564,47 @@ def test_mixed_block_sizes_in_one_layer():
     mixed = routed_attention(q, k, v, routing, geom, sliding_block_rows=128, **kw)
     serial = routed_attention(q, k, v, routing, geom, fused=False, **kw)
     assert torch.equal(fused, mixed) and torch.equal(fused, serial)
+
+
+def test_sliding_launch_merges_tiles_with_equal_key_lists():
+    """Hunyuan-129f: 150 query tiles, 24 distinct key lists (the clamped window is the same for the two outermost tiles
+    of a dimension and for all three tiles of the time axis): the merged launch has 2-7 % padded rows where one group
+    per tile has 29 %; same result as the per-tile launch up to the rounding of different reference points."""
+    from vorta_amd.routed import RoutedGeometry
+    geom = RoutedGeometry(HY_LATENT, HY_TILE, WINDOW, HY_GROUP, 0.5, dev())
+    q_rows, kv_rows, n_kv = geom.sta_tables(96)
+    qm, lists, n_kv2, table, n_lists = geom.sta_launch_tables(96, 256)
+    assert n_lists == 24 and lists.shape == (24, n_kv) and n_kv2 == n_kv and qm.shape == q_rows.shape
+    t = table.cpu().numpy()
+    Sf = 33 * 45 * 80
+    assert t[0, 1] == 0 and t[-1, 2] == Sf and (t[1:, 1] == t[:-1, 2]).all()          # the blocks tile [0, S)
+    assert ((t[:, 2] - t[:, 1]) <= 256).all() and (np.diff(t[:, 0]) >= 0).all()
+    sizes = sorted(set(np.bincount(t[:, 0], weights=t[:, 2] - t[:, 1]).astype(int) // geom.tok))
+    assert sizes == [3, 6, 12]
+    assert len(t) * 256 / Sf < 1.05 and (Sf // geom.tok) * 4 * 256 / Sf > 1.29      # padded rows: < 5 % vs 29 %
+    assert torch.equal(qm.sort().values, q_rows.sort().values)                       # still a permutation of the tokens
+    # every position still sees its tile's keys
+    tile_of = {int(r): i // geom.tok for i, r in enumerate(q_rows.cpu().tolist())}
+    qmc, lc, kc = qm.cpu(), lists.cpu(), kv_rows.cpu()
+    for g, p0, _ in t[:: max(1, len(t) // 40)]:
+        assert torch.equal(lc[g], kc[tile_of[int(qmc[p0])]])
+
+
+@pytest.mark.parametrize("model", ["hunyuan", "wan"])
+def test_merged_sliding_launch_matches_per_tile_launch(model, monkeypatch):
+    import vorta_amd.routed as R
+    from vorta_amd.routed import HeadRouting, routed_attention
+    dtype = torch.float16
+    torch.manual_seed(51)
+    H = 3
+    T, te = (16, 11) if model == "hunyuan" else (0, 0)
+    q, k, v = (torch.randn((1, H, S + T, 128), device=dev()).to(dtype) for _ in range(3))
+    route = HeadRouting.from_expert_ids([2, 2, 2], dev())
+    a = routed_attention(q, k, v, route, _geom(), model=model, text_len=T, text_valid=te)
+    monkeypatch.setattr(R, "STA_MERGE", False)
+    b = routed_attention(q, k, v, route, _geom(), model=model, text_len=T, text_valid=te)
+    assert (a.float() - b.float()).abs().max().item() <= 2.5e-3
+    gi = O.group_info(LATENT, GROUP, 0.5)
+    ref = O.routed_attention(q.double().cpu().numpy(), k.double().cpu().numpy(), v.double().cpu().numpy(), np.array([2, 2, 2]),
+                             model=model, latent=LATENT, tile=TILE, window=WINDOW, gi=gi, t_text=T, t_eff=te)
+    check(a[0], ref[0], dtype)

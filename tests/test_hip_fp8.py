@@ -224,11 +224,13 @@ def _emulate_routed(q16, k16, v16, f8, experts, geom, model, T, te, scale=None):
                               q_valid=geom.S_low + te, q_rows=kq[y], kv_rows=kk[y], dup_rows=dq[y], n_dup_pos=geom.G,
                               ambiguous=amb[h])
     if hs[2]:
-        q_rows, kv_rows, n_kv = geom.sta_tables(te)
-        qr, kr = q_rows.cpu().numpy(), kv_rows.cpu().numpy()
+        q_rows, kv_rows, n_kv, table, n_lists = geom.sta_launch_tables(te, 256)  # query tiles of equal key lists merged
+        qr, kr, tb = q_rows.cpu().numpy(), kv_rows.cpu().numpy(), table.cpu().numpy()
+        bounds = [(int(tb[tb[:, 0] == g, 1].min()), int(tb[tb[:, 0] == g, 2].max())) for g in range(n_lists)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == S and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
         for h in hs[2]:
-            O.fp8_attn_launch(q8[h], k8[h], v8[h], out[h], vd[h], n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=qr,
-                              kv_rows=kr, ambiguous=amb[h])
+            O.fp8_attn_launch(q8[h], k8[h], v8[h], out[h], vd[h], n_q=S, n_kv=n_kv, q_rows=qr, kv_rows=kr,
+                              q_group_bounds=bounds, ambiguous=amb[h])
             if T:
                 O.fp8_attn_launch(q8[h], k8[h], v8[h], out[h], vd[h], n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te,
                                   n_splits=_auto_splits(len(hs[2]), T, S + te), ambiguous=amb[h])

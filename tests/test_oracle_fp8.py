@@ -109,3 +109,18 @@ def test_probability_rounding_is_bounded_and_reference_points_move():
     z = q[:32] @ k.T
     assert (mw <= z.max(1) + 1e-12).all() and (mw >= z.max(1) - 3.0 - 1e-12).all()
     assert (mw > (q[:32] @ k[:64].T).max(1)).any()
+
+
+def test_launch_emulator_groups_of_different_lengths():
+    rng = np.random.default_rng(5)
+    rows = 300
+    q, k, v = _operands(rng, rows, 0.6), _operands(rng, rows, 0.6), _operands(rng, rows, 2.0)
+    bounds = [(0, 70), (70, 100), (100, 230)]
+    kv_rows = np.stack([rng.permutation(rows)[:90] for _ in bounds])
+    q_rows = rng.permutation(rows)[:230]
+    out = np.zeros((rows, 128))
+    O.fp8_attn_launch(q, k, v, out, np.ones(128), n_q=230, n_kv=90, q_rows=q_rows, kv_rows=kv_rows, q_group_bounds=bounds,
+                      round_p=False)
+    for g, (a, b) in enumerate(bounds):
+        ref = O._softmax_attend(q[q_rows[a:b]], k[kv_rows[g]], v[kv_rows[g]], scale=np.log(2.0))
+        assert np.abs(out[q_rows[a:b]] - ref).max() < 1e-12

@@ -36,6 +36,7 @@ class AttnArgs(C.Structure):
         ("ws_o", _vp), ("ws_ml", _vp),
         ("n_kv_dev", _vp), ("q_valid_dev", _vp),
         ("variant", _i32), ("reserved", _i32),
+        ("q_block_table", _vp), ("n_q_blocks", _i32), ("reserved2", _i32),
     ]
 
 

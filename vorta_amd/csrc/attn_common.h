@@ -34,7 +34,20 @@ struct Params {
   float* ws_o; float* ws_ml;
   int xcd_remap;
   float defer_log2;  // online-softmax rescale is skipped while the row max grows by <= this (log2 units)
+  const int32_t* q_block_table;  // optional [n_groups * blocks_per_group][3] = (group, first position, end position)
 };
+
+// query block qb of a launch -> its group (key list), first position and the end of its positions
+__device__ __forceinline__ void q_block_of(const Params& p, int qb, int rows_per_block, int& grp, int& p0, int& pend) {
+  if (p.q_block_table) {
+    const int32_t* t = p.q_block_table + 3 * qb;
+    grp = t[0]; p0 = t[1]; pend = t[2];
+  } else {
+    grp = qb / p.blocks_per_group;
+    p0 = grp * p.q_group_len + (qb - grp * p.blocks_per_group) * rows_per_block;
+    pend = min((grp + 1) * p.q_group_len, p.n_q);
+  }
+}
 
 constexpr int MAX_SEGMENTS = 4;  // launches fused into one grid (vorta_attn_fwd_batch)
 struct MultiParams {

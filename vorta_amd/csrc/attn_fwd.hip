@@ -49,10 +49,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
   const int y = rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
-  const int grp = qb / p.blocks_per_group;
-  const int bi = qb - grp * p.blocks_per_group;
-  const int p0 = grp * p.q_group_len + bi * QB;
-  const int pend = min((grp + 1) * p.q_group_len, p.n_q);
+  int grp, p0, pend;
+  q_block_of(p, qb, QB, grp, p0, pend);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -314,10 +312,8 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   const int y = rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
-  const int grp = qb / p.blocks_per_group;
-  const int bi = qb - grp * p.blocks_per_group;
-  const int p0 = grp * p.q_group_len + bi * QB;
-  const int pend = min((grp + 1) * p.q_group_len, p.n_q);
+  int grp, p0, pend;
+  q_block_of(p, qb, QB, grp, p0, pend);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -878,6 +874,12 @@ int vorta_attn::fill_params(const vorta_attn_args* a, Params& p, int& block_rows
     block_rows = (pad256 * 100 > pad128 * 106) ? 128 : 256;
   }
   p.blocks_per_group = (p.q_group_len + block_rows - 1) / block_rows;
+  p.q_block_table = a->q_block_table;
+  if (a->q_block_table) {  // one table row per workgroup; the rows are the caller's contract (device memory)
+    if (a->n_q_blocks <= 0 || (a->block_rows != 128 && a->block_rows != 256)) return VORTA_EINVAL;
+    p.n_groups = a->n_q_blocks;
+    p.blocks_per_group = 1;
+  }
   const int nblk = (p.n_kv + KVB - 1) / KVB;
   p.blocks_per_split = (nblk + p.n_splits - 1) / p.n_splits;
   return VORTA_OK;

@@ -81,10 +81,8 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   const int y = rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
-  const int grp = qb / p.blocks_per_group;
-  const int bi = qb - grp * p.blocks_per_group;
-  const int p0 = grp * p.q_group_len + bi * QB;
-  const int pend = min((grp + 1) * p.q_group_len, p.n_q);
+  int grp, p0, pend;
+  q_block_of(p, qb, QB, grp, p0, pend);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;

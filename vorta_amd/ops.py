@@ -93,7 +93,8 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
                scale: Optional[float] = None, block_rows: int = 0, n_splits: int = 1,
                n_kv_dev: Optional[torch.Tensor] = None, q_valid_dev: Optional[torch.Tensor] = None,
                variant: int = 0, tag: str = "", flops: float = 0.0,
-               v_descale: Optional[torch.Tensor] = None, fp8_opts: Optional[dict] = None):
+               v_descale: Optional[torch.Tensor] = None, fp8_opts: Optional[dict] = None,
+               q_block_table: Optional[torch.Tensor] = None, n_key_lists: int = 0):
     """Fill a vorta_attn_args; returns (args, workspace tensors to keep alive until the launch is enqueued).
     q,k,v of dtype uint8 = e4m3 operands from `fp8_quantize_qkv` (then `v_descale` is required and `out` is 16-bit):
     the args carry `_ext`, the vorta_attn_fp8_ext of the fp8 entry points."""
@@ -131,6 +132,12 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     # the kernels trust the tables: check every extent that can be checked on the host (the row VALUES live on the
     # device and are the caller's contract, vorta_hip.h)
     n_groups = 1 if q_group_len <= 0 else -(-n_q // q_group_len)
+    if q_block_table is not None:
+        # query groups of different lengths: one (group, first, end) row per workgroup (vorta_hip.h); n_key_lists = the
+        # number of groups the rows refer to (extent check of kv_rows below)
+        if q_block_table.dim() != 2 or q_block_table.shape[1] != 3 or block_rows not in (128, 256) or n_key_lists <= 0:
+            raise ValueError("q_block_table must be (n_blocks, 3) int32 with an explicit block_rows (128 / 256) and n_key_lists")
+        n_groups = n_key_lists
     if head_list is not None and head_list.numel() < n_heads:
         raise ValueError(f"head_list holds {head_list.numel()} heads, n_heads = {n_heads}")
     if q_rows is not None and (q_rows.dim() not in (1, 2) or q_rows.shape[-1] < n_q
@@ -178,6 +185,8 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
                     raise ValueError("fp8 attention addresses K/V rows with 32-bit offsets: a head must fit a 2 GiB window")
                 a.variant = 1
     a.reserved = NO_XCD_REMAP
+    if q_block_table is not None:
+        a.q_block_table, a.n_q_blocks = _ptr(q_block_table), q_block_table.shape[0]
     ws = None
     if n_splits > 1:
         so, sm = C.c_uint64(), C.c_uint64()

@@ -88,11 +88,36 @@ class RoutedGeometry:
         self.tok = self.tile[0] * self.tile[1] * self.tile[2]
 
     def sta_tables(self, t_eff: int):
+        """per query tile: (q_rows (S,), kv_rows (n_tiles, n_kv), n_kv) -- vorta_sta_build_tables"""
         if t_eff not in self._sta:
             q_rows, kv_rows = ops.sta_build_tables(self.latent, self.tile, self.window, t_eff, self.device,
                                                    row_map=self.row_map)
             self._sta[t_eff] = (q_rows, kv_rows, kv_rows.shape[1])
         return self._sta[t_eff]
+
+    def sta_launch_tables(self, t_eff: int, block_rows: int = 256):
+        """The sliding-tile launch with query tiles of EQUAL key lists merged into one group.  The reference clamps the
+        window centre (sliding_attn_flex.py:118-120), so the two outermost tiles of a dimension -- all tiles, when the
+        dimension has no more tiles than the window -- see the same keys: Hunyuan-129f has 150 query tiles and 24
+        distinct key lists.  Merged, a group is 3, 6 or 12 tiles long and is cut into full 256-row workgroups (2-7 %
+        padding) where every single 792-token tile ended in a 24-row one (29 %).
+        Returns (q_rows (S,), kv_lists (n_lists, n_kv), n_kv, block_table (n_blocks, 3) int32, n_lists)."""
+        key = ("merged", t_eff, block_rows)
+        if key not in self._sta:
+            q_rows, kv_rows, n_kv = self.sta_tables(t_eff)
+            n_tiles = kv_rows.shape[0]
+            lists, inverse, counts = torch.unique(kv_rows, dim=0, return_inverse=True, return_counts=True)
+            order = torch.argsort(inverse, stable=True)  # tiles grouped by key list, tile-major order kept inside a group
+            q_m = q_rows.view(n_tiles, self.tok)[order].reshape(-1).contiguous()
+            rows = []
+            start = 0
+            for g, c in enumerate(counts.cpu().tolist()):  # built once per geometry / prompt
+                end = start + c * self.tok
+                rows += [(g, p, min(p + block_rows, end)) for p in range(start, end, block_rows)]
+                start = end
+            table = torch.tensor(rows, dtype=torch.int32).to(self.device)
+            self._sta[key] = (q_m, lists.contiguous(), n_kv, table, lists.shape[0])
+        return self._sta[key]
 
 
 def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
@@ -103,6 +128,9 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
     return max(1, min(want, kv_blocks // 8 if kv_blocks >= 16 else 1, 256))
 
 
+# merge query tiles of equal key lists into one group of the sliding-tile launch (RoutedGeometry.sta_launch_tables);
+# VORTA_STA_MERGE=0: one group per tile, as round 1 (A/B)
+STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
 _SIDE_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
 
 
@@ -184,10 +212,16 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     # ---- expert 2: sliding-tile attention (hunyuan.py:459-507 / wan.py:272-294) ----
     def expert_sliding():
         sl = routing.slot_args(2, H)
-        q_rows, kv_rows, n_kv = geom.sta_tables(te)
-        calls = [dict(base, out=o_e[2], n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
-                      kv_rows_stride_g=n_kv, tag="sliding", flops=nheads(2) * 4.0 * D * S * n_kv,
-                      block_rows=sliding_block_rows, **sl)]
+        if STA_MERGE and sliding_block_rows in (128, 256):
+            q_rows, kv_rows, n_kv, table, n_lists = geom.sta_launch_tables(te, sliding_block_rows)
+            calls = [dict(base, out=o_e[2], n_q=S, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows, kv_rows_stride_g=n_kv,
+                          q_block_table=table, n_key_lists=n_lists, tag="sliding", flops=nheads(2) * 4.0 * D * S * n_kv,
+                          block_rows=sliding_block_rows, **sl)]
+        else:
+            q_rows, kv_rows, n_kv = geom.sta_tables(te)
+            calls = [dict(base, out=o_e[2], n_q=S, q_group_len=geom.tok, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows,
+                          kv_rows_stride_g=n_kv, tag="sliding", flops=nheads(2) * 4.0 * D * S * n_kv,
+                          block_rows=sliding_block_rows, **sl)]
         if T > 0:
             # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
             txt = dict(base, out=o_e[2], n_q=T, q_valid=te, n_kv=S + te, n_splits=_auto_splits(sl["n_heads"], T, S + te),
