@@ -81,35 +81,85 @@ def algorithmic_flops(cfg, experts):
     return n[0] * f_full + n[1] * f_low + n[2] * f_sl, dict(full=f_full, lowres=f_low, sliding=f_sl)
 
 
-def cpu_baseline(cfg, mix, step_flops):
-    """The CPU oracle (oracle/vorta_oracle.py, numpy) timed on this host on a bounded sample of the same
-    workload: one query slab per expert at the full key length, extrapolated by algorithmic FLOPs."""
+def cpu_baseline(cfg, layer_ids):
+    """SURVEY.md §8(d) / BASELINE.md §3: the CPU restatement of the path timed on this host -- torch-CPU SDPA for the
+    contractions, the oracle's index code (oracle/vorta_oracle.py: group tables + cosine ranking, tile-major order,
+    clamped tile windows) for the coreset selection / pooling / unpooling and the sliding-tile key lists -- ONE head per
+    expert at the full sequence length of the configuration (a bounded sample: seconds), extrapolated by the number of
+    heads per expert, layers and forwards per step.  The reference's own Python cannot travel to the GPU box."""
+    import torch.nn.functional as F
     from oracle import vorta_oracle as O
+    cores = min(os.cpu_count() or 1, 64)  # beyond one socket's cores SDPA on one head slows down
+    torch.set_num_threads(cores)
+    cpu_model = "unknown"
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
-    te, D = cfg["text_valid"], 128
-    rng = np.random.default_rng(0)
-    k = rng.standard_normal((1, 1, S + te, D)).astype(np.float32)
-    v = rng.standard_normal((1, 1, S + te, D)).astype(np.float32)
-    rows = 2048
-    q = rng.standard_normal((1, 1, rows, D)).astype(np.float32)
-    t0 = time.perf_counter()
-    done_flops, n = 0.0, 0
-    while time.perf_counter() - t0 < 12.0:
-        O._softmax_attend(q, k, v, dtype=np.float32)
-        done_flops += 4.0 * rows * (S + te) * D
-        n += 1
-    dt = time.perf_counter() - t0
-    rate = done_flops / dt  # FLOP/s of the oracle's attention core on this host
-    step_s = step_flops / rate
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    latent, tile, window, group = cfg["latent"], cfg["tile"], cfg["window"], cfg["group"]
+    S = latent[0] * latent[1] * latent[2]
+    hy = cfg["model"] == "hunyuan"
+    T, te = (cfg["text"], cfg["text_valid"]) if hy else (0, 0)
+    dt = torch.bfloat16
+    gen = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn((1, 1, S + T, 128), generator=gen).to(dt) for _ in range(3))
+    sdpa = lambda a, b, c: F.scaled_dot_product_attention(a, b, c)
+    times = {}
+    with torch.no_grad():
+        sdpa(q[:, :, :256], k[:, :, :256], v[:, :, :256])  # warm the dispatcher
+        # expert 0: dense on the valid keys (hunyuan.py:167-176)
+        t0 = time.perf_counter()
+        sdpa(q[:, :, :S + te], k[:, :, :S + te], v[:, :, :S + te])
+        times["full"] = time.perf_counter() - t0
+        # expert 1: rank, pool, dense on the packed sequence, unpool (coreset_select.py:68-185)
+        t0 = time.perf_counter()
+        gi = O.group_info(latent, group, cfg["rate"])
+        qv, kv = q[:, :, :S].float().numpy(), k[:, :, :S].float().numpy()
+        mq = O.coreset_match(qv, gi)
+        mk = O.coreset_match(kv, gi) if hy else mq
+        keep_q, drop_q = O.coreset_row_lists(gi, *mq)
+        keep_k, _ = O.coreset_row_lists(gi, *mk)
+        iq = torch.cat([torch.from_numpy(keep_q[0, 0]), torch.arange(S, S + te)])
+        ik = torch.cat([torch.from_numpy(keep_k[0, 0]), torch.arange(S, S + te)])
+        o_low = sdpa(q[:, :, iq], k[:, :, ik], v[:, :, ik])
+        out = torch.zeros_like(q)
+        out[:, :, iq] = o_low
+        centres = o_low[:, :, :gi.n_groups]
+        out[:, :, torch.from_numpy(drop_q[0, 0]).reshape(-1)] = centres.repeat_interleave(drop_q.shape[-1], dim=2)
+        times["lowres"] = time.perf_counter() - t0
+        # expert 2: tile-major order, per query tile the keys of its clamped window (+ valid text), text queries see all
+        t0 = time.perf_counter()
+        perm = torch.from_numpy(O.tile_major_order(latent, tile))
+        sees = O.sta_window_tiles(latent, tile, window)
+        tok = tile[0] * tile[1] * tile[2]
+        text_keys = torch.arange(S, S + te)
+        n_tiles = S // tok
+        sample = sorted(set(int(x) for x in np.linspace(0, n_tiles - 1, min(n_tiles, 16))))  # bounded: 16 evenly spaced tiles
+        for ti in sample:
+            keys = torch.cat([perm[j * tok:(j + 1) * tok] for j in np.nonzero(sees[ti])[0]] + [text_keys])
+            rows = perm[ti * tok:(ti + 1) * tok]
+            out[:, :, rows] = sdpa(q[:, :, rows], k[:, :, keys], v[:, :, keys])
+        t_tiles = (time.perf_counter() - t0) * n_tiles / len(sample)
+        t0 = time.perf_counter()
+        if te:
+            out[:, :, S:S + te] = sdpa(q[:, :, S:S + te], k[:, :, :S + te], v[:, :, :S + te])
+        times["sliding"] = t_tiles + (time.perf_counter() - t0)
+    layer_s = 0.0
+    for e in layer_ids:
+        n = [int((e == i).sum()) for i in range(3)]
+        layer_s += n[0] * times["full"] + n[1] * times["lowres"] + n[2] * times["sliding"]
+    step_s = layer_s * cfg["fwd_per_step"]
     tokens = S * cfg["fwd_per_step"]
-    return {"value": tokens / step_s, "unit": "video_tokens/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} x dense oracle attention of {rows} query rows against all {S + te} keys (1 head, fp32 numpy), "
-                      f"{dt:.1f}s = {rate / 1e9:.0f} GFLOP/s, extrapolated by algorithmic FLOPs to the whole routed step"}
+    return {"value": tokens / step_s, "unit": "video_tokens/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
+            "dtype": "bf16", "step_s_extrapolated": round(step_s, 1),
+            "seconds_per_head": {k_: round(v_, 3) for k_, v_ in times.items()},
+            "sample": f"one head per expert at the full sequence (S = {S}, text {T}/{te}): torch-CPU SDPA (bf16, "
+                      f"{cores} threads) + the oracle's index code for coreset ranking / pooling / unpooling and the "
+                      f"sliding-tile key lists ({len(sample)} of its {n_tiles} query tiles timed); extrapolated x heads per expert x {cfg['layers']} layers x "
+                      f"{cfg['fwd_per_step']} forward(s) per step"}
 
 
 def main():
@@ -266,10 +316,10 @@ def main():
     # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself);
     # only valid for the workload they were collected on
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
         if pmc["workload"] == f"{args.config} {args.mix} {cfg['dtype']}" and world == 1:
             roofline["traffic"] = round(pmc["kernels"][dom_sym]["hbm_bytes_per_launch"])
-            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.json)"
+            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_hbm_traffic.json)"
     except Exception:
         pass
     per_tag = {f"{tag}: {sym}": {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
@@ -323,7 +373,7 @@ def main():
             roofline["library_gemm_error"] = f"{type(exc).__name__}: {exc}"[:200]
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not emu:
-            res["cpu_baseline"] = cpu_baseline(cfg, args.mix, step_flops)
+            res["cpu_baseline"] = cpu_baseline(cfg, layer_ids)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -13,6 +13,8 @@ typedef __attribute__((ext_vector_type(2))) int pi2;
 template <int NV, int KIND>
 __device__ __forceinline__ void valu(float& x0, float& x1, float& x2, float& x3) {
   pi4 ldsv; pi2 ldsv2;
+  typedef __attribute__((ext_vector_type(2))) float pf2;
+  pf2 xp = {x0, x1};
   const int ldsa = (threadIdx.x & 63) * 16;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -25,6 +27,12 @@ __device__ __forceinline__ void valu(float& x0, float& x1, float& x2, float& x3)
     else if (KIND == 5) asm volatile("ds_read_b128 %0, %1" : "=v"(ldsv) : "v"(ldsa));
     else if (KIND == 6) asm volatile("ds_read_b64_tr_b8 %0, %1" : "=v"(ldsv2) : "v"(ldsa));
     else if (KIND == 7) asm volatile("v_cvt_pk_fp8_f32 %0, %1, %1 op_sel:[0,0,1]" : "+v"(x) : "v"(x1));
+    else if (KIND == 8) asm volatile("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(x) : "v"(x1));
+    else if (KIND == 9) asm volatile("v_dot2_f32_bf16 %0, %1, %1, %0" : "+v"(x) : "v"(x1));
+    else if (KIND == 10) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(xp) : "v"(xp));
+    else if (KIND == 11) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "+v"(x) : "v"(x1));
+    else if (KIND == 12) asm volatile("v_cvt_pk_f16_f32 %0, %1, %1" : "+v"(x) : "v"(x1));
+    else if (KIND == 13) asm volatile("v_dot2c_f32_bf16 %0, %1, %1" : "+v"(x) : "v"(x1));
   }
   if (KIND == 5 || KIND == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
@@ -128,11 +136,13 @@ int main() {
   hipMalloc(&d, 16);
 #define CROW(MODE, KIND, NAME) chip_nv<MODE, 0, KIND>(d, NAME); chip_nv<MODE, 4, KIND>(d, NAME); chip_nv<MODE, 8, KIND>(d, NAME); \
   chip_nv<MODE, 12, KIND>(d, NAME); chip_nv<MODE, 16, KIND>(d, NAME); chip_nv<MODE, 24, KIND>(d, NAME);
-  CROW(0, 3, "cvt_pk_fp8")
-  CROW(0, 7, "cvt_pk_fp8 hi")
-  CROW(0, 4, "v_max3_i32")
-  CROW(0, 5, "ds_read_b128")
-  CROW(0, 6, "ds_read_tr8")
+  CROW(1, 8, "v_dot2_f32_f16")
+  CROW(1, 9, "v_dot2_f32_bf16")
+  CROW(1, 13, "v_dot2c_f32_bf16")
+  CROW(1, 10, "v_pk_add_f32")
+  CROW(1, 11, "v_cvt_pk_bf16_f32")
+  CROW(1, 12, "v_cvt_pk_f16_f32")
+  CROW(1, 0, "v_add_f32")
   hipDeviceSynchronize();
   return 0;
   for (int threads : {256, 512, 1024}) { chip<0>(d, 256, threads); chip<1>(d, 256, threads); }

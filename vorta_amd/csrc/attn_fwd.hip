@@ -434,6 +434,23 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, b_[i_]);   \
     dst_ = half_max(mx_);                                                         \
   }
+  // The loop only asks two things of the NEXT block's row max: "is it above `defer` (> 0)?" and, if so, its value.  Both
+  // are answered by a signed-integer max over the float bit patterns (order-preserving for non-negative floats, any
+  // negative result reads as "not above"; -inf of masked keys is a negative integer, there are no NaNs): v_max3_i32
+  // needs no canonicalising v_max x,x of the MFMA outputs, and two chains halve the dependent latency.
+#define ROW_MAX_POS(dst_, a_, b_)                                                  \
+  {                                                                               \
+    int m0_ = max(max(__float_as_int(a_[0]), __float_as_int(a_[1])), __float_as_int(a_[2])); \
+    int m1_ = max(max(__float_as_int(b_[0]), __float_as_int(b_[1])), __float_as_int(b_[2])); \
+    _Pragma("unroll") for (int i_ = 3; i_ < 15; i_ += 2) {                        \
+      m0_ = max(max(m0_, __float_as_int(a_[i_])), __float_as_int(a_[i_ + 1]));    \
+      m1_ = max(max(m1_, __float_as_int(b_[i_])), __float_as_int(b_[i_ + 1]));    \
+    }                                                                             \
+    m0_ = max(max(m0_, __float_as_int(a_[15])), __float_as_int(b_[15]));          \
+    m0_ = max(m0_, m1_);                                                          \
+    auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m0_, false, false); \
+    dst_ = __int_as_float(max((int)r_[0], (int)r_[1]));                           \
+  }
   // the same with the fragments of the first KPRE k-steps already in registers (read at the top of the step,
   // their LDS latency hides under the row-max phase)
 #define QK_PRE(d0_, d1_, par_)                                                    \
@@ -575,7 +592,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
           o[dt_] = MF<T>::mfma(vf_, pb_[kg_], o[dt_]);                            \
         }                                                                         \
       }                                                                           \
-      ROW_MAX(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */   \
+      ROW_MAX_POS(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */ \
       SCHED_RECIPE()                                                              \
     }                                                                             \
     STEP_SYNC()                                                                   \
@@ -643,6 +660,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #undef QK
 #undef QK_PRE
 #undef ROW_MAX
+#undef ROW_MAX_POS
 #undef RAISE_REF
 #undef STEP
 #undef STAGE_DMA

@@ -106,17 +106,31 @@ class RoutedGeometry:
         if key not in self._sta:
             q_rows, kv_rows, n_kv = self.sta_tables(t_eff)
             n_tiles = kv_rows.shape[0]
-            lists, inverse, counts = torch.unique(kv_rows, dim=0, return_inverse=True, return_counts=True)
-            order = torch.argsort(inverse, stable=True)  # tiles grouped by key list, tile-major order kept inside a group
-            q_m = q_rows.view(n_tiles, self.tok)[order].reshape(-1).contiguous()
-            rows = []
-            start = 0
-            for g, c in enumerate(counts.cpu().tolist()):  # built once per geometry / prompt
+            # a tile's key list is fixed by the first tile of its clamped window in every dimension
+            # (csrc/sta_tables.hip: centre = min(max(t, half), n - 1 - half), first = max(centre - half, 0)): host integers
+            nt = [l // t for l, t in zip(self.latent, self.tile)]
+            first = []
+            for d in range(3):
+                half = self.window[d] // 2
+                first.append([max(min(max(t, half), nt[d] - 1 - half) - half, 0) for t in range(nt[d])])
+            ids = [(first[0][a], first[1][b], first[2][c]) for a in range(nt[0]) for b in range(nt[1]) for c in range(nt[2])]
+            order = sorted(range(n_tiles), key=lambda i: ids[i])  # stable: tile-major order kept inside a group
+            groups = []  # (first tile of the group, number of tiles)
+            for i in order:
+                if groups and ids[groups[-1][0]] == ids[i]:
+                    groups[-1][1] += 1
+                else:
+                    groups.append([i, 1])
+            order_t = torch.tensor(order, device=self.device)
+            q_m = q_rows.view(n_tiles, self.tok)[order_t].reshape(-1).contiguous()
+            lists = kv_rows[torch.tensor([g[0] for g in groups], device=self.device)].contiguous()
+            rows, start = [], 0
+            for g, (_, c) in enumerate(groups):
                 end = start + c * self.tok
                 rows += [(g, p, min(p + block_rows, end)) for p in range(start, end, block_rows)]
                 start = end
             table = torch.tensor(rows, dtype=torch.int32).to(self.device)
-            self._sta[key] = (q_m, lists.contiguous(), n_kv, table, lists.shape[0])
+            self._sta[key] = (q_m, lists, n_kv, table, len(groups))
         return self._sta[key]
 
 
