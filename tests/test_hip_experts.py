@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import vorta_oracle as O
-from _util import ATOL_SAME, check, dev, pad128, rounded, to_dev
+from _util import ATOL_SAME, check, dev, pad128, rel_fro, rounded, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -608,3 +608,72 @@ def test_merged_sliding_launch_matches_per_tile_launch(model, monkeypatch):
     ref = O.routed_attention(q.double().cpu().numpy(), k.double().cpu().numpy(), v.double().cpu().numpy(), np.array([2, 2, 2]),
                              model=model, latent=LATENT, tile=TILE, window=WINDOW, gi=gi, t_text=T, t_eff=te)
     check(a[0], ref[0], dtype)
+
+
+@pytest.mark.parametrize("model", ["hunyuan", "wan"])
+def test_routed_golden_fp16_hard_gate(golden, model):
+    """test_routed_golden with fp16 inputs (11-bit mantissa: the coreset similarities are not reordered against the
+    reference's fp32 ranking) and the HARD tolerances on every head, coreset heads included."""
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, routed_attention
+    g = golden("g8_eval_calls")
+    dtype = torch.float16
+    geom = _geom()
+    experts = O.route_heads(g["routing_score"], 0.3)
+    route = HeadRouting.from_expert_ids(experts, dev())
+    t, te = (int(x) for x in g["text"])
+    gi = O.group_info(LATENT, GROUP, 0.5)
+    if model == "hunyuan":
+        q, k, v = (to_dev(pad128(g[n]), dtype) for n in ("hy_q", "hy_k", "hy_v"))
+        out = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=t, text_valid=te, scale=0.25)
+        gold = np.concatenate([g["hy_out"][0], g["hy_eout"][0]], axis=1)
+        # the kernel's rankings ARE the reference's (fp32, unrounded inputs): index for index
+        hl = torch.tensor([h for h, e in enumerate(experts) if e == 1], dtype=torch.int32, device=dev())
+        for x, name in ((q, "hy_q"), (k, "hy_k")):
+            keep, _ = ops.coreset_select(x[0], LATENT, GROUP, geom.n_keep, head_list=hl, want_drop=False)
+            kept, _ = O.coreset_match(g[name][:, hl.cpu().numpy(), :S].astype(np.float64), gi)
+            want, _ = O.coreset_row_lists(gi, kept, kept[..., :0])
+            assert np.array_equal(keep.cpu().numpy()[:, :geom.S_low], want[0]), name
+        for h in range(len(experts)):
+            check(out[0, h, :, :16], gold[h], dtype, gold=True)
+        o = out[0].float().cpu().numpy()
+        assert np.all(o[:, S + te:] == 0) and np.all(o[..., 16:] == 0)
+    else:
+        q, k, v = (to_dev(pad128(g[n]), dtype) for n in ("wan_q", "wan_k", "wan_v"))
+        out = routed_attention(q, k, v, route, geom, model="wan", scale=0.25)
+        o = out[0].float().cpu().numpy()[..., :16]
+        y = o.transpose(1, 0, 2).reshape(1, S, 96) @ g["wan_w_to_out_0_weight"].astype(np.float64).T + g["wan_w_to_out_0_bias"]
+        gold = g["wan_out_tau3"]
+        err = np.abs(y - gold)
+        assert err.max() <= 3e-2 and rel_fro(y, gold) <= 1e-2, (err.max(), rel_fro(y, gold))
+
+
+@pytest.mark.parametrize("mix", ["uniform", "sparse-heavy"])
+def test_routed_vs_native_attention_operator_psnr(mix):
+    """what the ROUTING costs -- the routed op against native (all-dense) attention on the same q,k,v,
+    per routing mix (the stand-in, at the operator, for scripts/hunyuan/inference.py:103-121's `--native_attention`
+    comparison).  On white-noise q,k,v the three experts see no structure to exploit, so this is the floor of the
+    method's approximation, not a property of the kernels: the numbers are printed (and recorded in DESIGN.md); the
+    assertions pin that dense-routed heads are the native result and that the sparse experts are approximations."""
+    import bench
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, dense_attention, routed_attention
+    dtype = torch.bfloat16
+    latent, tile, group = (12, 24, 16), (3, 6, 4), (3, 3, 2)  # 4 x 4 x 4 tiles: a 3-tile window is a real restriction
+    Sx, H = 12 * 24 * 16, 12
+    gen = torch.Generator(device=dev()).manual_seed(77)
+    q, k, v = (torch.randn((1, H, Sx, 128), generator=gen, device=dev(), dtype=dtype) for _ in range(3))
+    cfg = dict(heads=H)
+    experts = [int(e) for e in bench.layer_experts(cfg, mix, 0)]
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
+    out = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, model="wan")
+    ref = dense_attention(q, k, v)
+    psnr = lambda a, b: 10 * math.log10(((b.float().max() - b.float().min()).item() ** 2) / max(((a.float() - b.float()) ** 2).mean().item(), 1e-30))
+    per = {}
+    for e, name in enumerate(("full", "coreset", "sliding-tile")):
+        hs = [h for h in range(H) if experts[h] == e]
+        if hs:
+            per[name] = psnr(out[0, hs], ref[0, hs])
+    print(f"routed vs native attention, white-noise inputs, mix {mix} {[experts.count(e) for e in range(3)]}: "
+          f"whole op {psnr(out, ref):.2f} dB; per expert {dict((n, round(p, 2)) for n, p in per.items())}")
+    assert per["full"] > 100.0  # the same kernel on the same heads
+    assert 5.0 < per["coreset"] < 60.0 and 5.0 < per["sliding-tile"] < 60.0
