@@ -238,8 +238,8 @@ def main():
 
     emu = args.emulate_rank
     if emu:
-        if world != 1 or fp8:
-            raise SystemExit("--emulate-rank runs on one GPU, 16-bit")
+        if world != 1:
+            raise SystemExit("--emulate-rank runs on one GPU")
         P = emu
     if P == 1:
         geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], dev)
@@ -262,13 +262,11 @@ def main():
                                      concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
                                      fp8=fp8, fp8_operands=f8buf)
     else:
-        if fp8:
-            raise SystemExit("--dtype fp8 with --gpus N>1 is not wired yet")
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
                                             concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
-                                            groups=args.sp_groups if (H // P) % args.sp_groups == 0 else 1,
-                                            loopback=bool(emu))
+                                            groups=1 if fp8 else (args.sp_groups if (H // P) % args.sp_groups == 0 else 1),
+                                            loopback=bool(emu), fp8=fp8)
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):

@@ -58,3 +58,11 @@ def test_bench_emulated_rank_and_fp8_lines():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["dtype"] == "fp8" and j["roofline"]["peak"] == 5000.0 and j["roofline"]["kernel"].startswith("attn8_")
+
+
+def test_bench_emulated_rank_fp8_line():
+    r = subprocess.run([sys.executable, "bench.py", "--config", "tiny", "--steps", "1", "--warmup", "1", "--emulate-rank", "2",
+                        "--dtype", "fp8", "--no-gemm-ceiling"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["emulated_rank_of"] == 2 and j["dtype"] == "fp8" and j["roofline"]["kernel"].startswith("attn8_")

@@ -190,3 +190,40 @@ def test_config3_one_rank_of_eight_at_full_size():
                      model="hunyuan", text_len=T, text_valid=te, out=lay.head_view(obuf))
     ov, rm = lay.head_view(obuf), lay.row_map.long()
     _verify_samples("hunyuan", geom, q, k, v, experts, lambda h, ids: ov[h][rm[ids]], dtype, 501, (T, te))
+
+
+def test_config4_one_rank_of_eight_fp8_at_full_size():
+    """BASELINE configs[4]: Wan-2.1 14B 81x720x1280, Ulysses over 8 GPUs, fp8 contractions.  One rank's share -- 5 of the
+    40 heads over the whole S = 75 600 sequence in the zero-copy receive layout, converted to e4m3 ONCE per buffer
+    (UlyssesLayout.fp8_views) -- against the bf16 kernels on the same layout: gate (ii) of tests/test_hip_fp8.py."""
+    import math
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    from vorta_amd.ulysses import UlyssesLayout
+    dtype = torch.bfloat16
+    H, P, rank = 40, 8, 3
+    latent, tile, group = (21, 45, 80), (7, 9, 8), (3, 3, 2)
+    S = 21 * 45 * 80
+    lay = UlyssesLayout(H, S, 0, 128, P, rank, dev(), dtype)
+    Hl, Sl = lay.Hl, lay.Sl
+    assert (Hl, Sl) == (5, 9450)
+    bufs = []
+    for i in range(3):
+        b = lay.new_buffer()
+        b[:lay.rows_video] = _rand((lay.rows_video, 128), 600 + i, dtype)
+        bufs.append(b)
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev(), row_map=lay.row_map)
+    route = HeadRouting.from_expert_ids([0, 1, 2, 1, 2], dev())
+    views = [lay.head_view(b) for b in bufs]
+    ref, out = lay.new_buffer(), lay.new_buffer()
+    routed_attention(*views, route, geom, model="wan", out=lay.head_view(ref), fp8=False)
+    q8, k8, v8, vd, f8 = lay.fp8_views(bufs)
+    assert f8.q.shape == (1, lay.rows_total, 128) and vd.shape == (Hl, 128)
+    routed_attention(*views, route, geom, model="wan", out=lay.head_view(out), fp8=False, fp8_views=(q8, k8, v8, vd))
+    torch.cuda.synchronize()
+    rm = lay.row_map.long()
+    a, b = lay.head_view(out)[:, rm[:S]].float(), lay.head_view(ref)[:, rm[:S]].float()  # (Hl, S, D) in token order
+    assert not torch.isnan(a).any()
+    for i in range(Hl):
+        mse = ((a[i] - b[i]) ** 2).mean().item()
+        psnr = 10 * math.log10((b[i].max() - b[i].min()).item() ** 2 / mse)
+        assert psnr >= 40.0, (i, psnr)

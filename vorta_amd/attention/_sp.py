@@ -86,13 +86,25 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     local = [experts[h] for h in order[me * lay.Hl:(me + 1) * lay.Hl]]
     rm = lay.row_map
 
+    from .. import routed as _routed
+    fp8 = _routed.DEFAULT_FP8 and groups == 1  # the e4m3 path converts the receive buffers after the whole exchange
+
     def attend(g0, g1, gi):
+        if fp8:
+            q8, k8, v8, vd, _ = lay.fp8_views(bufs)
+            if dense_only:
+                ops.attn_fwd(q8[g0:g1], k8[g0:g1], v8[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
+                             q_rows=rm[:S + T], kv_rows=rm[:S + te], v_descale=vd[g0:g1])
+                return
+            views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
+        else:
+            views = None
         if dense_only:
             ops.attn_fwd(qv[g0:g1], kv[g0:g1], vv[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
                          q_rows=rm[:S + T], kv_rows=rm[:S + te])
         else:
             routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], _routing(tuple(local[g0:g1]), q.device), geom,
-                             model=model, text_len=T, text_valid=te, out=ov[g0:g1])
+                             model=model, text_len=T, text_valid=te, out=ov[g0:g1], fp8=False, fp8_views=views)
 
     # the received heads are written straight into the (1, N, H, D) result the output projection reads
     buf = torch.empty((1, N, H, D), dtype=q.dtype, device=q.device)

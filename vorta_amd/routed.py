@@ -145,6 +145,17 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
 # merge query tiles of equal key lists into one group of the sliding-tile launch (RoutedGeometry.sta_launch_tables);
 # VORTA_STA_MERGE=0: one group per tile, as round 1 (A/B)
 STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
+# process-wide default of `routed_attention(fp8=None)`: the processors of vorta.attention call it that way, so the
+# unchanged inference scripts pick the e4m3 path up from the environment or from `set_attention_precision("fp8")`
+DEFAULT_FP8 = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower() == "fp8"
+
+
+def set_attention_precision(precision: str) -> None:
+    """"native" (the dtype of q,k,v: the reference's behaviour) or "fp8" (e4m3 contractions, 16-bit output)"""
+    global DEFAULT_FP8
+    if precision not in ("native", "fp8"):
+        raise ValueError("precision is 'native' or 'fp8'")
+    DEFAULT_FP8 = precision == "fp8"
 _SIDE_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
 
 
@@ -159,8 +170,10 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                      geom: RoutedGeometry, *, model: str, text_len: int = 0, text_valid: int = 0,
                      out: Optional[torch.Tensor] = None, scale: Optional[float] = None,
                      concurrent: bool = False, fused: bool = True, sliding_block_rows: int = 0,
-                     expert_outs: Optional[Sequence[torch.Tensor]] = None, fp8: bool = False,
-                     fp8_operands: Optional[ops.Fp8Operands] = None) -> torch.Tensor:
+                     expert_outs: Optional[Sequence[torch.Tensor]] = None, fp8: Optional[bool] = None,
+                     fp8_operands: Optional[ops.Fp8Operands] = None,
+                     fp8_views: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None
+                     ) -> torch.Tensor:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
     hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383.
@@ -173,7 +186,10 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     expert_outs: one output tensor per expert instead of `out` (heads may then appear under several experts).
     fp8=True: both contractions in e4m3 (BASELINE.json configs[4]; no reference counterpart): q,k,v are converted once
     per call (vorta_fp8_quantize_qkv, or `fp8_operands` to reuse buffers) and every expert launch reads the e4m3
-    copies; the coreset ranking still reads the 16-bit q/k (coreset_select.py:98-105 ranks in the input dtype)."""
+    copies; the coreset ranking still reads the 16-bit q/k (coreset_select.py:98-105 ranks in the input dtype).
+    fp8=None follows the process-wide default (`set_attention_precision`, VORTA_ATTENTION_PRECISION=fp8).
+    fp8_views = (q8, k8, v8, v_descale): e4m3 views with the geometry of q,k,v that were converted elsewhere (the
+    sequence-parallel path converts the receive buffers once, vorta_amd/ulysses/engine.py)."""
     if q.dim() == 4 and q.shape[0] != 1:
         # hunyuan.py:168 asserts batch 1; Wan's CFG runs two batch-1 forwards (pipeline_wan.py:322-344)
         raise AssertionError(f"Batch size {q.shape[0]} is not supported by routed_attention.")
@@ -199,7 +215,11 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         return routing.counts_host[e] if routing.counts_host is not None else 0
 
     base = dict(q=q3, k=k3, v=v3, scale=scale)
-    if fp8:
+    if fp8 is None:
+        fp8 = DEFAULT_FP8
+    if fp8_views is not None:
+        base = dict(q=fp8_views[0], k=fp8_views[1], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
+    elif fp8:
         f8 = ops.fp8_quantize_qkv(q3, k3, v3, scale, out=fp8_operands)
         base = dict(q=f8.q, k=f8.k, v=f8.v, scale=scale, v_descale=f8.v_descale)
 

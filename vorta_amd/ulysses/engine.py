@@ -110,7 +110,20 @@ class UlyssesLayout:
         self.loopback = False
 
     def new_buffer(self) -> torch.Tensor:
-        return torch.empty((self.rows_total, self.D), dtype=self.dtype, device=self.device)
+        # zeros: the rows between a head's T text rows and the next head's are never written, and the fp8 conversion
+        # takes the abs-max of the whole buffer
+        return torch.zeros((self.rows_total, self.D), dtype=self.dtype, device=self.device)
+
+    def fp8_views(self, bufs: Sequence[torch.Tensor], scale: Optional[float] = None, out=None):
+        """e4m3 copies of the q, k, v receive buffers for the fp8 attention kernels: ONE conversion of each whole buffer
+        (the head views overlap, so converting per head would redo it Hl times), hence one q/k scale pair and one
+        per-channel v scale for all local heads.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
+        from .. import ops
+        x = [b.view(1, self.rows_total, self.D) for b in bufs[:3]]
+        f8 = ops.fp8_quantize_qkv(*x, scale, out=out)
+        shape, stride = (self.Hl, self.rows_total - (self.Hl - 1) * self.Sl, self.D), (self.Sl * self.D, self.D, 1)
+        hv = lambda t: t[0].as_strided(shape, stride)
+        return hv(f8.q), hv(f8.k), hv(f8.v), f8.v_descale.expand(self.Hl, self.D).contiguous(), f8
 
     def head_view(self, buf: torch.Tensor) -> torch.Tensor:
         """(Hl, rows, D) overlapping view: head slot i starts i*Sl rows into the buffer."""
@@ -310,8 +323,11 @@ class UlyssesRoutedAttention:
 
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
                  rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
-                 sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False):
+                 sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False, fp8: bool = False):
         from ..routed import HeadRouting, RoutedGeometry
+        if fp8 and groups != 1:
+            raise ValueError("fp8 converts the receive buffers after the whole exchange: one slot group")
+        self.fp8, self.f8 = fp8, None
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
         self.cfg, self.P, self.rank = cfg, P, rank
@@ -351,9 +367,13 @@ class UlyssesRoutedAttention:
         q, k, v, o = (self.lay.head_view(b) for b in self.bufs)
 
         def attend(g0, g1, gi):
+            views = None
+            if self.fp8:
+                q8, k8, v8, vd, self.f8 = self.lay.fp8_views(self.bufs, out=self.f8)
+                views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
             routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], self.geom, model=self.cfg["model"],
                              text_len=self.cfg["text"], text_valid=self.te, out=o[g0:g1], concurrent=self.concurrent,
-                             fused=self.fused, sliding_block_rows=self.sliding_block_rows)
+                             fused=self.fused, sliding_block_rows=self.sliding_block_rows, fp8=False, fp8_views=views)
 
         exchange_and_attend(self.lay, shards, self.bufs, self.orders[l], texts, self.groups, attend, self.out_shard,
                             self.out_text)
