@@ -6,6 +6,7 @@
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 __device__ __forceinline__ unsigned hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
 
@@ -13,6 +14,7 @@ template <int MODE, int RANDOM>
 __global__ __launch_bounds__(512) void k(long long* out, int iters) {
   i32x8 a[4], b[4];
   bf16x8 ha[4], hb[4];
+  f16x8 fa[4], fb[4];
   for (int s = 0; s < 4; ++s)
     for (int i = 0; i < 8; ++i) {
       unsigned r0 = hash(threadIdx.x * 64 + s * 16 + i), r1 = hash(r0 + 12345);
@@ -21,6 +23,8 @@ __global__ __launch_bounds__(512) void k(long long* out, int iters) {
       b[s][i] = RANDOM ? (int)(r1 & 0xe7e7e7e7u) : 0x38383838;
       ha[s][i] = RANDOM ? (__bf16)(((int)(r0 & 0xffff) - 32768) * (1.0f / 8192)) : (__bf16)1.0f;
       hb[s][i] = RANDOM ? (__bf16)(((int)(r1 & 0xffff) - 32768) * (1.0f / 8192)) : (__bf16)1.0f;
+      fa[s][i] = RANDOM ? (_Float16)(((int)(r0 & 0xffff) - 32768) * (1.0f / 8192)) : (_Float16)1.0f;
+      fb[s][i] = RANDOM ? (_Float16)(((int)(r1 & 0xffff) - 32768) * (1.0f / 8192)) : (_Float16)1.0f;
     }
   f32x16 c0, c1;
   for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
@@ -31,9 +35,12 @@ __global__ __launch_bounds__(512) void k(long long* out, int iters) {
       if (MODE == 0) {
         c0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[u], b[u], c0, 0, 0, 0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[u], a[(u + 1) & 3], c1, 0, 0, 0, 0, 0, 0);
-      } else {
+      } else if (MODE == 1) {
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[u], hb[u], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hb[u], ha[(u + 1) & 3], c1, 0, 0, 0);
+      } else {
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u], fb[u], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[u], fa[(u + 1) & 3], c1, 0, 0, 0);
       }
     }
     if (RANDOM && (it & 63) == 63) {  // keep the accumulators finite
@@ -63,7 +70,7 @@ void run(long long* d, int grid, int threads) {
   const double flop_per = MODE == 0 ? 2.0 * 32 * 32 * 64 : 2.0 * 32 * 32 * 16;
   const double flops = (double)grid * (threads / 64) * iters * 8 * flop_per;
   const double clk = threads == 256 ? (double)h[0] / (ms * 1e6) : 0.0;
-  printf("%-5s %-8s grid %4d x %3d: %8.3f ms  %6.0f TFLOP/s  clock %.2f GHz\n", MODE == 0 ? "fp8" : "bf16",
+  printf("%-5s %-8s grid %4d x %3d: %8.3f ms  %6.0f TFLOP/s  clock %.2f GHz\n", MODE == 0 ? "fp8" : MODE == 1 ? "bf16" : "fp16",
          RANDOM ? "random" : "constant", grid, threads, ms, flops / ms / 1e9, clk);
 }
 
@@ -73,6 +80,7 @@ int main() {
   for (int rep = 0; rep < 2; ++rep) {
     run<0, 0>(d, 256, 256); run<0, 1>(d, 256, 256); run<0, 1>(d, 256, 512);
     run<1, 0>(d, 256, 256); run<1, 1>(d, 256, 256); run<1, 1>(d, 256, 512);
+    run<2, 0>(d, 256, 256); run<2, 1>(d, 256, 256); run<2, 1>(d, 256, 512);
   }
   return 0;
 }
