@@ -205,7 +205,10 @@ def _sp_worker(rank, world, port, ret):
     SP_STATE.cleanup()
 
 
-def test_pipeline_call_shards_frames_and_gathers_under_sp():
+def test_pipeline_call_keeps_whole_latents_under_sp():
+    """pipeline calls under sequence parallelism: every rank carries the WHOLE latent (the transformer shards its token
+    sequence itself, tests/test_ulysses_gloo.py::test_pipeline_token_shard_33_frames); a transformer called directly with
+    frame-sharded latents still gets the global rotary table through the zero-stride stand-in"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
@@ -219,6 +222,6 @@ def test_pipeline_call_shards_frames_and_gathers_under_sp():
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         for r in range(2):
             d = ret[r]
-            assert d["equal"], "gathered + decoded video must equal the single-process one for a per-token model"
-            assert d["shapes"] == [(1, 4, 2, 6, 8)] * 3  # each rank denoises its 2 of the 4 latent frames
+            assert d["equal"], "the video must equal the single-process one"
+            assert d["shapes"] == [(1, 4, 4, 6, 8)] * 3  # every forward of the loop sees all 4 latent frames
             assert d["same_seed"] and d["rope_rows"] == 4 * 6 * 8
