@@ -73,7 +73,16 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   const Params& p = pp.p;
   using O4 = typename OutT<TO>::v4;
   constexpr int QB = NW * 32;
-  constexpr int CH = 8 / NW;  // 1-KiB DMA pieces (8 tile rows) of one tile per wave: 1 (8 waves) or 2 (4 waves)
+  // -DVORTA_XLOAD8=1 (experiment, measured neutral): the tiles are requested by the first four waves only (2 of a tile's
+  // 8 1-KiB pieces each) -- in the 8-wave workgroup the waves whose step starts with the matrix part and who reach the
+  // barrier ~170 cycles before their partners.  tools/trace_fp8.py: a piece costs its wave 60-80 cycles of issue; with
+  // four loaders the partners' barrier wait drops from 165 to 76 cycles and the loaders' from 332 to 95, the step stays
+  // at ~1 700 cycles: the loop is bound by the SIMD's issue slots, not by either role's critical path.
+#ifndef VORTA_XLOAD8
+#define VORTA_XLOAD8 0
+#endif
+  constexpr int LW = VORTA_XLOAD8 ? 4 : NW;  // loader waves
+  constexpr int CH = 8 / LW;                 // 1-KiB DMA pieces (8 tile rows) of one tile per loader wave
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
@@ -125,25 +134,27 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.v + (int64_t)head * p.v_sh), 0, 0x7fffffff, 0x00020000);
   const int k_ss32 = (int)p.k_ss, v_ss32 = (int)p.v_ss;
+  const bool loader = wave < LW;  // wave-uniform
+  const int lwave = loader ? wave : 0;
   int k_col[CH], v_col[CH];  // source byte offset inside the row for the chunk this lane lands in
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
-    const int row = 8 * (CH * wave + i) + (lane >> 3);
+    const int row = 8 * (CH * lwave + i) + (lane >> 3);
     k_col[i] = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
     v_col[i] = ((lane & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4;
   }
   int rowK[CH], rowV[CH];
 #define ROWS_OF(dst_, blk_)                                                       \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
-    const int pos_ = min((blk_) * KVB + 8 * (CH * wave + i_) + (lane >> 3), n_kv - 1); \
+    const int pos_ = min((blk_) * KVB + 8 * (CH * lwave + i_) + (lane >> 3), n_kv - 1); \
     if constexpr (KVTAB) dst_[i_] = kv_rows[pos_];                                \
     else dst_[i_] = p.kv_row_offset + pos_;                                       \
   }
 #define DMA_K(slot_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(  \
-      k_rsrc, (LDS_AS void*)(smem + (slot_) * TILE8 + (CH * wave + i_) * 1024), 16,                                \
+      k_rsrc, (LDS_AS void*)(smem + (slot_) * TILE8 + (CH * lwave + i_) * 1024), 16,                               \
       (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + k_col[i_], 0, 0, 0);
 #define DMA_V(slot_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(  \
-      v_rsrc, (LDS_AS void*)(smem + (K_SLOTS + (slot_)) * TILE8 + (CH * wave + i_) * 1024), 16,                    \
+      v_rsrc, (LDS_AS void*)(smem + (K_SLOTS + (slot_)) * TILE8 + (CH * lwave + i_) * 1024), 16,                   \
       (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
 
   // ---- LDS read addresses ----
@@ -328,10 +339,12 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #define STAGE_DMA(kw_, vw_, jabs_)
 #else
 #define STAGE_DMA(kw_, vw_, jabs_)                                                \
-  DMA_K(kw_)                                                                      \
-  DMA_V(vw_)                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
-  ROWS_OF(rowK, (jabs_) + 3)                                                      \
+  if (loader) {                                                                   \
+    DMA_K(kw_)                                                                    \
+    DMA_V(vw_)                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];        \
+    ROWS_OF(rowK, (jabs_) + 3)                                                    \
+  }                                                                               \
   __builtin_amdgcn_sched_barrier(0);
 #endif
 #if defined(VORTA_DIAG_NOBAR)  // timing diagnostics only (results are wrong): no workgroup barrier / no wait at all
@@ -361,7 +374,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #ifndef VORTA_PRIO8
 #define VORTA_PRIO8 1  /* s_setprio around the matrix part (the partner wave is in its VALU part then) */
 #endif
-#if VORTA_PRIO8
+#if VORTA_PRIO8 == 1
 #define PRIO_HI() __builtin_amdgcn_s_setprio(2);
 #define PRIO_LO() __builtin_amdgcn_s_setprio(0);
 #else
@@ -415,14 +428,44 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     QK_FRAGS(n0_, n1_)                                                            \
     PRIO_LO()                                                                     \
   }
+  // -DVORTA_TRACE8=i (diagnostic builds, tools/trace_fp8.py; one interval per build -- the loop has no registers to
+  // spare): shader cycles between stamps i-1 and i of every step, summed per wave, go to ws_ml of an unsplit launch.
+  //   0 step start | 1 before the matrix part | 2 after it | 3 before the end-of-step wait | 4 before the barrier | 5 after
+#ifdef VORTA_TRACE8
+  unsigned tr_sum_ = 0, tr_t0_ = 0;
+#define TR_(i_)                                                                   \
+  if constexpr ((i_) == VORTA_TRACE8 - 1) {                                       \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    tr_t0_ = (unsigned)__builtin_readcyclecounter();                              \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  } else if constexpr ((i_) == VORTA_TRACE8) {                                    \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    tr_sum_ += (unsigned)__builtin_readcyclecounter() - tr_t0_;                   \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  }
+#undef STEP_SYNC
+#define STEP_SYNC()                                                               \
+  {                                                                               \
+    TR_(3)                                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
+    TR_(4)                                                                        \
+    asm volatile("s_barrier" ::: "memory");                                       \
+    TR_(5)                                                                        \
+  }
+#else
+#define TR_(i_)
+#endif
 #define STEP(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_)                       \
   {                                                                               \
+    TR_(0)                                                                        \
     STAGE_DMA(kw_, vw_, jabs_)                                                    \
     if (wave_active) {                                                            \
       if (role_y) VALU_PART(n0_, n1_, c0_, c1_)                                   \
       __builtin_amdgcn_sched_barrier(0);                                          \
+      TR_(1)                                                                      \
       MATRIX_PART(c0_, c1_, n0_, n1_, kr_, vr_, jabs_)                            \
       __builtin_amdgcn_sched_barrier(0);                                          \
+      TR_(2)                                                                      \
       if (!role_y) VALU_PART(c0_, c1_, n0_, n1_)                                  \
     }                                                                             \
     STEP_SYNC()                                                                   \
@@ -434,16 +477,21 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #else
   const bool role_y = NW == 8 && wave >= NW / 2;  // wave-uniform
 #endif
+#if VORTA_PRIO8 == 2  // experiment: static priority for the later-dispatched half, no flips
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   if (nsteps > 0) {
     // ---- prologue: K(0), V(0), K(1); the scores of block 0 fix the reference point ----
-    ROWS_OF(rowK, blk0)
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-    DMA_K(0)
-    DMA_V(0)
-    ROWS_OF(rowK, blk0 + 1)
-    DMA_K(1)
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-    ROWS_OF(rowK, blk0 + 2)
+    if (loader) {
+      ROWS_OF(rowK, blk0)
+      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
+      DMA_K(0)
+      DMA_V(0)
+      ROWS_OF(rowK, blk0 + 1)
+      DMA_K(1)
+      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
+      ROWS_OF(rowK, blk0 + 2)
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave_active) {
@@ -460,12 +508,15 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     }
     __syncthreads();  // every wave has read K(0) before its slot is overwritten
     {  // step 0: no PV yet -- the scores of block 1, then (first role) the VALU part of block 0
+      TR_(0)
       STAGE_DMA(0, 1, blk0)
       if (wave_active) {
+        TR_(1)
         KFRAGS0(1)
         KFRAGS1(1)
         QK_FRAGS(sB0, sB1)
         __builtin_amdgcn_sched_barrier(0);
+        TR_(2)
         if (!role_y) VALU_PART(sA0, sA1, sB0, sB1)
       }
       STEP_SYNC()
@@ -519,6 +570,13 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #undef DMA_V
 #undef SCHED_M
 #undef SG_
+#undef TR_
+#ifdef VORTA_TRACE8
+  if (p.n_splits == 1 && p.ws_ml && lane == 0) {
+    unsigned* tr = (unsigned*)p.ws_ml + ((int64_t)wg * NW + wave) * 2;
+    tr[0] = tr_sum_; tr[1] = (unsigned)(nsteps - 1);
+  }
+#endif
 
   if (!wave_active) return;
   // ---------------- epilogue ----------------
