@@ -31,7 +31,8 @@ extern "C" {
 #define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
 #define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
 
-#define VORTA_ABI_VERSION 2 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); every v1 call is unchanged */
+#define VORTA_ABI_VERSION 3 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
+                                every earlier call is unchanged */
 
 typedef enum vorta_dtype {
   VORTA_BF16 = 0,
@@ -325,12 +326,32 @@ int vorta_mix_experts(const vorta_mix_args* args, void* hip_stream);
  */
 int vorta_seq_row_map(int32_t* row_map, int32_t n_tokens, int32_t seg_len, int32_t seg_stride_rows, void* hip_stream);
 
+/*
+ * vorta_permute_heads -- the staging passes of the Ulysses exchange in one launch (vorta/ulysses/utils.py:61-91 does
+ * them as transpose + .contiguous() per tensor and direction; A13 in SURVEY.md §8a).  For up to four (heads, n_rows, D)
+ * views at once:
+ *     dst[t][dst_map ? dst_map[h] : h][r][:] = src[t][src_map ? src_map[h] : h][r][:]      h < heads, r < n_rows
+ * Send side: q, k, v projection views -> head-ordered contiguous blocks (src_map = head order), and the replicated text
+ * rows behind each local head slot; receive side: the head-ordered output back into the (rows, H*D) result (dst_map).
+ * The maps are device arrays of `heads` entries; a map must not repeat a head on the destination side.
+ */
+typedef struct vorta_permute_args {
+  uint32_t struct_size;
+  int32_t dtype, head_dim, heads, n_rows, n_tensors; /* dtype: VORTA_BF16 / VORTA_FP16 (2-byte) or VORTA_FP8E4M3 */
+  vorta_tensor src[4];
+  vorta_tensor dst[4];
+  const int32_t* src_map; /* [heads] or NULL */
+  const int32_t* dst_map; /* [heads] or NULL */
+} vorta_permute_args;
+
+int vorta_permute_heads(const vorta_permute_args* args, void* hip_stream);
+
 /* Introspection */
 int vorta_abi_version(void);
 const char* vorta_build_info(void); /* static string: arch, compiler */
 int vorta_last_hip_error(void);     /* last hipError_t seen by a failed launch in this thread */
 int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args, 5 norm_rope_args,
-                                       6 mix_args, 7 fp8_quant_args, 8 attn_fp8_ext */
+                                       6 mix_args, 7 fp8_quant_args, 8 attn_fp8_ext, 9 permute_args */
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvo
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
 VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3 = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i32, _i64, _u32, _f32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
 
@@ -86,6 +86,13 @@ class MixArgs(C.Structure):
     ]
 
 
+class PermuteArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32), ("n_rows", _i32),
+        ("n_tensors", _i32), ("src", Tensor * 4), ("dst", Tensor * 4), ("src_map", _vp), ("dst_map", _vp),
+    ]
+
+
 class Fp8QuantArgs(C.Structure):
     _fields_ = [
         ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32),
@@ -121,6 +128,7 @@ SYMBOLS = {
     "vorta_qk_norm_rope": (C.c_int, [C.POINTER(NormRopeArgs), _vp]),
     "vorta_mix_experts": (C.c_int, [C.POINTER(MixArgs), _vp]),
     "vorta_seq_row_map": (C.c_int, [_vp, _i32, _i32, _i32, _vp]),
+    "vorta_permute_heads": (C.c_int, [C.POINTER(PermuteArgs), _vp]),
     "vorta_abi_version": (C.c_int, []),
     "vorta_build_info": (C.c_char_p, []),
     "vorta_last_hip_error": (C.c_int, []),
@@ -159,7 +167,7 @@ def lib():
     if h.vorta_abi_version() != ABI_VERSION:
         raise VortaHipError(f"ABI mismatch: library {h.vorta_abi_version()} vs binding {ABI_VERSION}")
     for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs, MixArgs, Fp8QuantArgs,
-                                AttnFp8Ext)):
+                                AttnFp8Ext, PermuteArgs)):
         if h.vorta_sizeof(which) != C.sizeof(st):
             raise VortaHipError(f"struct layout mismatch for {st.__name__}: "
                                 f"C {h.vorta_sizeof(which)} vs ctypes {C.sizeof(st)}")

@@ -27,6 +27,7 @@ extern "C" int vorta_sizeof(int which) {
     case 6: return (int)sizeof(vorta_mix_args);
     case 7: return (int)sizeof(vorta_fp8_quant_args);
     case 8: return (int)sizeof(vorta_attn_fp8_ext);
+    case 9: return (int)sizeof(vorta_permute_args);
     default: return -1;
   }
 }

@@ -541,6 +541,33 @@ def mix_experts(xs, scores: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def permute_heads(srcs, dsts, src_map: Optional[torch.Tensor] = None, dst_map: Optional[torch.Tensor] = None) -> None:
+    """vorta_permute_heads: dsts[t][dst_map[h]] = srcs[t][src_map[h]] for up to four (H,N,D) views in one launch (the
+    staging passes of the Ulysses exchange, vorta/ulysses/utils.py:61-91).  Maps: int32 device tensors of H entries."""
+    _require_gpu(*srcs, *dsts)
+    if not srcs or len(srcs) != len(dsts) or len(srcs) > 4:
+        raise ValueError("permute_heads takes one to four source / destination pairs")
+    H, N, D = dsts[0].shape
+    a = _C.PermuteArgs()
+    a.struct_size = C.sizeof(_C.PermuteArgs)
+    dt = _C.VORTA_FP8E4M3 if dsts[0].dtype == FP8_STORAGE else _DT[dsts[0].dtype]
+    a.dtype, a.head_dim, a.heads, a.n_rows, a.n_tensors = dt, D, H, N, len(srcs)
+    for t, (x, y) in enumerate(zip(srcs, dsts)):
+        if x.dtype != y.dtype or y.dtype != dsts[0].dtype or tuple(y.shape) != (H, N, D) or x.shape[1:] != y.shape[1:]:
+            raise ValueError("permute_heads: every pair must be (heads, rows, D) views of one dtype and row count")
+        if x.stride(-1) != 1 or y.stride(-1) != 1:
+            raise ValueError("permute_heads: the channel dimension must be contiguous")
+        a.src[t], a.dst[t] = _tensor(x), _tensor(y)
+    for name, m, n_src in (("src_map", src_map, srcs[0].shape[0]), ("dst_map", dst_map, H)):
+        if m is not None:
+            if m.dtype != torch.int32 or m.numel() != H or not m.is_contiguous() or m.device != dsts[0].device:
+                raise ValueError(f"permute_heads: {name} must be a contiguous int32 device tensor with one entry per head")
+            setattr(a, name, m.data_ptr())
+    if src_map is None and srcs[0].shape[0] != H:
+        raise ValueError("permute_heads: without a source map the sources need as many heads as the destinations")
+    _C.check(_C.lib().vorta_permute_heads(C.byref(a), _stream()), "vorta_permute_heads")
+
+
 def seq_row_map(n_tokens: int, seg_len: int, seg_stride_rows: int, device) -> torch.Tensor:
     """vorta_seq_row_map (zero-copy Ulysses layout)."""
     out = torch.empty(n_tokens, dtype=torch.int32, device=device)

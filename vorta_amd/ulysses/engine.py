@@ -23,11 +23,16 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .. import ops
+
 
 # Transport of the head exchange.  "a2a" (default): one all_to_all_single per tensor whenever the chunks are in rank
 # order (always, once the heads went through the staging pass); "p2p": grouped send/recv for everything.  Slot-group
 # (overlapped) exchanges and shards sent straight from a permuted-but-contiguous source always use send/recv.
 TRANSPORT = __import__("os").environ.get("VORTA_SP_TRANSPORT", "a2a")
+# staging passes of device tensors: one vorta_permute_heads launch each ("hip"); "torch" keeps the index ops the CPU
+# rehearsals use (A/B measurements only)
+HIP_STAGING = __import__("os").environ.get("VORTA_SP_STAGING", "hip") != "torch"
 
 
 def balanced_head_order(experts: Sequence[int], cost_of_expert: Sequence[float], P: int, groups: int = 1) -> List[int]:
@@ -118,7 +123,6 @@ class UlyssesLayout:
         """e4m3 copies of the q, k, v receive buffers for the fp8 attention kernels: ONE conversion of each whole buffer
         (the head views overlap, so converting per head would redo it Hl times), hence one q/k scale pair and one
         per-channel v scale for all local heads.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
-        from .. import ops
         x = [b.view(1, self.rows_total, self.D) for b in bufs[:3]]
         f8 = ops.fp8_quantize_qkv(*x, scale, out=out)
         shape, stride = (self.Hl, self.rows_total - (self.Hl - 1) * self.Sl, self.D), (self.Sl * self.D, self.D, 1)
@@ -185,6 +189,18 @@ class UlyssesLayout:
             o.copy_(ho)
         return None
 
+    def _head_map(self, heads: Sequence[int]) -> torch.Tensor:
+        """int32 device copy of a head list for `ops.permute_heads`, built once per distinct list (a host-to-device copy
+        per layer would stall the stream)."""
+        maps = self.__dict__.setdefault("_head_maps", {})
+        key = tuple(heads)
+        m = maps.get(key)
+        if m is None:
+            if len(maps) > 4096:
+                maps.clear()
+            m = maps[key] = torch.tensor(key, dtype=torch.int32, device=self.device)
+        return m
+
     def _stage(self, key):
         """(H, Sl, D) staging buffers in head_order (one per tensor slot), allocated once per layout."""
         st = self.__dict__.setdefault("_stages", {})
@@ -222,24 +238,34 @@ class UlyssesLayout:
         blk = Hl * Sl
         groups = [(0, Hl)] if groups is None else [tuple(g) for g in groups]
         srcs = []
-        idx = None
+        staged = []
         for t, (x, buf) in enumerate(zip(shards, bufs)):
             direct = x.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
             if direct:
                 src = x
                 first = [self._run_of(head_order, j * Hl, Hl) for j in range(P)]
             else:
-                if idx is None:
-                    idx = torch.as_tensor(list(head_order), device=x.device)
                 src = self._stage(("s", t))
-                torch.index_select(x, 0, idx, out=src)
+                staged.append((x, src))
                 first = [j * Hl for j in range(P)]
             srcs.append((src, first, buf))
-        if texts is not None and self.T:
-            for t, buf in zip(texts, bufs):  # t: (H, T, D) replicated
-                for i in range(Hl):
-                    r0 = self.rows_video + i * Sl
-                    buf[r0:r0 + self.T].copy_(t[head_order[me * Hl + i]])
+        if staged:  # one gather pass orders the heads of every staged tensor
+            if staged[0][0].is_cuda and HIP_STAGING:
+                ops.permute_heads([x for x, _ in staged], [y for _, y in staged], src_map=self._head_map(head_order))
+            else:  # CPU rehearsal (gloo)
+                idx = torch.as_tensor(list(head_order), device=staged[0][0].device)
+                for x, y in staged:
+                    torch.index_select(x, 0, idx, out=y)
+        if texts is not None and self.T:  # texts[t]: (H, T, D) replicated; its rows follow each local head slot's video
+            mine = head_order[me * Hl:(me + 1) * Hl]
+            if texts[0].is_cuda and HIP_STAGING:
+                dsts = [buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1)) for buf in bufs]
+                ops.permute_heads(list(texts), dsts, src_map=self._head_map(mine))
+            else:
+                for t, buf in zip(texts, bufs):
+                    for i in range(Hl):
+                        r0 = self.rows_video + i * Sl
+                        buf[r0:r0 + self.T].copy_(t[mine[i]])
         in_rank_order = all(first == [j * Hl for j in range(P)] for _, first, _ in srcs)
         if TRANSPORT == "a2a" and groups == [(0, Hl)] and in_rank_order and P > 1:
             # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides
@@ -299,7 +325,10 @@ class UlyssesLayout:
         Hl, Sl = self.Hl, self.Sl
         out_shard, head_order = state["out_shard"], state["order"]
         if not state["direct"]:
-            out_shard.index_copy_(0, torch.as_tensor(head_order, device=out_shard.device), state["dst"])
+            if out_shard.is_cuda and HIP_STAGING:
+                ops.permute_heads([state["dst"]], [out_shard], dst_map=self._head_map(head_order))
+            else:
+                out_shard.index_copy_(0, torch.as_tensor(head_order, device=out_shard.device), state["dst"])
         if out_text is not None and self.T:
             local = torch.stack([buf[self.rows_video + i * Sl: self.rows_video + i * Sl + self.T] for i in range(Hl)])
             parts = [torch.empty_like(local) for _ in range(self.P)]
@@ -314,7 +343,10 @@ class UlyssesLayout:
             else:
                 parts = [local]
             allh = torch.cat(parts, dim=0)  # (H, T, D) in head_order
-            out_text[torch.as_tensor(list(head_order), device=out_text.device)] = allh
+            if out_text.is_cuda and HIP_STAGING:
+                ops.permute_heads([allh], [out_text], dst_map=self._head_map(head_order))
+            else:
+                out_text[torch.as_tensor(list(head_order), device=out_text.device)] = allh
 
 
 class UlyssesRoutedAttention:
