@@ -147,7 +147,8 @@ int vorta_attn_workspace_bytes(const vorta_attn_args* args, uint64_t* ws_o_bytes
  *   channels), which puts both maxima at sqrt(c0 * amax_q * amax_k) -- far inside e4m3's range (448), whose relative
  *   precision (2^-4) does not depend on where in the normal range a value sits.  v is scaled per head and channel to
  *   amax -> 240; v_descale[h][d] = amax_v[h][d] / 240 is applied to the output row in the attention epilogue.
- *   Enqueues 3 launches (abs-max reduction, scales, convert); nothing is read back to the host.
+ *   Enqueues 3 launches (abs-max reduction, scales, convert; one more small one with key centring, flags bit1);
+ *   nothing is read back to the host.
  *
  * vorta_attn_fwd_fp8 / _batch_fp8 -- vorta_attn_fwd / _batch with q,k,v = e4m3 (args->dtype = VORTA_FP8E4M3, strides
  *   in BYTES = elements, rows 16-byte aligned); `scale` is ignored (folded, above); the probabilities are re-packed
@@ -166,9 +167,16 @@ typedef struct vorta_fp8_quant_args {
   vorta_tensor q, k, v;     /* inputs, (H,S,D) views, strides in elements */
   vorta_tensor q8, k8, v8;  /* outputs, e4m3, strides in bytes; rows 16-byte aligned */
   float* v_descale;         /* [heads][head_dim] out */
-  float* ws;                /* workspace, vorta_fp8_quant_ws_floats(heads, head_dim) floats: abs-max slots + multipliers */
-  int32_t flags;            /* bit0: v scaled per head instead of per (head, channel) */
-  int32_t reserved;
+  float* ws;                /* workspace, vorta_fp8_quant_ws_floats(heads, head_dim) floats: abs-max slots, multipliers, centres */
+  int32_t flags;            /* bit0: v scaled per head instead of per (head, channel);
+                               bit1: centre the keys -- k8 = e4m3((k - c[h]) * kmul[h]) with c[h][:] the mean of ~1024 evenly
+                               spaced key rows of the head (softmax does not change when one vector is subtracted from
+                               every key; the e4m3 error of q8 . k8 shrinks with |k|) */
+  int32_t seg_len;          /* 0: q,k,v,q8,k8,v8 are (heads, n_tokens, D) views.  > 0: they are row arrays of n_tokens rows
+                               (stride_h unused) in which row r belongs to head (r / seg_len) % heads -- the Ulysses
+                               receive layout (vorta_seq_row_map); every head gets its own scales and centre */
+  int32_t tail_first;       /* seg_len > 0 and tail_len > 0: from row tail_first (a multiple of seg_len) on, only the */
+  int32_t tail_len;         /* first tail_len rows of a segment hold data (text rows); the others are skipped */
 } vorta_fp8_quant_args;
 
 int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim);

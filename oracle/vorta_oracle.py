@@ -434,12 +434,30 @@ def e4m3_decode(b: np.ndarray) -> np.ndarray:
     return np.where(s == 1, -v, v)
 
 
+def fp8_center_rows(n_tokens: int, heads: int, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0) -> list:
+    """rows whose mean is the key centre of each head (fp8_quant.hip: fp8_kmean_kernel): candidates r = i * stride with an
+    odd stride ~ n_tokens / 1024 (per head), kept if they belong to the head and hold data."""
+    stride = max(1, n_tokens // (1024 * heads) if seg_len > 0 else n_tokens // 1024) | 1
+    cand = np.arange(0, n_tokens, stride)
+    if seg_len <= 0:
+        return [cand] * heads
+    seg = cand // seg_len
+    ok = np.ones(cand.shape, bool)
+    if tail_len > 0:
+        ok = ~((cand >= tail_first) & (cand - seg * seg_len >= tail_len))
+    return [cand[ok & (seg % heads == h)] for h in range(heads)]
+
+
 def fp8_quantize_qkv(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: Optional[float] = None,
-                     v_per_head: bool = False) -> dict:
+                     v_per_head: bool = False, k_center: Optional[np.ndarray] = None) -> dict:
     """include/vorta_hip.h vorta_fp8_quantize_qkv on (H,S,D) arrays holding bf16/fp16-representable values.
-    The multipliers are computed in float32 like the kernel (fp8_quant.hip: fp8_scales_kernel), the products too."""
+    The multipliers are computed in float32 like the kernel (fp8_quant.hip: fp8_scales_kernel), the products too.
+    `k_center` (H,D) float32: the centre subtracted from the keys (flags bit1; any vector is legitimate -- softmax over
+    the keys does not see it -- so tests pass the kernel's own, after checking it against `fp8_center_rows`)."""
     f32 = np.float32
     q, k, v = (np.asarray(a, dtype=f32) for a in (q, k, v))
+    if k_center is not None:
+        k = (k - np.asarray(k_center, f32)[:, None, :]).astype(f32)
     D = q.shape[-1]
     c0 = f32(f32(1.0 / np.sqrt(D) if scale is None else scale) * f32(1.4426950408889634))
     mq, mk = np.abs(q).max((1, 2)), np.abs(k).max((1, 2))

@@ -16,7 +16,9 @@ The reference has no fp8 code, so the gates are this build's own, stated here an
              10 log10(R^2 / mse) with R = the data range max - min of the bf16 output (the convention of
              skimage.metrics.peak_signal_noise_ratio / torchmetrics for float data).  The stricter figure with
              R = max |output| (6 dB lower for a symmetric signal) is printed beside it and held above 39 dB.  The inputs
-             are white noise (no structure for the quantisation noise to average against): the worst case.
+             are white noise (no structure for the quantisation noise to average against): the worst case for the
+             rounding noise, the best case for the operand ranges -- keys with a common component (a per-channel mean)
+             fall under the gate unless the conversion centres them, which it does by default (flags bit1).
 """
 import math
 
@@ -37,6 +39,15 @@ def _decoded(f8):
     """the GPU's e4m3 operands as float64 (H,S,D) arrays + v_descale (H,D)"""
     return (O.e4m3_decode(f8.q.cpu().numpy()), O.e4m3_decode(f8.k.cpu().numpy()), O.e4m3_decode(f8.v.cpu().numpy()),
             f8.v_descale.cpu().numpy().astype(np.float64))
+
+
+def _psnr(x, ref):
+    """(PSNR over the data range max - min, PSNR over max |ref|, relative rms error)"""
+    x, ref = x.float(), ref.float()
+    mse = torch.mean((x - ref) ** 2).item()
+    rng, peak = (ref.max() - ref.min()).item(), ref.abs().max().item()
+    f = lambda r: 10.0 * math.log10(r * r / max(mse, 1e-30))
+    return f(rng), f(peak), math.sqrt(mse / torch.mean(ref ** 2).item())
 
 
 def _vmax(v8, vd):
@@ -85,6 +96,89 @@ def test_quantizer_matches_oracle_bit_for_bit(dtype):
     h8 = ops.fp8_quantize_qkv(qd, kd, vd, v_per_head=True)
     zh = O.fp8_quantize_qkv(rounded(q, dtype), rounded(k, dtype), rounded(v, dtype), v_per_head=True)
     assert (h8.v.cpu().numpy() == zh["v8"]).all() and (h8.v_descale.cpu().numpy() == zh["v_descale"]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_quantizer_key_centring_and_segmented_rows(dtype):
+    """flags bit1 (centre the keys) and the Ulysses row layout (seg_len > 0: per-head scales / centres on ONE row array,
+    gaps behind the text rows skipped) against the oracle and against the (H,S,D) call on the same data"""
+    from vorta_amd import ops
+    rng = np.random.default_rng(5)
+    Hl, P, Sl, T = 3, 4, 700, 33
+    S = P * Sl
+    q = rng.standard_normal((Hl, S + T, 128)) * np.array([0.5, 1.0, 4.0])[:, None, None]
+    k = rng.standard_normal((Hl, S + T, 128)) + 5.0 * rng.standard_normal((Hl, 1, 128))
+    v = rng.standard_normal((Hl, S + T, 128)) * np.linspace(0.05, 8.0, 128)
+    qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+    kr = rounded(k, dtype)
+    # (H,S,D) layout, centred: the centre is the mean of the oracle's sample rows; everything else bit for bit
+    f8 = ops.fp8_quantize_qkv(qd, kd, vd, center_k=True)
+    c = f8.k_center().cpu().numpy()
+    rows = O.fp8_center_rows(S + T, Hl)
+    want = np.stack([kr[h, rows[h]].mean(0) for h in range(Hl)])
+    assert np.abs(c - want).max() <= 1e-5 * np.abs(want).max()
+    z = O.fp8_quantize_qkv(rounded(q, dtype), kr, rounded(v, dtype), k_center=c)
+    qm, km, vm = (t.cpu().numpy() for t in f8.multipliers())
+    assert (qm == z["qmul"]).all() and (km == z["kmul"]).all() and (vm == z["vmul"]).all()
+    for name, t in (("q8", f8.q), ("k8", f8.k), ("v8", f8.v)):
+        assert (t.cpu().numpy() == z[name]).all(), name
+    assert float(km.max()) > 1.5 * float(ops.fp8_quantize_qkv(qd, kd, vd).multipliers()[1].max())  # the range went to the signal
+    # the same data in the receive layout of rank-local heads: chunk j = (Hl, Sl, D), text rows behind slot i's video rows
+    rows_video, rows_total = P * Hl * Sl, P * Hl * Sl + Hl * Sl
+    phys = lambda h, s: (s // Sl) * Hl * Sl + h * Sl + s % Sl
+    bufs = []
+    for x in (qd, kd, vd):
+        b = torch.full((rows_total, 128), 300.0, dtype=dtype, device=dev())  # gaps hold junk that must not be read
+        for h in range(Hl):
+            for j in range(P):
+                b[phys(h, j * Sl):phys(h, j * Sl) + Sl] = x[h, j * Sl:(j + 1) * Sl]
+            b[rows_video + h * Sl:rows_video + h * Sl + T] = x[h, S:]
+        bufs.append(b.view(1, rows_total, 128))
+    for center in (False, True):
+        g8 = ops.fp8_quantize_qkv(*bufs, heads=Hl, seg_len=Sl, tail_first=rows_video, tail_len=T, center_k=center)
+        cs = g8.k_center().cpu().numpy()
+        if center:
+            srows = O.fp8_center_rows(rows_total, Hl, Sl, rows_video, T)
+            kb = bufs[1][0].float().cpu().numpy()
+            want = np.stack([kb[srows[h]].mean(0) for h in range(Hl)])
+            assert np.abs(cs - want).max() <= 1e-5 * np.abs(want).max()
+        zs = O.fp8_quantize_qkv(rounded(q, dtype), kr, rounded(v, dtype), k_center=cs if center else None)
+        qm, km, vm = (t.cpu().numpy() for t in g8.multipliers())
+        assert (qm == zs["qmul"]).all() and (km == zs["kmul"]).all() and (vm == zs["vmul"]).all()
+        assert (g8.v_descale.cpu().numpy() == zs["v_descale"]).all()
+        for name, t in (("q8", g8.q), ("k8", g8.k), ("v8", g8.v)):
+            got = t[0].cpu().numpy()
+            for h in range(Hl):
+                for j in range(P):
+                    assert (got[phys(h, j * Sl):phys(h, j * Sl) + Sl] == zs[name][h, j * Sl:(j + 1) * Sl]).all(), (name, h, j)
+                assert (got[rows_video + h * Sl:rows_video + h * Sl + T] == zs[name][h, S:]).all(), (name, h, "text")
+    with pytest.raises(ValueError):
+        ops.fp8_quantize_qkv(qd, kd, vd, seg_len=Sl)  # segmented layout needs (1,rows,D) arrays and `heads`
+    with pytest.raises(ValueError):  # VORTA_EINVAL: the text region starts on a segment boundary
+        ops.fp8_quantize_qkv(*bufs, heads=Hl, seg_len=Sl, tail_first=rows_video + 1, tail_len=T)
+
+
+def test_key_centring_buys_back_a_common_key_component():
+    """keys with a per-channel mean of 8 standard deviations: the e4m3 operator falls under the 40 dB gate without the
+    centring and keeps its white-noise PSNR with it (what `routed_attention(fp8=True)` does by default)"""
+    from vorta_amd import ops
+    H, S = 2, 8192
+    g = torch.Generator(device=dev()).manual_seed(11)
+    q = torch.randn((H, S, 128), generator=g, device=dev()).to(torch.bfloat16)
+    k = (torch.randn((H, S, 128), generator=g, device=dev()) +
+         8.0 * torch.randn((H, 1, 128), generator=g, device=dev())).to(torch.bfloat16)
+    v = torch.randn((H, S, 128), generator=g, device=dev()).to(torch.bfloat16)
+    ref = torch.empty_like(q)
+    ops.attn_fwd(q, k, v, ref, n_q=S, n_kv=S)
+    res = {}
+    for center in (False, True):
+        f8 = ops.fp8_quantize_qkv(q, k, v, center_k=center)
+        o = torch.empty_like(q)
+        ops.attn_fwd(f8.q, f8.k, f8.v, o, n_q=S, n_kv=S, v_descale=f8.v_descale)
+        res[center] = _psnr(o, ref)
+    print("fp8 vs bf16, keys with an 8-sigma common component (PSNR range dB, PSNR peak dB, rel rms): as is",
+          tuple(round(x, 3) for x in res[False]), "centred", tuple(round(x, 3) for x in res[True]))
+    assert res[True][0] >= 40.0 and res[False][0] < 40.0 and res[True][0] >= res[False][0] + 8.0
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -276,15 +370,6 @@ def test_fp8_routed_attention_vs_emulator_and_oracle(model, fused):
     out2 = routed_attention(qd, kd, vd, HeadRouting.from_device(lists, counts), geom, model=model, text_len=T,
                             text_valid=te, fp8=True, fused=fused)
     assert torch.equal(out2, out)
-
-
-def _psnr(x, ref):
-    """(PSNR over the data range max - min, PSNR over max |ref|, relative rms error)"""
-    x, ref = x.float(), ref.float()
-    mse = torch.mean((x - ref) ** 2).item()
-    rng, peak = (ref.max() - ref.min()).item(), ref.abs().max().item()
-    f = lambda r: 10.0 * math.log10(r * r / max(mse, 1e-30))
-    return f(rng), f(peak), math.sqrt(mse / torch.mean(ref ** 2).item())
 
 
 def test_fp8_operator_psnr_wan14b_81f_geometry():

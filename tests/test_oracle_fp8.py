@@ -52,6 +52,33 @@ def test_quantizer_folds_the_softmax_scale_and_balances_ranges():
     assert np.allclose(zh["v_descale"], zh["v_descale"][:, :1])
 
 
+def test_key_centring_is_softmax_invariant_and_buys_back_the_common_component():
+    """flags bit1 of vorta_fp8_quantize_qkv: subtracting one vector from every key of a head leaves the attention
+    output alone; with a common component in the keys the e4m3 scores are far closer to the true ones after it"""
+    rng = np.random.default_rng(3)
+    H, S, D = 2, 300, 128
+    q = rng.standard_normal((H, S, D))
+    k = rng.standard_normal((H, S, D)) + 6.0 * rng.standard_normal((H, 1, D))
+    v = rng.standard_normal((H, S, D))
+    rows = O.fp8_center_rows(S, H)
+    c = np.stack([k[h, rows[h]].mean(0) for h in range(H)]).astype(np.float32)
+    assert np.allclose(O.dense_attention(q, k - c[:, None, :], v), O.dense_attention(q, k, v), atol=1e-9)
+    c0 = (1 / np.sqrt(D)) * 1.4426950408889634
+    s = np.einsum("hqd,hkd->hqk", q, k) * c0
+    err = {}
+    for name, kc in (("as is", None), ("centred", c)):
+        z = O.fp8_quantize_qkv(q, k, v, k_center=kc)
+        s8 = np.einsum("hqd,hkd->hqk", O.e4m3_decode(z["q8"]), O.e4m3_decode(z["k8"]))
+        d = s8 - s
+        d = d - d.mean(-1, keepdims=True)  # softmax sees the scores of a query up to a constant
+        err[name] = np.sqrt((d ** 2).mean())
+    assert err["centred"] < 0.3 * err["as is"], err
+    # the rows that define the centre: evenly spaced, in the segmented layout only the head's own rows that hold data
+    seg = O.fp8_center_rows(2 * 3 * 50 + 3 * 50, 3, seg_len=50, tail_first=300, tail_len=7)
+    for h, r in enumerate(seg):
+        assert len(r) and ((r // 50) % 3 == h).all() and ((r < 300) | (r % 50 < 7)).all()
+
+
 def _operands(rng, rows, scale=1.0):
     # values on the e4m3 grid, as the kernels see them
     return O.e4m3_round(rng.standard_normal((rows, 128)) * scale)

@@ -35,8 +35,8 @@ def main():
         print(f"vorta_qk_norm_rope {name} (H={H}, {S}+{T} tokens, per-head norm + rope): {ms:.3f} ms  {gb / ms:.2f} TB/s "
               f"({gb:.2f} GB read+write)", flush=True)
     q, k, v = (torch.randn((H, S + T, 128), device=dev, dtype=torch.bfloat16) for _ in range(3))
-    f8 = ops.fp8_quantize_qkv(q, k, v)
-    ms = timeit(lambda: ops.fp8_quantize_qkv(q, k, v, out=f8))
+    f8 = ops.fp8_quantize_qkv(q, k, v, center_k=True)
+    ms = timeit(lambda: ops.fp8_quantize_qkv(q, k, v, out=f8, center_k=True))
     gb = 3 * q.numel() * 5 / 1e9
     print(f"vorta_fp8_quantize_qkv bf16 (H={H}, {S + T} tokens; q,k,v: abs-max pass 2 B + convert pass 2 B in / 1 B out "
           f"per element): {ms:.3f} ms  {gb / ms:.2f} TB/s ({gb:.2f} GB)", flush=True)

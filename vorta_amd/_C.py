@@ -98,7 +98,7 @@ class Fp8QuantArgs(C.Structure):
         ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32),
         ("n_tokens", _i32), ("qk_scale", _f32),
         ("q", Tensor), ("k", Tensor), ("v", Tensor), ("q8", Tensor), ("k8", Tensor), ("v8", Tensor),
-        ("v_descale", _vp), ("ws", _vp), ("flags", _i32), ("reserved", _i32),
+        ("v_descale", _vp), ("ws", _vp), ("flags", _i32), ("seg_len", _i32), ("tail_first", _i32), ("tail_len", _i32),
     ]
 
 

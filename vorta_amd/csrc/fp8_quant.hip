@@ -1,8 +1,20 @@
 // vorta_fp8_quantize_qkv (include/vorta_hip.h): post-RoPE q,k,v (bf16 / fp16) -> e4m3 copies for the fp8 attention
 // kernels, with the softmax scale and log2(e) folded into the q/k multipliers.  HBM-bound: the abs-max pass reads
-// every element once (2 B), the convert pass reads it again and writes 1 B.  Three launches, no host round trip.
+// every element once (2 B), the convert pass reads it again and writes 1 B.  No host round trip.
 //
-// Workspace (floats): amax_q[H] | amax_k[H] | amax_v[H][D] | qmul[H] | kmul[H] | vmul[H][D]
+// Key centring (flags bit1): softmax over the keys of a head does not change when one vector is subtracted from all of
+// them (q . (k - c) = q . k - q . c, a per-query constant), but the e4m3 error of q8 . k8 grows with |k|, so a common
+// component of the keys -- a per-channel mean, usual in trained attention layers -- costs precision for nothing
+// (tools/dbg/fp8_kbias.py: a mean of 3 / 8 standard deviations costs 6 / 12 dB of output PSNR; centring gives all of it
+// back).  ANY vector c works, so c[h][d] is the mean of <= ~1024 evenly spaced key rows of the head: one small launch,
+// fixed summation order (deterministic), no extra pass over K.
+//
+// Row layouts: (heads, n_tokens, D) views (seg_len = 0), or ONE row array of n_tokens rows in which row r belongs to head
+// (r / seg_len) % heads (seg_len > 0: the Ulysses receive buffer, ulysses/engine.py -- each rank head keeps its own
+// scales and centre although the head views of that buffer overlap); from row tail_first on only the first tail_len
+// rows of a segment hold data (the text rows behind each head slot), the rest is skipped.
+//
+// Workspace (floats): amax_q[H] | amax_k[H] | amax_v[H][D] | qmul[H] | kmul[H] | vmul[H][D] | kmean[H][D]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -14,33 +26,105 @@ namespace {
 constexpr int D = 128;
 constexpr float V_TARGET = 240.f;  // amax of a v channel maps here (e4m3 max 448; relative precision is range-independent)
 constexpr float E4M3_MAX = 448.f;
+constexpr int MEAN_SAMPLES = 1024;  // key rows per head that define the centre (approximately: see fp8_kmean_kernel)
 
 struct QParams {
   const char* x[3]; int64_t x_sh[3], x_ss[3];  // inputs (bytes)
   char* y[3]; int64_t y_sh[3], y_ss[3];        // outputs (bytes)
   int heads, n_tokens, rows_per_block;
+  int seg_len, chunks_per_seg;                 // segmented row layout (seg_len > 0)
+  int tail_first, tail_len;                    // segments from row tail_first on hold tail_len rows of data each
+  int mean_stride;                             // candidate rows of the centre: r = i * mean_stride
   float c0;  // qk_scale * log2(e)
   float* ws; float* v_descale;
-  int v_per_head;
+  int v_per_head, center_k;
 };
 
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 
-// grid (row chunks, heads, 3): per-head abs-max of q and k, per-(head, channel) abs-max of v
+__device__ __forceinline__ float* kmean_of(const QParams& p) { return p.ws + 2 * (2 * p.heads + p.heads * D); }
+
+// the rows a block works on: [r0, r1) of head `head`, stored under physical head index `hphys`
+__device__ __forceinline__ void block_rows(const QParams& p, int& r0, int& r1, int& head, int& hphys) {
+  if (p.seg_len > 0) {
+    const int seg = blockIdx.x / p.chunks_per_seg, c = blockIdx.x - seg * p.chunks_per_seg;
+    const int s0 = seg * p.seg_len;
+    r0 = s0 + c * p.rows_per_block;
+    const int seg_rows = s0 >= p.tail_first ? p.tail_len : p.seg_len;  // tail_first is a multiple of seg_len
+    r1 = min(min(r0 + p.rows_per_block, s0 + seg_rows), p.n_tokens);
+    head = seg % p.heads;
+    hphys = 0;
+  } else {
+    head = hphys = blockIdx.y;
+    r0 = blockIdx.x * p.rows_per_block;
+    r1 = min(r0 + p.rows_per_block, p.n_tokens);
+  }
+}
+
+// grid (heads), 256 threads: centre of the head's keys = mean over the candidate rows r = i * mean_stride that belong to
+// the head (all of them in the (H,S,D) layout).  16 row lanes x 16 channel groups; fixed reduction order.
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_kmean_kernel(const QParams p) {
+  typedef __attribute__((ext_vector_type(8))) T T8;
+  const int h = blockIdx.x;
+  const int t = threadIdx.x, cc = t & 15, rl = t >> 4;
+  const char* base = p.x[1] + (p.seg_len > 0 ? 0 : (int64_t)h * p.x_sh[1]) + cc * 16;
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  int cnt = 0;
+  const int n_cand = (p.n_tokens + p.mean_stride - 1) / p.mean_stride;
+  for (int i = rl; i < n_cand; i += 16) {
+    const int r = i * p.mean_stride;
+    if (p.seg_len > 0) {
+      const int seg = r / p.seg_len;
+      if (seg % p.heads != h || (r >= p.tail_first && r - seg * p.seg_len >= p.tail_len)) continue;
+    }
+    const T8 v = *(const T8*)(base + (int64_t)r * p.x_ss[1]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += to_f(v[j]);
+    ++cnt;
+  }
+  __shared__ float red[16][D + 1];
+  __shared__ int cred[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = s[i];
+  if (cc == 0) cred[rl] = cnt;
+  __syncthreads();
+  if (t < D) {
+    float a = 0.f;
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { a += red[j][t]; n += cred[j]; }
+    kmean_of(p)[h * D + t] = n > 0 ? a / (float)n : 0.f;
+  }
+}
+
+// grid (row chunks, heads or 1, 3): per-head abs-max of q and k (k minus its centre), per-(head, channel) abs-max of v
 template <typename T>
 __global__ __launch_bounds__(256) void fp8_absmax_kernel(const QParams p) {
   typedef __attribute__((ext_vector_type(8))) T T8;
-  const int which = blockIdx.z, h = blockIdx.y;
+  const int which = blockIdx.z;
+  int r0, r1, h, hphys;
+  block_rows(p, r0, r1, h, hphys);
+  if (r0 >= r1) return;
   const int t = threadIdx.x, cc = t & 15, rl = t >> 4;
-  const int r0 = blockIdx.x * p.rows_per_block, r1 = min(r0 + p.rows_per_block, p.n_tokens);
-  const char* base = p.x[which] + (int64_t)h * p.x_sh[which] + cc * 16;
+  const char* base = p.x[which] + (int64_t)hphys * p.x_sh[which] + cc * 16;
+  float c[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c[i] = 0.f;
+  if (which == 1 && p.center_k) {
+    const float* km = kmean_of(p) + h * D + cc * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c[i] = km[i];
+  }
   float m[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) m[i] = 0.f;
   for (int r = r0 + rl; r < r1; r += 16) {
     const T8 v = *(const T8*)(base + (int64_t)r * p.x_ss[which]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(to_f(v[i])));
+    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(to_f(v[i]) - c[i]));
   }
   __shared__ float red[16][D + 1];
 #pragma unroll
@@ -100,15 +184,19 @@ __global__ __launch_bounds__(128) void fp8_scales_kernel(const QParams p) {
 
 __device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -E4M3_MAX, E4M3_MAX); }
 
-// grid (row chunks, heads, 3): thread = 16 channels of a row (32 B in, 16 B out); 8 threads per row, 32 rows per pass
+// grid (row chunks, heads or 1, 3): thread = 16 channels of a row (32 B in, 16 B out); 8 threads per row, 32 rows per pass
 template <typename T>
 __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
   typedef __attribute__((ext_vector_type(8))) T T8;
-  const int which = blockIdx.z, h = blockIdx.y, H = p.heads;
+  const int which = blockIdx.z, H = p.heads;
+  int r0, r1, h, hphys;
+  block_rows(p, r0, r1, h, hphys);
+  if (r0 >= r1) return;
   const int t = threadIdx.x, cc = t & 7, rl = t >> 3;
-  const int r0 = blockIdx.x * p.rows_per_block, r1 = min(r0 + p.rows_per_block, p.n_tokens);
   const float* qmul = p.ws + 2 * H + H * D;
-  float mul[16];
+  float mul[16], sub[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sub[i] = 0.f;
   if (which == 2) {
     const float* vm = qmul + 2 * H + h * D + cc * 16;
 #pragma unroll
@@ -117,15 +205,23 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
     const float s = qmul[which * H + h];
 #pragma unroll
     for (int i = 0; i < 16; ++i) mul[i] = s;
+    if (which == 1 && p.center_k) {
+      const float* km = kmean_of(p) + h * D + cc * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sub[i] = km[i];
+    }
   }
-  const char* src = p.x[which] + (int64_t)h * p.x_sh[which] + cc * 32;
-  char* dst = p.y[which] + (int64_t)h * p.y_sh[which] + cc * 16;
+  const char* src = p.x[which] + (int64_t)hphys * p.x_sh[which] + cc * 32;
+  char* dst = p.y[which] + (int64_t)hphys * p.y_sh[which] + cc * 16;
   for (int r = r0 + rl; r < r1; r += 32) {
     const T8 a = *(const T8*)(src + (int64_t)r * p.x_ss[which]);
     const T8 b = *(const T8*)(src + (int64_t)r * p.x_ss[which] + 16);
     float f[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { f[i] = clamp448(to_f(a[i]) * mul[i]); f[8 + i] = clamp448(to_f(b[i]) * mul[8 + i]); }
+    for (int i = 0; i < 8; ++i) {
+      f[i] = clamp448((to_f(a[i]) - sub[i]) * mul[i]);
+      f[8 + i] = clamp448((to_f(b[i]) - sub[8 + i]) * mul[8 + i]);
+    }
     u32x4 o;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -140,14 +236,15 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
 
 extern "C" int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim) {
   if (heads <= 0 || head_dim != D) return VORTA_EINVAL;
-  return 2 * (2 * heads + heads * head_dim);
+  return 2 * (2 * heads + heads * head_dim) + heads * head_dim;
 }
 
 extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_stream) {
   if (!a || a->struct_size != sizeof(vorta_fp8_quant_args)) return VORTA_EINVAL;
   if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
   if (a->head_dim != D) return VORTA_EUNSUPPORTED;
-  if (a->heads < 0 || a->n_tokens < 0) return VORTA_EINVAL;
+  if (a->heads < 0 || a->n_tokens < 0 || a->seg_len < 0 || a->tail_first < 0 || a->tail_len < 0) return VORTA_EINVAL;
+  if (a->seg_len > 0 && a->tail_len > 0 && (a->tail_first % a->seg_len || a->tail_len > a->seg_len)) return VORTA_EINVAL;
   if (a->heads == 0 || a->n_tokens == 0) return VORTA_OK;
   if (!a->ws || !a->v_descale || !(a->qk_scale > 0.f)) return VORTA_EINVAL;
   const vorta_tensor* in[3] = {&a->q, &a->k, &a->v};
@@ -164,22 +261,46 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   p.c0 = a->qk_scale * 1.4426950408889634f;
   p.ws = a->ws; p.v_descale = a->v_descale;
   p.v_per_head = a->flags & 1;
+  p.center_k = (a->flags >> 1) & 1;
+  p.seg_len = a->seg_len;
+  p.tail_first = a->seg_len > 0 && a->tail_len > 0 ? a->tail_first : 0x7fffffff;
+  p.tail_len = a->tail_len;
   hipStream_t st = (hipStream_t)hip_stream;
   const int H = a->heads;
   hipError_t e = hipMemsetAsync(a->ws, 0, sizeof(float) * (2 * H + H * D), st);
   if (e != hipSuccess) return vorta_set_hip_error(e);
   // enough workgroups to fill the chip several times over, few enough that the atomics stay cheap
   p.rows_per_block = 1024;
-  const unsigned chunks = (unsigned)((a->n_tokens + p.rows_per_block - 1) / p.rows_per_block);
-  const dim3 grid(chunks, (unsigned)H, 3);
-  if (a->dtype == VORTA_BF16) hipLaunchKernelGGL((fp8_absmax_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  dim3 grid;
+  if (p.seg_len > 0) {
+    p.chunks_per_seg = (p.seg_len + p.rows_per_block - 1) / p.rows_per_block;
+    const int64_t n_seg = ((int64_t)a->n_tokens + p.seg_len - 1) / p.seg_len;
+    if (n_seg * p.chunks_per_seg > 0x7fffffffll) return VORTA_EINVAL;
+    grid = dim3((unsigned)(n_seg * p.chunks_per_seg), 1, 3);
+    p.mean_stride = (int)((int64_t)a->n_tokens / ((int64_t)MEAN_SAMPLES * H));
+  } else {
+    p.chunks_per_seg = 1;
+    grid = dim3((unsigned)((a->n_tokens + p.rows_per_block - 1) / p.rows_per_block), (unsigned)H, 3);
+    p.mean_stride = a->n_tokens / MEAN_SAMPLES;
+  }
+  if (p.mean_stride < 1) p.mean_stride = 1;
+  // an odd stride: a stride that divides the segment length would sample the same offsets of every segment
+  p.mean_stride |= 1;
+  const bool bf = a->dtype == VORTA_BF16;
+  if (p.center_k) {
+    if (bf) hipLaunchKernelGGL((fp8_kmean_kernel<__bf16>), dim3((unsigned)H), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fp8_kmean_kernel<_Float16>), dim3((unsigned)H), dim3(256), 0, st, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return vorta_set_hip_error(e);
+  }
+  if (bf) hipLaunchKernelGGL((fp8_absmax_kernel<__bf16>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fp8_absmax_kernel<_Float16>), grid, dim3(256), 0, st, p);
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
   hipLaunchKernelGGL(fp8_scales_kernel, dim3((unsigned)H), dim3(128), 0, st, p);
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
-  if (a->dtype == VORTA_BF16) hipLaunchKernelGGL((fp8_convert_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  if (bf) hipLaunchKernelGGL((fp8_convert_kernel<__bf16>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fp8_convert_kernel<_Float16>), grid, dim3(256), 0, st, p);
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);

@@ -314,25 +314,43 @@ class Fp8Operands:
         base = 2 * H + H * D
         return self.ws[base:base + H], self.ws[base + H:base + 2 * H], self.ws[base + 2 * H:base + 2 * H + H * D].view(H, D)
 
+    def k_center(self):
+        """(H,D) vector subtracted from every key of a head before the conversion (zeros unless centring was asked for)"""
+        H, D = self.v_descale.shape
+        base = 2 * (2 * H + H * D)
+        return self.ws[base:base + H * D].view(H, D)
+
 
 def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, *,
-                     out: Optional[Fp8Operands] = None, v_per_head: bool = False) -> Fp8Operands:
+                     out: Optional[Fp8Operands] = None, v_per_head: bool = False, center_k: bool = False,
+                     heads: Optional[int] = None, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0) -> Fp8Operands:
     """vorta_fp8_quantize_qkv: (H,S,D) bf16/fp16 views -> e4m3 copies (contiguous (H,S,D) uint8) with the softmax scale
-    and log2(e) folded into q/k.  `out` = a previous result to overwrite (same shapes)."""
+    and log2(e) folded into q/k.  `out` = a previous result to overwrite (same shapes).  `center_k`: subtract a per-head
+    centre from the keys first (softmax-invariant; see include/vorta_hip.h).  `seg_len > 0`: q,k,v are (1,rows,D) row
+    arrays in which row r belongs to head (r // seg_len) % heads (the Ulysses receive layout); from row `tail_first` on
+    only the first `tail_len` rows of a segment hold data."""
     _require_gpu(q, k, v)
     if q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype):
         raise ValueError("q,k,v must share dtype bf16 or fp16")
     if not (q.shape == k.shape == v.shape) or q.dim() != 3:
         raise ValueError("fp8_quantize_qkv takes (H,S,D) views of equal shape")
-    H, S, D = q.shape
+    Hx, S, D = q.shape
+    if seg_len > 0:
+        if Hx != 1 or not heads or heads < 1:
+            raise ValueError("fp8_quantize_qkv: the segmented layout takes (1,rows,D) row arrays and the number of heads")
+        H = heads
+    else:
+        if heads not in (None, Hx):
+            raise ValueError("fp8_quantize_qkv: `heads` only applies to the segmented layout")
+        H = Hx
     dev = q.device
     nws = _C.lib().vorta_fp8_quant_ws_floats(H, D)
     if nws < 0:
         raise ValueError(f"fp8_quantize_qkv: unsupported head_dim {D}")
     if out is None:
-        out = Fp8Operands(*(torch.empty((H, S, D), dtype=FP8_STORAGE, device=dev) for _ in range(3)),
+        out = Fp8Operands(*(torch.empty((Hx, S, D), dtype=FP8_STORAGE, device=dev) for _ in range(3)),
                           torch.empty((H, D), dtype=torch.float32, device=dev),
-                          torch.empty(nws, dtype=torch.float32, device=dev))
+                          torch.zeros(nws, dtype=torch.float32, device=dev))
     a = _C.Fp8QuantArgs()
     a.struct_size = C.sizeof(_C.Fp8QuantArgs)
     a.dtype, a.head_dim, a.heads, a.n_tokens = _DT[q.dtype], D, H, S
@@ -340,7 +358,8 @@ def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: O
     a.q, a.k, a.v = _tensor(q), _tensor(k), _tensor(v)
     a.q8, a.k8, a.v8 = _tensor(out.q), _tensor(out.k), _tensor(out.v)
     a.v_descale, a.ws = out.v_descale.data_ptr(), out.ws.data_ptr()
-    a.flags = 1 if v_per_head else 0
+    a.flags = (1 if v_per_head else 0) | (2 if center_k else 0)
+    a.seg_len, a.tail_first, a.tail_len = seg_len, tail_first, tail_len
     _C.check(_C.lib().vorta_fp8_quantize_qkv(C.byref(a), _stream()), "vorta_fp8_quantize_qkv")
     return out
 

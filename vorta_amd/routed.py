@@ -148,6 +148,9 @@ STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
 # process-wide default of `routed_attention(fp8=None)`: the processors of vorta.attention call it that way, so the
 # unchanged inference scripts pick the e4m3 path up from the environment or from `set_attention_precision("fp8")`
 DEFAULT_FP8 = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower() == "fp8"
+# the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
+# the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
+FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
 
 
 def set_attention_precision(precision: str) -> None:
@@ -220,7 +223,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     if fp8_views is not None:
         base = dict(q=fp8_views[0], k=fp8_views[1], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
     elif fp8:
-        f8 = ops.fp8_quantize_qkv(q3, k3, v3, scale, out=fp8_operands)
+        f8 = ops.fp8_quantize_qkv(q3, k3, v3, scale, out=fp8_operands, center_k=FP8_CENTER_K)
         base = dict(q=f8.q, k=f8.k, v=f8.v, scale=scale, v_descale=f8.v_descale)
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----

@@ -121,13 +121,16 @@ class UlyssesLayout:
 
     def fp8_views(self, bufs: Sequence[torch.Tensor], scale: Optional[float] = None, out=None):
         """e4m3 copies of the q, k, v receive buffers for the fp8 attention kernels: ONE conversion of each whole buffer
-        (the head views overlap, so converting per head would redo it Hl times), hence one q/k scale pair and one
-        per-channel v scale for all local heads.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
+        (the head views overlap, so converting per view would redo it Hl times) in the quantiser's segmented row layout
+        -- row r belongs to head slot (r // Sl) % Hl, text rows behind the video rows -- so every local head keeps its
+        own scales and key centre.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
+        from ..routed import FP8_CENTER_K
         x = [b.view(1, self.rows_total, self.D) for b in bufs[:3]]
-        f8 = ops.fp8_quantize_qkv(*x, scale, out=out)
+        f8 = ops.fp8_quantize_qkv(*x, scale, out=out, center_k=FP8_CENTER_K, heads=self.Hl, seg_len=self.Sl,
+                                  tail_first=self.rows_video, tail_len=self.T)
         shape, stride = (self.Hl, self.rows_total - (self.Hl - 1) * self.Sl, self.D), (self.Sl * self.D, self.D, 1)
         hv = lambda t: t[0].as_strided(shape, stride)
-        return hv(f8.q), hv(f8.k), hv(f8.v), f8.v_descale.expand(self.Hl, self.D).contiguous(), f8
+        return hv(f8.q), hv(f8.k), hv(f8.v), f8.v_descale, f8
 
     def head_view(self, buf: torch.Tensor) -> torch.Tensor:
         """(Hl, rows, D) overlapping view: head slot i starts i*Sl rows into the buffer."""
