@@ -14,7 +14,8 @@
 // scales and centre although the head views of that buffer overlap); from row tail_first on only the first tail_len
 // rows of a segment hold data (the text rows behind each head slot), the rest is skipped.
 //
-// Workspace (floats): amax_q[H] | amax_k[H] | amax_v[H][D] | qmul[H] | kmul[H] | vmul[H][D] | kmean[H][D]
+// Workspace (floats): amax_q[H] | amax_k[H] | amax_v[H][D] | qmul[H] | kmul[H] | vmul[H][D] | kmean[H][D] |
+//                     ksum[H][MEAN_BLOCKS][D] | kcnt[H][MEAN_BLOCKS]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,6 +28,7 @@ constexpr int D = 128;
 constexpr float V_TARGET = 240.f;  // amax of a v channel maps here (e4m3 max 448; relative precision is range-independent)
 constexpr float E4M3_MAX = 448.f;
 constexpr int MEAN_SAMPLES = 1024;  // key rows per head that define the centre (approximately: see fp8_kmean_kernel)
+constexpr int MEAN_BLOCKS = 8;      // workgroups per head that sum them (partial sums, combined in a fixed order)
 
 struct QParams {
   const char* x[3]; int64_t x_sh[3], x_ss[3];  // inputs (bytes)
@@ -43,6 +45,17 @@ struct QParams {
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
 
 __device__ __forceinline__ float* kmean_of(const QParams& p) { return p.ws + 2 * (2 * p.heads + p.heads * D); }
+__device__ __forceinline__ float* ksum_of(const QParams& p) { return kmean_of(p) + p.heads * D; }
+__device__ __forceinline__ float* kcnt_of(const QParams& p) { return ksum_of(p) + p.heads * MEAN_BLOCKS * D; }
+// centre of channel d of head h from the partial sums: the same expression wherever it is needed (bit-identical)
+__device__ __forceinline__ float kcenter(const QParams& p, int h, int d) {
+  const float* ks = ksum_of(p) + (int64_t)h * MEAN_BLOCKS * D + d;
+  const float* kc = kcnt_of(p) + h * MEAN_BLOCKS;
+  float a = 0.f, n = 0.f;
+#pragma unroll
+  for (int b = 0; b < MEAN_BLOCKS; ++b) { a += ks[b * D]; n += kc[b]; }
+  return n > 0.f ? a / n : 0.f;
+}
 
 // the rows a block works on: [r0, r1) of head `head`, stored under physical head index `hphys`
 __device__ __forceinline__ void block_rows(const QParams& p, int& r0, int& r1, int& head, int& hphys) {
@@ -61,11 +74,13 @@ __device__ __forceinline__ void block_rows(const QParams& p, int& r0, int& r1, i
   }
 }
 
-// grid (heads), 256 threads: centre of the head's keys = mean over the candidate rows r = i * mean_stride that belong to
-// the head (all of them in the (H,S,D) layout).  16 row lanes x 16 channel groups; fixed reduction order.
+// grid (heads, MEAN_BLOCKS), 1024 threads: partial sums for the centre of the head's keys = mean over the candidate rows
+// r = i * mean_stride that belong to the head (all of them in the (H,S,D) layout).  64 row lanes x 16 channel groups,
+// four rows in flight per lane; fixed reduction order here and in `kcenter` (deterministic).
 template <typename T>
-__global__ __launch_bounds__(256) void fp8_kmean_kernel(const QParams p) {
+__global__ __launch_bounds__(1024) void fp8_kmean_kernel(const QParams p) {
   typedef __attribute__((ext_vector_type(8))) T T8;
+  constexpr int RL = 64;
   const int h = blockIdx.x;
   const int t = threadIdx.x, cc = t & 15, rl = t >> 4;
   const char* base = p.x[1] + (p.seg_len > 0 ? 0 : (int64_t)h * p.x_sh[1]) + cc * 16;
@@ -74,19 +89,30 @@ __global__ __launch_bounds__(256) void fp8_kmean_kernel(const QParams p) {
   for (int i = 0; i < 8; ++i) s[i] = 0.f;
   int cnt = 0;
   const int n_cand = (p.n_tokens + p.mean_stride - 1) / p.mean_stride;
-  for (int i = rl; i < n_cand; i += 16) {
-    const int r = i * p.mean_stride;
-    if (p.seg_len > 0) {
-      const int seg = r / p.seg_len;
-      if (seg % p.heads != h || (r >= p.tail_first && r - seg * p.seg_len >= p.tail_len)) continue;
-    }
-    const T8 v = *(const T8*)(base + (int64_t)r * p.x_ss[1]);
+  auto mine = [&](int i) -> bool {
+    if (i >= n_cand) return false;
+    if (p.seg_len <= 0) return true;
+    const int r = i * p.mean_stride, seg = r / p.seg_len;
+    return seg % p.heads == h && !(r >= p.tail_first && r - seg * p.seg_len >= p.tail_len);
+  };
+  for (int i0 = blockIdx.y * 4 * RL + rl; i0 < n_cand; i0 += MEAN_BLOCKS * 4 * RL) {
+    T8 v[4];
+    bool ok[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] += to_f(v[j]);
-    ++cnt;
+    for (int u = 0; u < 4; ++u) {
+      ok[u] = mine(i0 + u * RL);
+      if (ok[u]) v[u] = *(const T8*)(base + (int64_t)(i0 + u * RL) * p.mean_stride * p.x_ss[1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += to_f(v[u][j]);
+        ++cnt;
+      }
   }
-  __shared__ float red[16][D + 1];
-  __shared__ int cred[16];
+  __shared__ float red[RL][D + 1];
+  __shared__ int cred[RL];
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = s[i];
   if (cc == 0) cred[rl] = cnt;
@@ -94,9 +120,9 @@ __global__ __launch_bounds__(256) void fp8_kmean_kernel(const QParams p) {
   if (t < D) {
     float a = 0.f;
     int n = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) { a += red[j][t]; n += cred[j]; }
-    kmean_of(p)[h * D + t] = n > 0 ? a / (float)n : 0.f;
+    for (int j = 0; j < RL; ++j) { a += red[j][t]; n += cred[j]; }
+    ksum_of(p)[((int64_t)h * MEAN_BLOCKS + blockIdx.y) * D + t] = a;
+    if (t == 0) kcnt_of(p)[h * MEAN_BLOCKS + blockIdx.y] = (float)n;
   }
 }
 
@@ -114,9 +140,8 @@ __global__ __launch_bounds__(256) void fp8_absmax_kernel(const QParams p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) c[i] = 0.f;
   if (which == 1 && p.center_k) {
-    const float* km = kmean_of(p) + h * D + cc * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) c[i] = km[i];
+    for (int i = 0; i < 8; ++i) c[i] = kcenter(p, h, cc * 8 + i);
   }
   float m[8];
 #pragma unroll
@@ -180,6 +205,7 @@ __global__ __launch_bounds__(128) void fp8_scales_kernel(const QParams p) {
   }
   vmul[h * D + d] = mv > 0.f ? V_TARGET / mv : 0.f;
   p.v_descale[h * D + d] = mv / V_TARGET;
+  kmean_of(p)[h * D + d] = p.center_k ? kcenter(p, h, d) : 0.f;
 }
 
 __device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -E4M3_MAX, E4M3_MAX); }
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) mul[i] = s;
     if (which == 1 && p.center_k) {
-      const float* km = kmean_of(p) + h * D + cc * 16;
+      const float* km = kmean_of(p) + h * D + cc * 16;  // written by the scales kernel (= kcenter)
 #pragma unroll
       for (int i = 0; i < 16; ++i) sub[i] = km[i];
     }
@@ -236,7 +262,7 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
 
 extern "C" int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim) {
   if (heads <= 0 || head_dim != D) return VORTA_EINVAL;
-  return 2 * (2 * heads + heads * head_dim) + heads * head_dim;
+  return 2 * (2 * heads + heads * head_dim) + heads * head_dim + heads * MEAN_BLOCKS * (head_dim + 1);
 }
 
 extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_stream) {
@@ -288,8 +314,8 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   p.mean_stride |= 1;
   const bool bf = a->dtype == VORTA_BF16;
   if (p.center_k) {
-    if (bf) hipLaunchKernelGGL((fp8_kmean_kernel<__bf16>), dim3((unsigned)H), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((fp8_kmean_kernel<_Float16>), dim3((unsigned)H), dim3(256), 0, st, p);
+    if (bf) hipLaunchKernelGGL((fp8_kmean_kernel<__bf16>), dim3((unsigned)H, MEAN_BLOCKS), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((fp8_kmean_kernel<_Float16>), dim3((unsigned)H, MEAN_BLOCKS), dim3(1024), 0, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return vorta_set_hip_error(e);
   }
