@@ -96,3 +96,33 @@ def test_bandwidth_at_a_rank_of_eight():
     tbs = 6 * H * Sl * 256 / ms / 1e9
     print(f"permute_heads: {ms * 1e3:.0f} us, {tbs:.2f} TB/s")
     assert tbs > 2.0
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_exchange_engine_on_device_equals_the_cpu_engine(groups):
+    """ulysses/engine.py on device tensors takes the vorta_permute_heads passes (send staging, text rows, output
+    un-permute, text scatter); on CPU tensors the torch index ops.  Same data, one rank (P = 1, every pass still runs
+    because the head order is a permutation): identical buffers and outputs."""
+    from vorta_amd.ulysses import UlyssesLayout, exchange_and_attend, slot_groups
+    H, S, T, D = 6, 192, 7, 128
+    order = [3, 0, 5, 1, 4, 2]
+    g = torch.Generator().manual_seed(0)
+    shards_c = [torch.randn((S, H, D), generator=g).to(torch.bfloat16).transpose(0, 1) for _ in range(3)]
+    texts_c = [torch.randn((H, T, D), generator=g).to(torch.bfloat16) for _ in range(3)]
+    res = {}
+    for device in ("cpu", dev()):
+        lay = UlyssesLayout(H, S, T, D, 1, 0, device, torch.bfloat16)
+        shards = [x.transpose(0, 1).contiguous().to(device).transpose(0, 1) for x in shards_c]  # keep the (S,H,D) storage
+        texts = [x.to(device) for x in texts_c]
+        b = [lay.new_buffer() for _ in range(4)]
+
+        def attend(g0, g1, gi):
+            lay.head_view(b[3])[g0:g1].copy_(lay.head_view(b[0])[g0:g1])
+
+        o = torch.zeros((S, H, D), dtype=torch.bfloat16, device=device).transpose(0, 1)
+        t = torch.zeros((H, T, D), dtype=torch.bfloat16, device=device)
+        exchange_and_attend(lay, shards, b, order, texts, slot_groups(lay.Hl, groups), attend, o, t)
+        res[str(device)] = [x.cpu() for x in (*b[:3], o, t)]
+    for x, y in zip(*res.values()):
+        assert torch.equal(x, y)
+    assert torch.equal(res["cpu"][3], shards_c[0]) and torch.equal(res["cpu"][4], texts_c[0])
