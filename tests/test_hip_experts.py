@@ -407,7 +407,9 @@ def test_full_size_coreset_properties():
 
 
 def test_fused_layer_launch_matches_separate_launches():
-    """All experts of a layer as ONE grid (vorta_attn_fwd_batch) vs one launch per expert: bit-identical."""
+    """All experts of a layer as ONE grid (vorta_attn_fwd_batch) vs one launch per expert: bit-identical, except the text
+    rows of the sliding heads -- the fused grid runs that segment unsplit (scheduled first), the stand-alone launch cuts
+    its keys and combines partials (another summation order)."""
     from vorta_amd import ops
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
     dtype = torch.bfloat16
@@ -426,12 +428,16 @@ def test_fused_layer_launch_matches_separate_launches():
     assert [r[1] for r in tl.records] == ["attn_fwd_multi_kernel<__bf16>"]  # really one grid
     b = routed_attention(q, k, v, route, geom, model="hunyuan", text_len=T, text_valid=te, fused=False)
     torch.cuda.synchronize()
-    assert torch.equal(a, b)
+    sliding = [2, 3]
+    others = [0, 1, 4, 5]
+    assert torch.equal(a[0, others], b[0, others]) and torch.equal(a[0, sliding, :Sx], b[0, sliding, :Sx])
+    assert rel_fro(a[0, sliding, Sx:].float().cpu().numpy(), b[0, sliding, Sx:].float().cpu().numpy()) < 4e-3
     gi = O.group_info(latent, group, 0.5)
     ref = O.routed_attention(rounded(q.float().cpu().numpy(), dtype), rounded(k.float().cpu().numpy(), dtype),
                              rounded(v.float().cpu().numpy(), dtype), np.array([0, 1, 2, 2, 0, 1]), model="hunyuan",
                              latent=latent, tile=tile, window=WINDOW, gi=gi, t_text=T, t_eff=te)
     check(a[0], ref[0], dtype)
+    check(b[0], ref[0], dtype)
     # device-resident routing through the fused grid as well
     _, lists, counts = ops.route_scores(torch.eye(3, device=dev())[torch.tensor([0, 1, 2, 2, 0, 1])][None], 0.3)
     c = routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,

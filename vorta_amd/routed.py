@@ -151,6 +151,10 @@ DEFAULT_FP8 = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lowe
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
 # the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
 FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
+# fused grid: the sliding expert's text-query segment goes first with at most this many key splits (0: as round 1 -- last,
+# with the stand-alone launch's split count; A/B)
+FUSED_TEXT_SPLITS = int(__import__("os").environ.get("VORTA_FUSED_TEXT_SPLITS", "1"))
+FUSED_TEXT_FIRST = FUSED_TEXT_SPLITS > 0
 
 
 def set_attention_precision(precision: str) -> None:
@@ -283,6 +287,16 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     if not concurrent:
         calls = [c for fn, on in experts if on for c in fn()]
         if fused:
+            if FUSED_TEXT_FIRST:
+                # the text-query launch of the sliding expert (one query block per head against every key) does not have
+                # to fill the chip inside a fused grid, only not to be its tail: scheduled FIRST and unsplit it is as long
+                # as a full-attention workgroup, with no partials to write and no combine launch (the stand-alone launch
+                # cuts the keys 64-232 ways).  Measured on one box, splits 0(last, auto) / 8 / 4 / 2 / 1: rank of 8
+                # 549.5 / 542.2 / 540.0 | 557.0 (4) / 553.9 / 552.8 ms; one GPU 4 130 / 4 115 (8) | 4 226 (4) / 4 208 (1)
+                for c in calls:
+                    if c.get("tag") == "sliding_text":
+                        c["n_splits"] = min(c["n_splits"], FUSED_TEXT_SPLITS)
+                calls.sort(key=lambda c: c.get("tag") != "sliding_text")
             ops.attn_fwd_batch(calls)
         else:
             launch(calls)
