@@ -227,3 +227,54 @@ def test_config4_one_rank_of_eight_fp8_at_full_size():
         mse = ((a[i] - b[i]) ** 2).mean().item()
         psnr = 10 * math.log10((b[i].max() - b[i].min()).item() ** 2 / mse)
         assert psnr >= 40.0, (i, psnr)
+
+
+def test_hunyuan_129f_fp8_with_text_and_biased_keys_at_full_size():
+    """The e4m3 path on the headline geometry (S = 118 800, text 256 / 96 valid) through the Ulysses receive layout of a
+    rank of 8 (3 heads, per-head scales and key centres from the segmented quantiser) -- one head per expert, keys with a
+    3-sigma common component: operator PSNR >= 40 dB per expert against the fp16 kernels, valid text rows included; the
+    padded text rows are exactly zero."""
+    import math
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    from vorta_amd.ulysses import UlyssesLayout
+    dtype = torch.float16
+    H, P, rank = 24, 8, 2
+    latent, tile, group = (33, 45, 80), (11, 9, 8), (3, 3, 2)
+    S, T, te = 33 * 45 * 80, 256, 96
+    lay = UlyssesLayout(H, S, T, 128, P, rank, dev(), dtype)
+    Hl, Sl = lay.Hl, lay.Sl
+    bufs = []
+    for i in range(3):
+        b = lay.new_buffer()
+        x = _rand((lay.rows_total, 128), 700 + i, dtype)
+        if i == 1:  # keys: every head slot gets its own common component
+            seg = (torch.arange(lay.rows_total, device=dev()) // Sl) % Hl
+            bias = 3.0 * _rand((Hl, 128), 710, torch.float32)
+            x = (x.float() + bias[seg]).to(dtype)
+        b[:lay.rows_video] = x[:lay.rows_video]
+        for s in range(Hl):
+            b[lay.rows_video + s * Sl: lay.rows_video + s * Sl + T] = x[lay.rows_video + s * Sl: lay.rows_video + s * Sl + T]
+        bufs.append(b)
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev(), row_map=lay.row_map)
+    route = HeadRouting.from_expert_ids([0, 1, 2], dev())
+    views = [lay.head_view(b) for b in bufs]
+    ref, out = lay.new_buffer(), lay.new_buffer()
+    routed_attention(*views, route, geom, model="hunyuan", text_len=T, text_valid=te, out=lay.head_view(ref), fp8=False)
+    q8, k8, v8, vd, f8 = lay.fp8_views(bufs)
+    c = f8.k_center()
+    assert vd.shape == (Hl, 128) and float((c - bias).abs().max()) < 0.5  # each slot's own centre, near its own bias
+    routed_attention(*views, route, geom, model="hunyuan", text_len=T, text_valid=te, out=lay.head_view(out), fp8=False,
+                     fp8_views=(q8, k8, v8, vd))
+    torch.cuda.synchronize()
+    rm = lay.row_map.long()
+    a, b = lay.head_view(out)[:, rm].float(), lay.head_view(ref)[:, rm].float()  # (Hl, S + T, D) in token order
+    assert not torch.isnan(a).any()
+    assert (a[:, S + te:] == 0).all() and (b[:, S + te:] == 0).all()
+    table = {}
+    for i, name in enumerate(("full", "coreset", "sliding-tile")):
+        for part, sl in (("video", slice(0, S)), ("text", slice(S, S + te))):
+            mse = ((a[i, sl] - b[i, sl]) ** 2).mean().item()
+            table[f"{name}/{part}"] = 10 * math.log10((b[i, sl].max() - b[i, sl].min()).item() ** 2 / mse)
+    print("fp8 vs fp16, Hunyuan-129f geometry, keys with a 3-sigma common component (PSNR over data range, dB):",
+          {n: round(p, 2) for n, p in table.items()})
+    assert min(table.values()) >= 40.0, table
