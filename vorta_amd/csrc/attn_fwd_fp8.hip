@@ -64,8 +64,18 @@ template <typename TO> struct OutT;
 template <> struct OutT<__bf16> { using v4 = bf16x4; };
 template <> struct OutT<_Float16> { using v4 = f16x4; };
 
-// LDS: K ring of 2 tiles, V ring of 3 tiles (8 KiB each).
+// LDS: K ring of 2 tiles, V ring of 3 tiles (8 KiB each), one workgroup barrier per key block.
+// -DVORTA_SYNC2=1: rings of 4 + 4 tiles and one barrier per TWO key blocks (block j requests K(j+3) and V(j+1); everything a
+// block reads was requested at least two blocks earlier, and the barrier behind every odd block separates the last read
+// of a slot from the request that refills it).
+#ifndef VORTA_SYNC2
+#define VORTA_SYNC2 0
+#endif
+#if VORTA_SYNC2
+constexpr int K_SLOTS = 4, V_SLOTS = 4;
+#else
 constexpr int K_SLOTS = 2, V_SLOTS = 3;
+#endif
 constexpr int SMEM8 = (K_SLOTS + V_SLOTS) * TILE8;
 
 template <typename TO, int NW, bool KVTAB, bool LMFMA>
@@ -144,6 +154,9 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     v_col[i] = ((lane & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4;
   }
   int rowK[CH], rowV[CH];
+#if VORTA_SYNC2
+  int rowV1[CH];  // V lags K by two blocks: rows(j+3) -> rowV1 -> rowV
+#endif
 #define ROWS_OF(dst_, blk_)                                                       \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
     const int pos_ = min((blk_) * KVB + 8 * (CH * lwave + i_) + (lane >> 3), n_kv - 1); \
@@ -338,6 +351,16 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #if defined(VORTA_DIAG_NODMA)
 #define STAGE_DMA(kw_, vw_, jabs_)
 #else
+#if VORTA_SYNC2
+#define STAGE_DMA(kw_, vw_, jabs_)                                                \
+  if (loader) {                                                                   \
+    DMA_K(kw_)                                                                    \
+    DMA_V(vw_)                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) { rowV[i_] = rowV1[i_]; rowV1[i_] = rowK[i_]; } \
+    ROWS_OF(rowK, (jabs_) + 4)                                                    \
+  }                                                                               \
+  __builtin_amdgcn_sched_barrier(0);
+#else
 #define STAGE_DMA(kw_, vw_, jabs_)                                                \
   if (loader) {                                                                   \
     DMA_K(kw_)                                                                    \
@@ -346,6 +369,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     ROWS_OF(rowK, (jabs_) + 3)                                                    \
   }                                                                               \
   __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
 #if defined(VORTA_DIAG_NOBAR)  // timing diagnostics only (results are wrong): no workgroup barrier / no wait at all
 #define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -455,7 +479,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #else
 #define TR_(i_)
 #endif
-#define STEP(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_)                       \
+#define STEP_(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_, sync_)                \
   {                                                                               \
     TR_(0)                                                                        \
     STAGE_DMA(kw_, vw_, jabs_)                                                    \
@@ -468,8 +492,9 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
       TR_(2)                                                                      \
       if (!role_y) VALU_PART(c0_, c1_, n0_, n1_)                                  \
     }                                                                             \
-    STEP_SYNC()                                                                   \
+    if constexpr (sync_) { STEP_SYNC() }                                          \
   }
+#define STEP(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_) STEP_(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_, true)
 
   const int nsteps = blk1 - blk0;
 #if defined(VORTA_DIAG_ALLX)
@@ -481,6 +506,22 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
 #endif
   if (nsteps > 0) {
+#if VORTA_SYNC2
+    // ---- prologue: K(0), V(0), K(1), K(2); the scores of block 0 fix the reference point ----
+    if (loader) {
+      ROWS_OF(rowK, blk0)
+      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
+      DMA_K(0)
+      DMA_V(0)
+      ROWS_OF(rowK, blk0 + 1)
+      DMA_K(1)
+      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];   // rows(1): V(1), requested by step 0
+      ROWS_OF(rowK, blk0 + 2)
+      DMA_K(2)
+      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV1[i_] = rowK[i_];  // rows(2): V(2), requested by step 1
+      ROWS_OF(rowK, blk0 + 3)
+    }
+#else
     // ---- prologue: K(0), V(0), K(1); the scores of block 0 fix the reference point ----
     if (loader) {
       ROWS_OF(rowK, blk0)
@@ -492,6 +533,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
       _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
       ROWS_OF(rowK, blk0 + 2)
     }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave_active) {
@@ -509,7 +551,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     __syncthreads();  // every wave has read K(0) before its slot is overwritten
     {  // step 0: no PV yet -- the scores of block 1, then (first role) the VALU part of block 0
       TR_(0)
-      STAGE_DMA(0, 1, blk0)
+      STAGE_DMA(VORTA_SYNC2 ? 3 : 0, 1, blk0)
       if (wave_active) {
         TR_(1)
         KFRAGS0(1)
@@ -519,8 +561,23 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
         TR_(2)
         if (!role_y) VALU_PART(sA0, sA1, sB0, sB1)
       }
+#if !VORTA_SYNC2  // (with the deeper rings step 1 reads and refills nothing that step 0 touches)
       STEP_SYNC()
+#endif
     }
+#if VORTA_SYNC2
+    // slots of step j: K written (j+3)&3, K read (j+1)&3, V written (j+1)&3, V read (j+3)&3; a barrier behind odd steps
+    for (int jj = 1; jj < nsteps; jj += 4) {
+      STEP_(sB0, sB1, sA0, sA1, 0, 2, 2, 0, blk0 + jj, true)
+      if (jj + 1 >= nsteps) break;
+      STEP_(sA0, sA1, sB0, sB1, 1, 3, 3, 1, blk0 + jj + 1, false)
+      if (jj + 2 >= nsteps) break;
+      STEP_(sB0, sB1, sA0, sA1, 2, 0, 0, 2, blk0 + jj + 2, true)
+      if (jj + 3 >= nsteps) break;
+      STEP_(sA0, sA1, sB0, sB1, 3, 1, 1, 3, blk0 + jj + 3, false)
+    }
+    STEP_SYNC()  // the last block's V tile may have been requested behind the last barrier
+#else
     // K slots cycle with period 2, V slots with period 3, score roles with period 2: unrolled by 6
     for (int jj = 1; jj < nsteps; jj += 6) {
       STEP(sB0, sB1, sA0, sA1, 1, 0, 2, 0, blk0 + jj)
@@ -535,6 +592,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
       if (jj + 5 >= nsteps) break;
       STEP(sA0, sA1, sB0, sB1, 0, 1, 1, 2, blk0 + jj + 5)
     }
+#endif
     // ---- drain: the second role still owes the VALU part of the last block; then PV of the last block ----
     if (wave_active) {
       if (role_y) {
