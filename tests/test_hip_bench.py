@@ -31,18 +31,20 @@ def test_bench_single_gpu_line():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(j["cpu_baseline"]) and "workload" in j["config"]
 
 
-def test_bench_two_rank_rehearsal():
+@pytest.mark.parametrize("dtype", ["fp16", "fp8"])
+def test_bench_two_rank_rehearsal(dtype):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
-                        "--config", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                        "--config", "tiny", "--dtype", dtype, "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+                       env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = _line(r.stdout)
-    assert KEYS <= set(j) and j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert KEYS <= set(j) and j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0 and j["dtype"] == dtype
 
 
 def test_bench_emulated_rank_and_fp8_lines():
