@@ -236,6 +236,43 @@ def test_hunyuan_triple_eval_vs_oracle(dual):
     assert rel_fro(hid4.float().cpu().numpy(), ref_h) < 1.5e-2
 
 
+@pytest.mark.parametrize("dual", [True, False])
+def test_hunyuan_block_projects_into_one_buffer(dual):
+    """SURVEY §8f N1 "+ text concat": the video and text projections land in one (1, S+T, H*D) buffer per tensor (the
+    GEMMs write it), qk-norm + RoPE run in place on the row ranges -- the same q, k, v as the reference's route
+    (separate projections + torch.cat in a dual-stream block, concatenated inputs in a single-stream one), bit for bit,
+    and the whole processor call agrees too."""
+    from vorta_amd.attention import HunyuanVideoFlashAttnProcessor, hunyuan as hy
+    dtype = torch.bfloat16
+    hidden_dim, T, te = 64, 16, 11
+    attn = _HyFakeAttn(hidden_dim, dual, dtype, seed=9)
+    torch.manual_seed(6)
+    hidden = torch.randn((1, S, hidden_dim), device=dev()).to(dtype)
+    enc = torch.randn((1, T, hidden_dim), device=dev()).to(dtype)
+    ang = torch.rand((S, 64), device=dev()) * 6.28
+    rope = (ang.cos().repeat_interleave(2, dim=1), ang.sin().repeat_interleave(2, dim=1))
+    mask = torch.zeros((1, 1, 1, S + T), dtype=torch.bool, device=dev())
+    mask[..., :S + te] = True
+    proc = HunyuanVideoFlashAttnProcessor()
+    res = {}
+    for joint in (True, False):
+        hy.JOINT_PROJECTION = joint
+        try:
+            with torch.no_grad():
+                q, k, v, _ = proc._project(attn, hidden, enc, rope)
+                out = proc(attn, hidden, enc, mask, rope)
+        finally:
+            hy.JOINT_PROJECTION = True
+        res[joint] = (q, k, v, *out)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    if dual:  # one buffer: (1,H,S+T,D) views of a (1,S+T,H*D) tensor; the reference's route: contiguous concat results
+        assert res[True][0].transpose(1, 2).is_contiguous() and res[False][0].is_contiguous()
+        # with autograd on and trainable weights the `out=` form is not available: back to the concat route
+        q, _, _, _ = proc._project(attn, hidden, enc, rope)
+        assert q.is_contiguous() == any(p.requires_grad for p in attn.to_q.parameters())
+
+
 # --------------------------------------------------------------------------------------------- SP rehearsal
 def _sp_worker(rank, world, port, ret):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",

@@ -47,6 +47,31 @@ def fused_norm_rope(x: torch.Tensor, norm, rope: Optional[Tuple[torch.Tensor, to
     return x
 
 
+# project video and text tokens straight into ONE (1, S+T, H*D) buffer per tensor: the `torch.cat([q, eq], dim=2)` of a
+# dual-stream block (hunyuan.py:106-134: a read and a write of all of q, k and v) and the input concat of a
+# single-stream block (hunyuan.py:47-48) disappear (SURVEY.md §8f N1 "+ text concat").  VORTA_JOINT_PROJECTION=0: the
+# reference's route (A/B, tests).
+JOINT_PROJECTION = __import__("os").environ.get("VORTA_JOINT_PROJECTION", "1") != "0"
+
+
+def _linear_into(lin: torch.nn.Linear, x2d: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst (rows, out_features; contiguous rows of a larger buffer) = lin(x2d), written by the GEMM itself"""
+    if lin.bias is not None:
+        torch.addmm(lin.bias, x2d, lin.weight.t(), out=dst)
+    else:
+        torch.mm(x2d, lin.weight.t(), out=dst)
+
+
+def _joint_projectable(x: torch.Tensor, e: torch.Tensor, lins) -> bool:
+    if not JOINT_PROJECTION or x.shape[0] != 1 or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if e.dtype != x.dtype or not all(type(m) is torch.nn.Linear and m.weight.dtype == x.dtype for m in lins):
+        return False
+    # `out=` is an inference-only form: autograd refuses it as soon as an argument requires grad
+    return not (torch.is_grad_enabled() and (x.requires_grad or e.requires_grad or
+                                             any(m.weight.requires_grad for m in lins)))
+
+
 def _valid_keys(attention_mask: torch.Tensor) -> torch.Tensor:
     """Number of valid keys L (int32, shape (1,), on the device) from the reference's attention mask
     (hunyuan.py:169 `attention_mask.squeeze().sum()` on the diffusers 0.33 [B,1,1,N] key mask).  Other diffusers versions
@@ -69,15 +94,18 @@ class HunyuanVideoFlashAttnProcessor:
     # -- steps 1-4 of hunyuan.py:42-134: everything before the attention boundary ----------------------
     def _project(self, attn, hidden_states, encoder_hidden_states, image_rotary_emb):
         single_stream = attn.add_q_proj is None  # single blocks carry text inside hidden_states
-        if single_stream:
-            hidden_states = torch.cat([hidden_states, encoder_hidden_states], dim=1)
         T = encoder_hidden_states.shape[1]
-        q = attn.to_q(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
-        k = attn.to_k(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
-        v = attn.to_v(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
         rope = None
         if image_rotary_emb is not None:
             rope = (shrink_dim(image_rotary_emb[0], dim=0), shrink_dim(image_rotary_emb[1], dim=0))
+        joint = self._project_joint(attn, hidden_states, encoder_hidden_states, rope, single_stream)
+        if joint is not None:
+            return (*joint, T)
+        if single_stream:
+            hidden_states = torch.cat([hidden_states, encoder_hidden_states], dim=1)
+        q = attn.to_q(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+        k = attn.to_k(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
+        v = attn.to_v(hidden_states).unflatten(2, (attn.heads, -1)).transpose(1, 2)
         n_video = q.shape[2] - (T if single_stream else 0)
         if q.shape[0] == 1 and _fusable_norm(attn.norm_q, q, 128) and _fusable_norm(attn.norm_k, k, 128):
             # one in-place HIP pass per tensor: norm everywhere, rotation on the video tokens only
@@ -108,6 +136,43 @@ class HunyuanVideoFlashAttnProcessor:
                     ek = attn.norm_added_k(ek)
             q, k, v = torch.cat([q, eq], dim=2), torch.cat([k, ek], dim=2), torch.cat([v, ev], dim=2)
         return q, k, v, T
+
+    @staticmethod
+    def _project_joint(attn, hidden_states, encoder_hidden_states, rope, single_stream: bool):
+        """Fused-norm case: the video and text projections land in ONE (1, S+T, H*D) buffer per tensor, written by the
+        GEMMs -- no `torch.cat([q, eq], dim=2)` pass over q, k, v in a dual-stream block (hunyuan.py:106-134), no concat
+        of the block inputs in a single-stream one (hunyuan.py:47-48); qk-norm + RoPE run in place on the row ranges.
+        None when the modules do not allow it (the caller then takes the reference's route)."""
+        vid = (attn.to_q, attn.to_k, attn.to_v)
+        txt = vid if single_stream else (attn.add_q_proj, attn.add_k_proj, attn.add_v_proj)
+        if not _joint_projectable(hidden_states, encoder_hidden_states, vid + txt):
+            return None
+        S_, T, H = hidden_states.shape[1], encoder_hidden_states.shape[1], attn.heads
+        out_f = attn.to_q.out_features
+        probe = hidden_states.new_empty((1, H, 1, out_f // H))
+        norms = (attn.norm_q, attn.norm_k) if single_stream else (attn.norm_q, attn.norm_k, attn.norm_added_q,
+                                                                   attn.norm_added_k)
+        if out_f // H != 128 or not all(_fusable_norm(n, probe, 128) for n in norms):
+            return None
+        if any(m.out_features != out_f for m in vid + txt):
+            return None
+        x2d, e2d = hidden_states[0], encoder_hidden_states[0]
+        qkv = []
+        for lin, elin in zip(vid, txt):
+            buf = hidden_states.new_empty((1, S_ + T, out_f))
+            _linear_into(lin, x2d, buf[0, :S_])
+            _linear_into(elin, e2d, buf[0, S_:])
+            qkv.append(buf.unflatten(2, (H, -1)).transpose(1, 2))  # (1, H, S+T, D) view
+        q, k, v = qkv
+        if single_stream:  # one norm for both row ranges, rotation on the video rows
+            fused_norm_rope(q, attn.norm_q, rope, S_)
+            fused_norm_rope(k, attn.norm_k, rope, S_)
+        else:
+            fused_norm_rope(q[:, :, :S_], attn.norm_q, rope, S_)
+            fused_norm_rope(k[:, :, :S_], attn.norm_k, rope, S_)
+            fused_norm_rope(q[:, :, S_:], attn.norm_added_q, None)
+            fused_norm_rope(k[:, :, S_:], attn.norm_added_k, None)
+        return q, k, v
 
     # -- step 6 (hunyuan.py:191-208) ---------------------------------------------------------------------
     @staticmethod
