@@ -341,7 +341,8 @@ int vorta_seq_row_map(int32_t* row_map, int32_t n_tokens, int32_t seg_len, int32
  *     dst[t][dst_map ? dst_map[h] : h][r][:] = src[t][src_map ? src_map[h] : h][r][:]      h < heads, r < n_rows
  * Send side: q, k, v projection views -> head-ordered contiguous blocks (src_map = head order), and the replicated text
  * rows behind each local head slot; receive side: the head-ordered output back into the (rows, H*D) result (dst_map).
- * The maps are device arrays of `heads` entries; a map must not repeat a head on the destination side.
+ * The maps are device arrays of `heads` entries; a map must not repeat a head on the destination side, and no source may
+ * overlap a destination (the copy is not an in-place permutation).
  */
 typedef struct vorta_permute_args {
   uint32_t struct_size;
