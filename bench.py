@@ -341,6 +341,9 @@ def main():
                    + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else ""),
                    "experts": {"fused": "one fused grid per layer", "serial": "one launch per expert",
                                "concurrent": "experts on side streams"}[args.experts],
+                   **({"fp8": "e4m3 q,k,v and probabilities on the fp8 MFMA; conversion (per-head scales, key centring "
+                              + ("on" if __import__("vorta_amd.routed", fromlist=["x"]).FP8_CENTER_K else "off")
+                              + ") inside the timed step; bf16 in / out"} if fp8 else {}),
                    "step_algorithmic_pflop": round(step_flops / 1e15, 3),
                    "step_tflops_per_gpu": round(step_flops / (ms_per_step * 1e-3) / 1e12 / (emu or world), 1)},
         "roofline": roofline,
