@@ -309,6 +309,60 @@ def test_processor_under_sequence_parallel_rehearsal():
     assert ret[0] == 0.0 and ret[1] == 0.0, dict(ret)
 
 
+def _sp_worker_fp8(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import vorta_amd
+    from vorta_amd import routed
+    from vorta_amd.attention import WanAttnProcessorTripleEval
+    from vorta_amd.ulysses import SP_STATE
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g8_eval_calls.npz"))
+    dtype = torch.bfloat16
+    attn = _WanFakeAttn(g, dtype)
+    hidden = torch.tensor(g["wan_hidden"]).to(dtype).to(dev())
+    score = torch.tensor(g["routing_score"]).to(dev())
+    proc = WanAttnProcessorTripleEval(check_input=True)
+    native = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    vorta_amd.set_attention_precision("fp8")
+    res, full, part = {}, {}, {}
+    Sl = S // world
+    shard = hidden[:, rank * Sl:(rank + 1) * Sl].contiguous()
+    for center in (False, True):
+        routed.FP8_CENTER_K = center
+        full[center] = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    SP_STATE.setup_sp_group(world)
+    for center in (False, True):
+        routed.FP8_CENTER_K = center
+        part[center] = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
+    for center in (False, True):
+        ref = full[center][:, rank * Sl:(rank + 1) * Sl].float()
+        nat = native[:, rank * Sl:(rank + 1) * Sl].float()
+        res[center] = (float((part[center].float() - ref).abs().max()), rel(part[center].float(), nat), rel(ref, nat))
+    ret[rank] = res
+    dist.barrier()
+    SP_STATE.cleanup()
+
+
+def test_processor_under_sequence_parallel_rehearsal_fp8():
+    """The same with the e4m3 contractions: under SP the receive buffers are converted in the quantiser's segmented row
+    layout, with the same per-head abs-max as the single-process call -- bit-identical without key centring; with it
+    the centre is the mean of other sample rows (any vector is legitimate): another realisation of the e4m3 rounding of
+    the keys, the same distance from the 16-bit result."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_sp_worker_fp8, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        (d0, sp0, one0), (_, sp1, one1) = ret[r][False], ret[r][True]
+        assert d0 == 0.0 and sp0 == one0, dict(ret)
+        assert 0.0 < one0 < 0.1 and 0.0 < one1 < 0.1 and abs(sp1 - one1) < 0.15 * one1, dict(ret)
+
+
 # --------------------------------------------------------------------------- soft mixture (training forward)
 def test_mix_experts_kernel():
     from vorta_amd import ops
