@@ -505,10 +505,16 @@ def test_hunyuan_pipeline_token_shard_takes_any_frame_count(world):
             assert err <= 2e-2 * max(mag, 1.0) and shape_ok and same_scores, (r, ret[r])
 
 
-def test_hunyuan_pipeline_under_sequence_parallel_rehearsal():
+@pytest.mark.parametrize("precision", ["native", "fp8"])
+def test_hunyuan_pipeline_under_sequence_parallel_rehearsal(precision, monkeypatch):
     """2 ranks sharing the one GPU (gloo, host-staged transport): whole latents on every rank, token-sharded inside the
-    transformer, global rotary table and attention mask from the stock forward, video == single process."""
+    transformer, global rotary table and attention mask from the stock forward, video == single process.  With
+    VORTA_ATTENTION_PRECISION=fp8 the unchanged call goes through the e4m3 kernels (text rows and padding through the
+    segmented quantiser): the ranks still agree bit for bit; against the single-process fp8 run the video differs by
+    another realisation of the rounding noise (the key centres are means of other sample rows)."""
     import torch.multiprocessing as mp
+    if precision == "fp8":
+        monkeypatch.setenv("VORTA_ATTENTION_PRECISION", "fp8")
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()
@@ -521,7 +527,7 @@ def test_hunyuan_pipeline_under_sequence_parallel_rehearsal():
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         for r in range(2):
             err, mag, same_scores, same_seed = ret[r]
-            assert err <= 2e-2 * max(mag, 1.0), (r, err, mag)
+            assert err <= (2e-2 if precision == "native" else 0.25) * max(mag, 1.0), (r, err, mag)
             assert same_scores and same_seed
 
 
