@@ -560,7 +560,11 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #if defined(VORTA_DIAG_ALLX)
   const bool role_y = false;
 #else
+#if defined(VORTA_ROLE_SWAP)  // experiment: the earlier-dispatched half starts its steps with the VALU part
+  const bool role_y = NW == 8 && wave < NW / 2;
+#else
   const bool role_y = NW == 8 && wave >= NW / 2;  // wave-uniform
+#endif
 #endif
 #if VORTA_PRIO8 == 2  // experiment: static priority for the later-dispatched half, no flips
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
