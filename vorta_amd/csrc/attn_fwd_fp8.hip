@@ -91,7 +91,7 @@ constexpr int K_SLOTS = 2, V_SLOTS = 3;
 #endif
 constexpr int SMEM8 = (K_SLOTS + V_SLOTS) * TILE8;
 
-template <typename TO, int NW, bool KVTAB, bool LMFMA>
+template <typename TO, int NW, bool KVTAB, bool LMFMA, bool SWAP = false>
 __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__ smem, const int wg) {
   const Params& p = pp.p;
   using O4 = typename OutT<TO>::v4;
@@ -560,11 +560,10 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #if defined(VORTA_DIAG_ALLX)
   const bool role_y = false;
 #else
-#if defined(VORTA_ROLE_SWAP)  // experiment: the earlier-dispatched half starts its steps with the VALU part
-  const bool role_y = NW == 8 && wave < NW / 2;
-#else
-  const bool role_y = NW == 8 && wave >= NW / 2;  // wave-uniform
-#endif
+  // which half of the workgroup starts its steps with the VALU part (wave-uniform).  SWAP = the earlier-dispatched half:
+  // measured per kernel -- the fused layer kernel runs 3.2-3.7 % faster that way (Wan-14B fp8 step 2 113 -> 2 036 ms,
+  // dense-only fused launch 10.88 -> 10.55 ms), the single-launch kernels 0.5-1 % slower (10.55 -> 10.61 ms)
+  const bool role_y = NW == 8 && (SWAP ? wave < NW / 2 : wave >= NW / 2);
 #endif
 #if VORTA_PRIO8 == 2  // experiment: static priority for the later-dispatched half, no flips
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
@@ -776,8 +775,8 @@ __global__ __launch_bounds__(512, 2) void attn8_multi_kernel(const MultiParams8 
   for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
   const Params8& pp = mp.seg[s];
   const int wg = xcd_order(b - mp.start[s], mp.start[s + 1] - mp.start[s]);
-  if (pp.p.kv_rows) attn8_body<TO, 8, true, true>(pp, smem, wg);
-  else attn8_body<TO, 8, false, true>(pp, smem, wg);
+  if (pp.p.kv_rows) attn8_body<TO, 8, true, true, true>(pp, smem, wg);
+  else attn8_body<TO, 8, false, true, true>(pp, smem, wg);
 #endif
 }
 
