@@ -75,8 +75,8 @@ template <> struct OutT<_Float16> { using v4 = f16x4; };
 // instead of right after the barrier -- they go from the barrier straight into their MFMAs (no address arithmetic, no
 // request issue in the head of the segment) and the requests of the two roles no longer queue up together.  Same box,
 // dense / table launch at S = 75 600, H = 8: 11.78 / 11.45 ms with every request at the top of the step (and a run-time
-// "is this wave a loader" test), 10.85 / 10.63 ms now.  bit1: the other role requests behind its VALU part (slower);
-// 5: the V request a while after the K request (slower).  The loader test has to be a compile-time fact: as a run-time
+// "is this wave a loader" test), 10.85 / 10.63 ms now.  bit1: the other role requests behind its VALU part (slower; so
+// is a V request issued a while after the K request).  The loader test has to be a compile-time fact: as a run-time
 // branch it puts a control-flow join behind the requests, the compiler waits there for the table path's pending row-id
 // load, and the queue order makes that a wait for the tile request before it (13.4 ms on the table launch).
 // The 8-wave kernels only (the 4-wave ones have no roles).  The gain is the single-launch kernels' (-7 %: all heads dense,
@@ -393,17 +393,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     ROWS_OF(rowK, (jabs_) + 3)                                                    \
   }                                                                               \
   __builtin_amdgcn_sched_barrier(0);
-// the same in two halves (experiment VORTA_DMA_SPLIT bit2: the V request a while after the K request)
-#define STAGE_DMA_A(kw_, vw_, jabs_)                                              \
-  if (loader) { DMA_K(kw_) }                                                      \
-  __builtin_amdgcn_sched_barrier(0);
-#define STAGE_DMA_B(kw_, vw_, jabs_)                                              \
-  if (loader) {                                                                   \
-    DMA_V(vw_)                                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];        \
-    ROWS_OF(rowK, (jabs_) + 3)                                                    \
-  }                                                                               \
-  __builtin_amdgcn_sched_barrier(0);
 #endif
 #endif
 #if defined(VORTA_DIAG_NOBAR)  // timing diagnostics only (results are wrong): no workgroup barrier / no wait at all
@@ -458,14 +447,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #define VALU_PART(e0_, e1_, m0_, m1_)                                             \
   {                                                                               \
     EXP_BLOCK(e0_, e1_)                                                           \
-    PACK_BLOCK(e0_, e1_)                                                          \
-    ROW_MAX_POS(mx_cur, m0_, m1_)                                                 \
-  }
-#define VALU_PART_MID(e0_, e1_, m0_, m1_, mid_)                                   \
-  {                                                                               \
-    EXP_BLOCK(e0_, e1_)                                                           \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    mid_                                                                          \
     PACK_BLOCK(e0_, e1_)                                                          \
     ROW_MAX_POS(mx_cur, m0_, m1_)                                                 \
   }
@@ -526,17 +507,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   {                                                                               \
     TR_(0)                                                                        \
     /* VORTA_DMA_SPLIT bit0: role X requests behind its matrix part; bit1: role Y behind its VALU part; */ \
-    /* 5: X behind its matrix part, both roles' V request behind the exps of their VALU part               */ \
-    if (VORTA_DMA_SPLIT == 5 && !VORTA_SYNC2) {                                   \
-      if (!wave_active) { STAGE_DMA(kw_, vw_, jabs_) }                            \
-      else {                                                                      \
-        if (role_y) { STAGE_DMA_A(kw_, vw_, jabs_) VALU_PART_MID(n0_, n1_, c0_, c1_, STAGE_DMA_B(kw_, vw_, jabs_)) } \
-        __builtin_amdgcn_sched_barrier(0);                                        \
-        MATRIX_PART(c0_, c1_, n0_, n1_, kr_, vr_, jabs_)                          \
-        __builtin_amdgcn_sched_barrier(0);                                        \
-        if (!role_y) { STAGE_DMA_A(kw_, vw_, jabs_) VALU_PART_MID(c0_, c1_, n0_, n1_, STAGE_DMA_B(kw_, vw_, jabs_)) } \
-      }                                                                           \
-    } else {                                                                      \
     {                                                                             \
     if (!wave_active || NW != 8 || (role_y ? !(VORTA_DMA_SPLIT & 2) : !(VORTA_DMA_SPLIT & 1))) { STAGE_DMA(kw_, vw_, jabs_) } \
     if (wave_active) {                                                            \
@@ -549,7 +519,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
       TR_(2)                                                                      \
       if ((VORTA_DMA_SPLIT & 1) && NW == 8 && !role_y) { STAGE_DMA(kw_, vw_, jabs_) } \
       if (!role_y) VALU_PART(c0_, c1_, n0_, n1_)                                  \
-    }                                                                             \
     }                                                                             \
     }                                                                             \
     if constexpr (sync_) { STEP_SYNC() }                                          \
