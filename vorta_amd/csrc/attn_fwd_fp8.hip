@@ -530,8 +530,8 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   const bool role_y = false;
 #else
   // which half of the workgroup starts its steps with the VALU part (wave-uniform).  SWAP = the earlier-dispatched half:
-  // measured per kernel -- the fused layer kernel runs 3.2-3.7 % faster that way (Wan-14B fp8 step 2 113 -> 2 036 ms,
-  // dense-only fused launch 10.88 -> 10.55 ms), the single-launch kernels 0.5-1 % slower (10.55 -> 10.61 ms)
+  // measured per kernel -- the table-free body of the fused layer kernel runs 2.5-3.6 % faster that way (dense-only
+  // fused launch 11.13 -> 10.86 ms), its table body 0-1 % slower, the single-launch kernels 0.5-1 % slower
   const bool role_y = NW == 8 && (SWAP ? wave < NW / 2 : wave >= NW / 2);
 #endif
 #if VORTA_PRIO8 == 2  // experiment: static priority for the later-dispatched half, no flips
@@ -744,8 +744,13 @@ __global__ __launch_bounds__(512, 2) void attn8_multi_kernel(const MultiParams8 
   for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
   const Params8& pp = mp.seg[s];
   const int wg = xcd_order(b - mp.start[s], mp.start[s + 1] - mp.start[s]);
-  if (pp.p.kv_rows) attn8_body<TO, 8, true, true, true>(pp, smem, wg);
-  else attn8_body<TO, 8, false, true, true>(pp, smem, wg);
+#ifndef VORTA_MULTI_SWAP
+#define VORTA_MULTI_SWAP 1  /* see attn8_body: which half of the workgroup starts its steps with the VALU part; bit0 the body
+                               without row tables, bit1 the body with them.  One box, fp8 step in ms, 0 / 1 / 2 / 3:
+                               Wan-14B 2 156 / 2 097 / 2 169 / 2 113, Hunyuan-129f 2 285 / 2 300 / 2 300 / 2 328 */
+#endif
+  if (pp.p.kv_rows) attn8_body<TO, 8, true, true, (VORTA_MULTI_SWAP & 2) != 0>(pp, smem, wg);
+  else attn8_body<TO, 8, false, true, (VORTA_MULTI_SWAP & 1) != 0>(pp, smem, wg);
 #endif
 }
 
