@@ -162,6 +162,24 @@ def cpu_baseline(cfg, layer_ids):
                       f"{cfg['fwd_per_step']} forward(s) per step"}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a child (one rank per GPU, rendezvous on 127.0.0.1 at a free port) and pass its stdout / stderr
+    and exit code through.  Called before anything initialises HIP in this process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     # the host driver only supports dmabuf IPC: must be in the environment before HIP / HSA initialise
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -183,6 +201,9 @@ def main():
                          "sequence through the zero-copy receive layout, the send-side staging passes and the un-permute "
                          "of the output included, the transfers themselves left out.  The step still covers the whole sequence, so "
                          "`value` is an upper bound of the P-GPU throughput; not a BASELINE line")
+    ap.add_argument("--no-v-wire", action="store_true",
+                    help="N>1 with --dtype fp8: exchange v in 16 bits and convert it on the receive side (A/B; default: v "
+                         "is converted on the send side and crosses the links as e4m3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-ceiling", action="store_true",
                     help="skip the torch.matmul (hipBLASLt) context measurement reported beside roofline.frac")
@@ -197,12 +218,14 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.dtype:
         cfg["dtype"] = args.dtype
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_rank:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (never exec: nothing in this
+        # process has touched the GPU yet, and nothing will), relay its output and exit with its code
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # VORTA_BENCH_BACKEND=gloo: 1-GPU rehearsal of the N>1 code path (all ranks share cuda:0, host-staged
     # messages); the driver's multi-GPU runs use RCCL ("nccl"), one rank per GPU
@@ -216,6 +239,15 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    # what the process group saw: one entry per rank (proof that N ranks on N devices ran the step over RCCL)
+    props = torch.cuda.get_device_properties(dev_index)
+    me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")), "host": os.uname().nodename, "pid": os.getpid()}
+    ranks_seen = [me]
+    if world > 1:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
 
     from vorta_amd import ops
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
@@ -265,8 +297,7 @@ def main():
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
                                             concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
-                                            groups=1 if fp8 else (args.sp_groups if (H // P) % args.sp_groups == 0 else 1),
-                                            loopback=bool(emu), fp8=fp8)
+                                            groups=args.sp_groups, loopback=bool(emu), fp8=fp8, v_wire=not args.no_v_wire)
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):
@@ -294,6 +325,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / args.steps
+    # order-independent fingerprint of the last layer's output (all ranks): lets two runs of one workload -- other slot
+    # groups, v on the wire or not -- be compared bit for bit from their JSON lines
+    fp_t = (out if P == 1 else sp.out_shard).contiguous().view(torch.int16).to(torch.int64)
+    fingerprint = (fp_t * (torch.arange(fp_t.numel(), device=dev).view(fp_t.shape) % 8191 + 1)).sum().reshape(1)
+    if world > 1:
+        fingerprint = fingerprint * (rank + 1)
+        dist.all_reduce(fingerprint)
+    fingerprint = int(fingerprint.item())
     tokens = S * cfg["fwd_per_step"]
 
     # ---- roofline of the dominant kernel symbol (largest share of the timed region) ----
@@ -332,7 +371,11 @@ def main():
             "upper bound of the %d-GPU value, not a measurement of it" % (emu, emu)} if emu else {}),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
-        "backend": (backend if world > 1 else None),
+        "backend": (backend if world > 1 else None), "output_fingerprint": fingerprint,
+        "process_group": {"world_size": dist.get_world_size() if world > 1 else 1,
+                          "backend": dist.get_backend() if world > 1 else None,
+                          "distinct_devices": len({(r["host"], r["uuid"] or r["device"]) for r in ranks_seen}),
+                          "ranks": ranks_seen},
         "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",

@@ -31,8 +31,9 @@ extern "C" {
 #define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
 #define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
 
-#define VORTA_ABI_VERSION 3 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
-                                every earlier call is unchanged */
+#define VORTA_ABI_VERSION 4 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
+                                4: vorta_fp8_quant_args gains slot_first / slot_count and flags bit2, adds vorta_fp8_v_absmax /
+                                vorta_fp8_v_convert; every earlier call means what it meant */
 
 typedef enum vorta_dtype {
   VORTA_BF16 = 0,
@@ -175,12 +176,45 @@ typedef struct vorta_fp8_quant_args {
   int32_t seg_len;          /* 0: q,k,v,q8,k8,v8 are (heads, n_tokens, D) views.  > 0: they are row arrays of n_tokens rows
                                (stride_h unused) in which row r belongs to head (r / seg_len) % heads -- the Ulysses
                                receive layout (vorta_seq_row_map); every head gets its own scales and centre */
-  int32_t tail_first;       /* seg_len > 0 and tail_len > 0: from row tail_first (a multiple of seg_len) on, only the */
-  int32_t tail_len;         /* first tail_len rows of a segment hold data (text rows); the others are skipped */
+  int32_t tail_first;       /* seg_len > 0 and either field non-zero: from row tail_first (a multiple of seg_len) on, only */
+  int32_t tail_len;         /* the first tail_len rows of a segment hold data (text rows); the others are skipped
+                               (tail_len = 0: the tail region is empty).  A head's tokens are its rows of the segments
+                               before tail_first, in order, then its tail rows: the centre of flags bit1 samples the same
+                               TOKENS in both layouts, so a head converts to the same bytes on one GPU and on a rank of P */
+  int32_t slot_first;       /* seg_len > 0: convert only the rows of head slots [slot_first, slot_first + slot_count) -- the */
+  int32_t slot_count;       /* slot group whose exchange has landed while the next one is in flight (0, 0 = every slot).
+                               Scales and centres are per head, so converting slot group by slot group gives the bytes
+                               one call over all slots gives */
 } vorta_fp8_quant_args;
+/* flags bit2: q and k only -- v, v8 and v_descale are not touched (v arrived as e4m3: vorta_fp8_v_convert on the sender) */
 
 int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim);
 int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* args, void* hip_stream);
+
+/*
+ * V on its own, for the sender side of the Ulysses exchange (vorta/ulysses/utils.py:61-91 moves 16-bit q, k, v): each rank
+ * takes the per-(head, channel) abs-max of ITS sequence shard of v (vorta_fp8_v_absmax: amax[h][d] is raised atomically,
+ * the caller zeroes it first; several calls accumulate -- video rows, then the replicated text rows), the ranks
+ * all-reduce amax with MAX (heads x 128 floats), and vorta_fp8_v_convert writes the e4m3 shard with the scales of the
+ * whole sequence, heads already in destination order (v8 head h <- v head src_map[h]): v crosses the links at half the
+ * bytes and lands as the attention kernels read it.  The bytes and v_descale equal what vorta_fp8_quantize_qkv produces
+ * from the assembled 16-bit sequence (abs-max over shards = abs-max over the sequence).
+ */
+typedef struct vorta_fp8_v_args {
+  uint32_t struct_size;
+  int32_t dtype;            /* input dtype: VORTA_BF16 / VORTA_FP16 */
+  int32_t head_dim, heads;  /* 128; heads of v (absmax) / of v8 (convert) */
+  int32_t n_tokens;
+  int32_t flags;            /* bit0: one scale per head instead of per (head, channel) */
+  vorta_tensor v;           /* (H, n_tokens, D) view, strides in elements */
+  vorta_tensor v8;          /* convert: (heads, n_tokens, D) e4m3 out, strides in bytes */
+  const int32_t* src_map;   /* convert: [heads] source head of every destination head, or NULL (identity) */
+  float* amax;              /* [H][D], indexed by the SOURCE head: absmax raises it, convert reads it */
+  float* v_descale;         /* convert: optional out [heads][D], indexed by the DESTINATION head: amax / 240 */
+} vorta_fp8_v_args;
+
+int vorta_fp8_v_absmax(const vorta_fp8_v_args* args, void* hip_stream);
+int vorta_fp8_v_convert(const vorta_fp8_v_args* args, void* hip_stream);
 
 typedef struct vorta_attn_fp8_ext {
   uint32_t struct_size;
@@ -360,7 +394,7 @@ int vorta_abi_version(void);
 const char* vorta_build_info(void); /* static string: arch, compiler */
 int vorta_last_hip_error(void);     /* last hipError_t seen by a failed launch in this thread */
 int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args, 5 norm_rope_args,
-                                       6 mix_args, 7 fp8_quant_args, 8 attn_fp8_ext, 9 permute_args */
+                                       6 mix_args, 7 fp8_quant_args, 8 attn_fp8_ext, 9 permute_args, 10 fp8_v_args */
 
 #ifdef __cplusplus
 }

@@ -435,17 +435,24 @@ def e4m3_decode(b: np.ndarray) -> np.ndarray:
 
 
 def fp8_center_rows(n_tokens: int, heads: int, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0) -> list:
-    """rows whose mean is the key centre of each head (fp8_quant.hip: fp8_kmean_kernel): candidates r = i * stride with an
-    odd stride ~ n_tokens / 1024 (per head), kept if they belong to the head and hold data."""
-    stride = max(1, n_tokens // (1024 * heads) if seg_len > 0 else n_tokens // 1024) | 1
-    cand = np.arange(0, n_tokens, stride)
+    """rows whose mean is the key centre of each head (fp8_quant.hip: fp8_kmean_kernel): TOKENS s = i * stride of the head
+    with an odd stride ~ tokens / 1024, mapped to physical rows -- the identity for (H,S,D) views; in the segmented layout
+    token s of head h is row ((s // seg_len) * heads + h) * seg_len + s % seg_len, the tail tokens follow at
+    tail_first + h * seg_len."""
     if seg_len <= 0:
-        return [cand] * heads
-    seg = cand // seg_len
-    ok = np.ones(cand.shape, bool)
-    if tail_len > 0:
-        ok = ~((cand >= tail_first) & (cand - seg * seg_len >= tail_len))
-    return [cand[ok & (seg % heads == h)] for h in range(heads)]
+        stride = max(1, n_tokens // 1024) | 1
+        return [np.arange(0, n_tokens, stride)] * heads
+    has_tail = tail_first > 0 or tail_len > 0
+    data_rows = tail_first if has_tail else n_tokens
+    video = (data_rows // seg_len // heads) * seg_len
+    per_head = video + (tail_len if has_tail else 0)
+    stride = max(1, per_head // 1024) | 1
+    s = np.arange(0, per_head, stride)
+    rows = []
+    for h in range(heads):
+        r = np.where(s < video, ((s // seg_len) * heads + h) * seg_len + s % seg_len, tail_first + h * seg_len + (s - video))
+        rows.append(r)
+    return rows
 
 
 def fp8_quantize_qkv(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: Optional[float] = None,

@@ -47,6 +47,28 @@ def test_bench_two_rank_rehearsal(dtype):
     assert KEYS <= set(j) and j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0 and j["dtype"] == dtype
 
 
+def test_bench_plain_command_launches_its_ranks_and_fp8_exchange_variants_agree():
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks itself (a child process running
+    torch.distributed.run); the JSON names the ranks the process group saw.  fp8: the overlapped exchange (two slot
+    groups, converted group by group) and v on the wire as e4m3 give the bytes of the plain exchange."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    lines = {}
+    for name, extra in (("plain", ["--no-v-wire"]), ("vwire", []), ("groups", ["--sp-groups", "2"]),
+                        ("groups16", ["--sp-groups", "2", "--no-v-wire"])):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "tiny", "--dtype", "fp8", "--steps", "1",
+                            "--warmup", "1", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, (name, r.stdout[-1500:], r.stderr[-3000:])
+        lines[name] = _line(r.stdout)
+    j = lines["plain"]
+    pg = j["process_group"]
+    assert j["n_gpus"] == 2 and pg["world_size"] == 2 and pg["backend"] == "gloo" and len(pg["ranks"]) == 2
+    assert sorted(r["rank"] for r in pg["ranks"]) == [0, 1] and len({r["pid"] for r in pg["ranks"]}) == 2
+    fps = {name: l["output_fingerprint"] for name, l in lines.items()}
+    assert len(set(fps.values())) == 1 and fps["plain"] != 0, fps
+
+
 def test_bench_emulated_rank_and_fp8_lines():
     """--emulate-rank P: one rank's share of a P-way Ulysses step on one GPU (loopback layout, no transfers);
     --dtype fp8: the e4m3 path (quantiser inside the step)."""

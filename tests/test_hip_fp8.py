@@ -135,7 +135,11 @@ def test_quantizer_key_centring_and_segmented_rows(dtype):
             b[rows_video + h * Sl:rows_video + h * Sl + T] = x[h, S:]
         bufs.append(b.view(1, rows_total, 128))
     for center in (False, True):
-        g8 = ops.fp8_quantize_qkv(*bufs, heads=Hl, seg_len=Sl, tail_first=rows_video, tail_len=T, center_k=center)
+        nws_ = ops._C.lib().vorta_fp8_quant_ws_floats(Hl, 128)
+        zero = ops.Fp8Operands(*(torch.zeros((1, rows_total, 128), dtype=torch.uint8, device=dev()) for _ in range(3)),
+                               torch.zeros((Hl, 128), dtype=torch.float32, device=dev()),
+                               torch.zeros(nws_, dtype=torch.float32, device=dev()))  # gap rows stay zero: comparable
+        g8 = ops.fp8_quantize_qkv(*bufs, heads=Hl, seg_len=Sl, tail_first=rows_video, tail_len=T, center_k=center, out=zero)
         cs = g8.k_center().cpu().numpy()
         if center:
             srows = O.fp8_center_rows(rows_total, Hl, Sl, rows_video, T)
@@ -152,8 +156,55 @@ def test_quantizer_key_centring_and_segmented_rows(dtype):
                 for j in range(P):
                     assert (got[phys(h, j * Sl):phys(h, j * Sl) + Sl] == zs[name][h, j * Sl:(j + 1) * Sl]).all(), (name, h, j)
                 assert (got[rows_video + h * Sl:rows_video + h * Sl + T] == zs[name][h, S:]).all(), (name, h, "text")
+        if center:  # the same TOKENS define the centre in both layouts: same centre, same bytes as the (H,S,D) call
+            assert (cs == c).all()
+            for name, t, u in (("q8", g8.q, f8.q), ("k8", g8.k, f8.k), ("v8", g8.v, f8.v)):
+                got = t[0]
+                for h in range(Hl):
+                    for j in range(P):
+                        assert torch.equal(got[phys(h, j * Sl):phys(h, j * Sl) + Sl], u[h, j * Sl:(j + 1) * Sl]), (name, h, j)
+        # slot group by slot group (the overlapped exchange converts the group that has landed): the bytes of one call
+        nws = g8.ws.numel()
+        part = ops.Fp8Operands(*(torch.zeros_like(t) for t in (g8.q, g8.k, g8.v)), torch.zeros_like(g8.v_descale),
+                               torch.zeros(nws, dtype=torch.float32, device=dev()))
+        for slots in ((2, 3), (0, 2)):
+            ops.fp8_quantize_qkv(*bufs, heads=Hl, seg_len=Sl, tail_first=rows_video, tail_len=T, center_k=center,
+                                 out=part, slots=slots)
+        for name in ("q", "k", "v", "v_descale"):
+            assert torch.equal(getattr(part, name), getattr(g8, name)), (name, center)
+        # v converted on the SEND side of the exchange: abs-max of every sequence shard (+ the replicated text rows),
+        # MAX over the shards, conversion into destination head order -- the receive-side bytes and v_descale
+        order = [2, 0, 1]
+        omap = torch.tensor(order, dtype=torch.int32, device=dev())
+        amax_parts = []
+        for j in range(P):
+            am = torch.zeros((Hl, 128), dtype=torch.float32, device=dev())
+            ops.fp8_v_absmax(vd[:, j * Sl:(j + 1) * Sl], am)
+            ops.fp8_v_absmax(vd[:, S:], am)
+            amax_parts.append(am)
+        amax = torch.stack(amax_parts).amax(0)  # the all-reduce
+        assert torch.equal(amax, vd.float().abs().amax(1))
+        for j in range(P):
+            st = torch.empty((Hl, Sl, 128), dtype=torch.uint8, device=dev())
+            vdsc = torch.empty((Hl, 128), dtype=torch.float32, device=dev())
+            ops.fp8_v_convert(vd[:, j * Sl:(j + 1) * Sl], amax, st, src_map=omap, v_descale=vdsc)
+            assert torch.equal(vdsc, g8.v_descale[omap.long()])
+            for i, h in enumerate(order):
+                assert torch.equal(st[i], g8.v[0, phys(h, j * Sl):phys(h, j * Sl) + Sl]), (j, h)
+        tx = torch.empty((Hl, T, 128), dtype=torch.uint8, device=dev())
+        ops.fp8_v_convert(vd[:, S:], amax, tx)
+        for h in range(Hl):
+            assert torch.equal(tx[h], g8.v[0, rows_video + h * Sl:rows_video + h * Sl + T])
+        # q and k only (v arrived as e4m3): v / v_descale of the operand set are left alone
+        qk = ops.Fp8Operands(torch.zeros_like(g8.q), torch.zeros_like(g8.k), torch.full_like(g8.v, 7),
+                             torch.full_like(g8.v_descale, 3.0), torch.zeros(nws, dtype=torch.float32, device=dev()))
+        ops.fp8_quantize_qkv(bufs[0], bufs[1], None, heads=Hl, seg_len=Sl, tail_first=rows_video, tail_len=T,
+                             center_k=center, out=qk)
+        assert torch.equal(qk.q, g8.q) and torch.equal(qk.k, g8.k) and bool((qk.v == 7).all()) and bool((qk.v_descale == 3.0).all())
     with pytest.raises(ValueError):
         ops.fp8_quantize_qkv(qd, kd, vd, seg_len=Sl)  # segmented layout needs (1,rows,D) arrays and `heads`
+    with pytest.raises(ValueError):
+        ops.fp8_quantize_qkv(qd, kd, vd, slots=(0, 1))  # a slot range needs the segmented layout
     with pytest.raises(ValueError):  # VORTA_EINVAL: the text region starts on a segment boundary
         ops.fp8_quantize_qkv(*bufs, heads=Hl, seg_len=Sl, tail_first=rows_video + 1, tail_len=T)
 

@@ -153,20 +153,23 @@ def test_zero_copy_layout_round_trip(world):
 
 
 def test_balanced_head_order_with_slot_groups():
-    from vorta_amd.ulysses import balanced_head_order
+    from vorta_amd.ulysses import balanced_head_order, slot_groups
     rng = np.random.default_rng(3)
     cost = [7.26, 1.82, 1.33]
-    for P, G in ((2, 2), (2, 3), (4, 2), (4, 3)):
+    for P, G in ((2, 2), (2, 3), (4, 2), (4, 3), (8, 2), (2, 5), (4, 4)):
         e = rng.permutation([0] * 8 + [1] * 8 + [2] * 8)
         plain, grouped = balanced_head_order(e, cost, P), balanced_head_order(e, cost, P, groups=G)
         Hl = 24 // P
-        for j in range(P):  # same heads per rank as without groups; groups of a rank carry near-equal cost
+        sg = slot_groups(Hl, G)  # as equal as Hl allows, larger groups first (Hl = 3, G = 2: 2 + 1)
+        assert sg[0][0] == 0 and sg[-1][1] == Hl and all(a[1] == b[0] for a, b in zip(sg, sg[1:]))
+        assert max(b - a for a, b in sg) - min(b - a for a, b in sg) <= 1
+        for j in range(P):  # same heads per rank as without groups; groups of a rank carry near-equal cost per slot
             assert sorted(grouped[j * Hl:(j + 1) * Hl]) == plain[j * Hl:(j + 1) * Hl]
-            n = Hl // G
-            loads = [sum(cost[e[h]] for h in grouped[j * Hl + g * n:j * Hl + (g + 1) * n]) for g in range(G)]
+            loads = [sum(cost[e[h]] for h in grouped[j * Hl + a:j * Hl + b]) / (b - a) for a, b in sg]
             assert max(loads) - min(loads) <= max(cost)
-    with pytest.raises(AssertionError):
-        balanced_head_order([0] * 8, cost, 2, groups=3)
+            for a, b in sg:
+                assert grouped[j * Hl + a:j * Hl + b] == sorted(grouped[j * Hl + a:j * Hl + b])
+    assert slot_groups(5, 2) == [(0, 3), (3, 5)] and slot_groups(3, 8) == [(0, 1), (1, 2), (2, 3)]
 
 
 def test_balanced_head_order():

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvo
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
 VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3 = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i32, _i64, _u32, _f32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
 
@@ -99,6 +99,14 @@ class Fp8QuantArgs(C.Structure):
         ("n_tokens", _i32), ("qk_scale", _f32),
         ("q", Tensor), ("k", Tensor), ("v", Tensor), ("q8", Tensor), ("k8", Tensor), ("v8", Tensor),
         ("v_descale", _vp), ("ws", _vp), ("flags", _i32), ("seg_len", _i32), ("tail_first", _i32), ("tail_len", _i32),
+        ("slot_first", _i32), ("slot_count", _i32),
+    ]
+
+
+class Fp8VArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32), ("n_tokens", _i32), ("flags", _i32),
+        ("v", Tensor), ("v8", Tensor), ("src_map", _vp), ("amax", _vp), ("v_descale", _vp),
     ]
 
 
@@ -117,6 +125,8 @@ SYMBOLS = {
     "vorta_attn_workspace_bytes": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vorta_fp8_quant_ws_floats": (C.c_int, [_i32, _i32]),
     "vorta_fp8_quantize_qkv": (C.c_int, [C.POINTER(Fp8QuantArgs), _vp]),
+    "vorta_fp8_v_absmax": (C.c_int, [C.POINTER(Fp8VArgs), _vp]),
+    "vorta_fp8_v_convert": (C.c_int, [C.POINTER(Fp8VArgs), _vp]),
     "vorta_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _vp]),
     "vorta_attn_fwd_batch_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _i32, _vp]),
     "vorta_coreset_select": (C.c_int, [C.POINTER(CoresetArgs), _vp]),
@@ -167,7 +177,7 @@ def lib():
     if h.vorta_abi_version() != ABI_VERSION:
         raise VortaHipError(f"ABI mismatch: library {h.vorta_abi_version()} vs binding {ABI_VERSION}")
     for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs, MixArgs, Fp8QuantArgs,
-                                AttnFp8Ext, PermuteArgs)):
+                                AttnFp8Ext, PermuteArgs, Fp8VArgs)):
         if h.vorta_sizeof(which) != C.sizeof(st):
             raise VortaHipError(f"struct layout mismatch for {st.__name__}: "
                                 f"C {h.vorta_sizeof(which)} vs ctypes {C.sizeof(st)}")

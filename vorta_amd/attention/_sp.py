@@ -13,18 +13,38 @@ import torch
 from .. import ops
 from ..routed import HeadRouting, geometry_for, routed_attention
 from ..ulysses import SP_STATE
-from ..ulysses.engine import UlyssesLayout, balanced_head_order, exchange_and_attend, slot_groups
+from ..ulysses.engine import UlyssesLayout, VWire, balanced_head_order, exchange_and_attend, slot_groups
 
 _LAYOUTS = {}
 _ROUTINGS = {}  # (local expert ids, device) -> HeadRouting: the device tables are built once per distinct local mix
 SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
+# fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
+# 16-bit exchange with the receive-side conversion (A/B; same bytes in the operand buffers either way)
+SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
 
 
-def _layout(H, S, T, D, device, dtype):
+class _SpBuffers:
+    """layout + receive buffers of one (H, S, T, D, dtype) geometry; the e4m3 operand buffers are allocated on first use"""
+
+    def __init__(self, lay):
+        self.lay = lay
+        self.bufs = [lay.new_buffer() for _ in range(4)]
+        self.f8 = None
+        self.vwire = None
+
+    def fp8(self):
+        if self.f8 is None:
+            self.f8 = self.lay.fp8_operands()
+            if SP_V_WIRE:
+                self.vwire = VWire(self.lay, self.f8.v[0])
+        return self.f8, self.vwire
+
+
+def _layout(H, S, T, D, device, dtype) -> _SpBuffers:
     key = (H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, str(device), dtype)
     if key not in _LAYOUTS:
-        lay = UlyssesLayout(H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, device, dtype, SP_STATE.group)
-        _LAYOUTS[key] = (lay, [lay.new_buffer() for _ in range(4)])
+        _LAYOUTS[key] = _SpBuffers(UlyssesLayout(H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, device, dtype,
+                                                 SP_STATE.group))
     return _LAYOUTS[key]
 
 
@@ -50,7 +70,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     P = SP_STATE.sp_size
     Sl = N - T
     S = Sl * P
-    lay, bufs = _layout(H, S, T, D, q.device, q.dtype)
+    sb = _layout(H, S, T, D, q.device, q.dtype)
+    lay, bufs = sb.lay, sb.bufs
     if routing_score is None:  # dense for every head
         experts = [0] * H
         te = T
@@ -76,8 +97,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
         _, _, n_kv = geom.sta_tables(te)
         cost = [float(S + te) ** 2, float(geom.S_low + te) ** 2, float(S) * n_kv]
     # VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot
-    # groups, so the exchange of one group overlaps the attention of another
-    groups = SP_GROUPS if lay.Hl % SP_GROUPS == 0 else 1
+    # groups (as equal as Hl allows), so the exchange of one group overlaps the attention of another
+    groups = min(SP_GROUPS, lay.Hl)
     order = balanced_head_order(experts, cost, P, groups)
     shards = [x[0, :, :Sl] for x in (q, k, v)]
     texts = [x[0, :, Sl:] for x in (q, k, v)] if T else None
@@ -86,19 +107,17 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     local = [experts[h] for h in order[me * lay.Hl:(me + 1) * lay.Hl]]
     rm = lay.row_map
 
+    # the precision switch (set_attention_precision / VORTA_ATTENTION_PRECISION) is about the ROUTED operator; dense
+    # attention -- --native_attention, the PSNR reference -- stays in the dtype of q,k,v on one GPU and under SP alike
     from .. import routed as _routed
-    fp8 = _routed.DEFAULT_FP8 and groups == 1  # the e4m3 path converts the receive buffers after the whole exchange
+    fp8 = _routed.DEFAULT_FP8 and not dense_only
+    f8, vwire = sb.fp8() if fp8 else (None, None)
 
     def attend(g0, g1, gi):
-        if fp8:
-            q8, k8, v8, vd, _ = lay.fp8_views(bufs)
-            if dense_only:
-                ops.attn_fwd(q8[g0:g1], k8[g0:g1], v8[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
-                             q_rows=rm[:S + T], kv_rows=rm[:S + te], v_descale=vd[g0:g1])
-                return
+        views = None
+        if fp8:  # the slot group that has landed is converted while the next one is in flight
+            q8, k8, v8, vd, _ = lay.fp8_views(bufs, out=f8, slots=(g0, g1), vwire=vwire)
             views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
-        else:
-            views = None
         if dense_only:
             ops.attn_fwd(qv[g0:g1], kv[g0:g1], vv[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
                          q_rows=rm[:S + T], kv_rows=rm[:S + te])
@@ -109,7 +128,7 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     # the received heads are written straight into the (1, N, H, D) result the output projection reads
     buf = torch.empty((1, N, H, D), dtype=q.dtype, device=q.device)
     exchange_and_attend(lay, shards, bufs, order, texts, slot_groups(lay.Hl, groups), attend,
-                        buf[0, :Sl].transpose(0, 1), buf[0, Sl:].transpose(0, 1) if T else None)
+                        buf[0, :Sl].transpose(0, 1), buf[0, Sl:].transpose(0, 1) if T else None, vwire=vwire)
     return buf
 
 

@@ -28,6 +28,7 @@ extern "C" int vorta_sizeof(int which) {
     case 7: return (int)sizeof(vorta_fp8_quant_args);
     case 8: return (int)sizeof(vorta_attn_fp8_ext);
     case 9: return (int)sizeof(vorta_permute_args);
+    case 10: return (int)sizeof(vorta_fp8_v_args);
     default: return -1;
   }
 }

@@ -6,13 +6,14 @@
 // them (q . (k - c) = q . k - q . c, a per-query constant), but the e4m3 error of q8 . k8 grows with |k|, so a common
 // component of the keys -- a per-channel mean, usual in trained attention layers -- costs precision for nothing
 // (tools/dbg/fp8_kbias.py: a mean of 3 / 8 standard deviations costs 6 / 12 dB of output PSNR; centring gives all of it
-// back).  ANY vector c works, so c[h][d] is the mean of <= ~1024 evenly spaced key rows of the head: one small launch,
-// fixed summation order (deterministic), no extra pass over K.
+// back).  ANY vector c works, so c[h][d] is the mean of <= ~1024 evenly spaced key TOKENS of the head (the same tokens in
+// either row layout below): one small launch, fixed summation order (deterministic), no extra pass over K.
 //
 // Row layouts: (heads, n_tokens, D) views (seg_len = 0), or ONE row array of n_tokens rows in which row r belongs to head
 // (r / seg_len) % heads (seg_len > 0: the Ulysses receive buffer, ulysses/engine.py -- each rank head keeps its own
 // scales and centre although the head views of that buffer overlap); from row tail_first on only the first tail_len
-// rows of a segment hold data (the text rows behind each head slot), the rest is skipped.
+// rows of a segment hold data (the text rows behind each head slot), the rest is skipped; slot_first / slot_count
+// restrict a call to some head slots (the slot group whose exchange has landed).
 //
 // Workspace (floats): amax_q[H] | amax_k[H] | amax_v[H][D] | qmul[H] | kmul[H] | vmul[H][D] | kmean[H][D] |
 //                     ksum[H][MEAN_BLOCKS][D] | kcnt[H][MEAN_BLOCKS]
@@ -36,10 +37,13 @@ struct QParams {
   int heads, n_tokens, rows_per_block;
   int seg_len, chunks_per_seg;                 // segmented row layout (seg_len > 0)
   int tail_first, tail_len;                    // segments from row tail_first on hold tail_len rows of data each
-  int mean_stride;                             // candidate rows of the centre: r = i * mean_stride
+  int mean_stride, mean_cand;                  // tokens of the centre: s = i * mean_stride, i < mean_cand (per head)
+  int64_t video_tokens;                        // segmented layout: tokens of a head that live in the non-tail segments
   float c0;  // qk_scale * log2(e)
   float* ws; float* v_descale;
   int v_per_head, center_k;
+  int slot_first, slot_count;                  // segmented layout: only head slots [slot_first, slot_first + slot_count)
+  int n_which;                                 // 3: q,k,v; 2: q,k only (v converted elsewhere, vorta_fp8_v_convert)
 };
 
 template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
@@ -60,7 +64,11 @@ __device__ __forceinline__ float kcenter(const QParams& p, int h, int d) {
 // the rows a block works on: [r0, r1) of head `head`, stored under physical head index `hphys`
 __device__ __forceinline__ void block_rows(const QParams& p, int& r0, int& r1, int& head, int& hphys) {
   if (p.seg_len > 0) {
-    const int seg = blockIdx.x / p.chunks_per_seg, c = blockIdx.x - seg * p.chunks_per_seg;
+    // blockIdx.x = (segment group, slot inside the range, row chunk): segment = group * heads + slot
+    const int per = p.slot_count * p.chunks_per_seg;
+    const int sg = blockIdx.x / per, rem = blockIdx.x - sg * per;
+    const int si = rem / p.chunks_per_seg, c = rem - si * p.chunks_per_seg;
+    const int seg = sg * p.heads + p.slot_first + si;
     const int s0 = seg * p.seg_len;
     r0 = s0 + c * p.rows_per_block;
     const int seg_rows = s0 >= p.tail_first ? p.tail_len : p.seg_len;  // tail_first is a multiple of seg_len
@@ -74,34 +82,36 @@ __device__ __forceinline__ void block_rows(const QParams& p, int& r0, int& r1, i
   }
 }
 
-// grid (heads, MEAN_BLOCKS), 1024 threads: partial sums for the centre of the head's keys = mean over the candidate rows
-// r = i * mean_stride that belong to the head (all of them in the (H,S,D) layout).  64 row lanes x 16 channel groups,
-// four rows in flight per lane; fixed reduction order here and in `kcenter` (deterministic).
+// grid (heads, MEAN_BLOCKS), 1024 threads: partial sums for the centre of the head's keys = mean over its tokens
+// s = i * mean_stride (i < n_cand), the same tokens whether the head is a (S,D) view or scattered over the segments of the
+// Ulysses receive layout (so a head gets the same centre, hence the same e4m3 bytes, on one GPU and on a rank of P).
+// 64 row lanes x 16 channel groups, four rows in flight per lane; fixed reduction order here and in `kcenter`.
 template <typename T>
 __global__ __launch_bounds__(1024) void fp8_kmean_kernel(const QParams p) {
   typedef __attribute__((ext_vector_type(8))) T T8;
   constexpr int RL = 64;
-  const int h = blockIdx.x;
+  const int h = p.slot_first + blockIdx.x;
   const int t = threadIdx.x, cc = t & 15, rl = t >> 4;
   const char* base = p.x[1] + (p.seg_len > 0 ? 0 : (int64_t)h * p.x_sh[1]) + cc * 16;
   float s[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s[i] = 0.f;
   int cnt = 0;
-  const int n_cand = (p.n_tokens + p.mean_stride - 1) / p.mean_stride;
-  auto mine = [&](int i) -> bool {
-    if (i >= n_cand) return false;
-    if (p.seg_len <= 0) return true;
-    const int r = i * p.mean_stride, seg = r / p.seg_len;
-    return seg % p.heads == h && !(r >= p.tail_first && r - seg * p.seg_len >= p.tail_len);
+  const int n_cand = p.mean_cand;
+  // physical row of token s of head h
+  auto row_of = [&](int i) -> int64_t {
+    const int64_t tok = (int64_t)i * p.mean_stride;
+    if (p.seg_len <= 0) return tok;
+    if (tok < p.video_tokens) return ((tok / p.seg_len) * p.heads + h) * p.seg_len + tok % p.seg_len;
+    return (int64_t)p.tail_first + (int64_t)h * p.seg_len + (tok - p.video_tokens);
   };
   for (int i0 = blockIdx.y * 4 * RL + rl; i0 < n_cand; i0 += MEAN_BLOCKS * 4 * RL) {
     T8 v[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      ok[u] = mine(i0 + u * RL);
-      if (ok[u]) v[u] = *(const T8*)(base + (int64_t)(i0 + u * RL) * p.mean_stride * p.x_ss[1]);
+      ok[u] = i0 + u * RL < n_cand;
+      if (ok[u]) v[u] = *(const T8*)(base + row_of(i0 + u * RL) * p.x_ss[1]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256) void fp8_absmax_kernel(const QParams p) {
 
 // grid (heads), 128 threads: multipliers from the abs-max slots
 __global__ __launch_bounds__(128) void fp8_scales_kernel(const QParams p) {
-  const int h = blockIdx.x, d = threadIdx.x, H = p.heads;
+  const int h = p.slot_first + blockIdx.x, d = threadIdx.x, H = p.heads;
   const float mq = p.ws[h], mk = p.ws[H + h];
   float* qmul = p.ws + 2 * H + H * D;
   float* kmul = qmul + H;
@@ -192,6 +202,8 @@ __global__ __launch_bounds__(128) void fp8_scales_kernel(const QParams p) {
     qmul[h] = p.c0 * t;
     kmul[h] = 1.f / t;
   }
+  kmean_of(p)[h * D + d] = p.center_k ? kcenter(p, h, d) : 0.f;
+  if (p.n_which < 3) return;  // v: vorta_fp8_v_convert wrote (or will write) v8 and v_descale
   float mv = p.ws[2 * H + h * D + d];
   if (p.v_per_head) {
     __shared__ float red[D];
@@ -205,7 +217,6 @@ __global__ __launch_bounds__(128) void fp8_scales_kernel(const QParams p) {
   }
   vmul[h * D + d] = mv > 0.f ? V_TARGET / mv : 0.f;
   p.v_descale[h * D + d] = mv / V_TARGET;
-  kmean_of(p)[h * D + d] = p.center_k ? kcenter(p, h, d) : 0.f;
 }
 
 __device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -E4M3_MAX, E4M3_MAX); }
@@ -270,13 +281,17 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
   if (a->head_dim != D) return VORTA_EUNSUPPORTED;
   if (a->heads < 0 || a->n_tokens < 0 || a->seg_len < 0 || a->tail_first < 0 || a->tail_len < 0) return VORTA_EINVAL;
-  if (a->seg_len > 0 && a->tail_len > 0 && (a->tail_first % a->seg_len || a->tail_len > a->seg_len)) return VORTA_EINVAL;
+  if (a->seg_len > 0 && (a->tail_first > 0 || a->tail_len > 0) && (a->tail_first % a->seg_len || a->tail_len > a->seg_len))
+    return VORTA_EINVAL;
+  if (a->slot_first < 0 || a->slot_count < 0 || (int64_t)a->slot_first + a->slot_count > a->heads) return VORTA_EINVAL;
+  if ((a->slot_first || a->slot_count) && a->seg_len <= 0) return VORTA_EINVAL;  // a slot range needs the segmented layout
   if (a->heads == 0 || a->n_tokens == 0) return VORTA_OK;
-  if (!a->ws || !a->v_descale || !(a->qk_scale > 0.f)) return VORTA_EINVAL;
+  const int n_which = (a->flags & 4) ? 2 : 3;
+  if (!a->ws || (n_which == 3 && !a->v_descale) || !(a->qk_scale > 0.f)) return VORTA_EINVAL;
   const vorta_tensor* in[3] = {&a->q, &a->k, &a->v};
   const vorta_tensor* out[3] = {&a->q8, &a->k8, &a->v8};
   QParams p{};
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < n_which; ++i) {
     if (!in[i]->ptr || !out[i]->ptr) return VORTA_EINVAL;
     if (((uintptr_t)in[i]->ptr & 15) || (in[i]->stride_s % 8) || (in[i]->stride_h % 8) || in[i]->stride_s < D) return VORTA_EINVAL;
     if (((uintptr_t)out[i]->ptr & 15) || (out[i]->stride_s % 16) || (out[i]->stride_h % 16) || out[i]->stride_s < D) return VORTA_EINVAL;
@@ -288,12 +303,20 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   p.ws = a->ws; p.v_descale = a->v_descale;
   p.v_per_head = a->flags & 1;
   p.center_k = (a->flags >> 1) & 1;
+  p.n_which = n_which;
   p.seg_len = a->seg_len;
-  p.tail_first = a->seg_len > 0 && a->tail_len > 0 ? a->tail_first : 0x7fffffff;
-  p.tail_len = a->tail_len;
+  // the tail rule applies when either field is set: tail_first > 0 with tail_len = 0 is an EMPTY tail region (Wan: no text)
+  const bool has_tail = a->seg_len > 0 && (a->tail_first > 0 || a->tail_len > 0);
+  p.tail_first = has_tail ? a->tail_first : 0x7fffffff;
+  p.tail_len = has_tail ? a->tail_len : 0;
+  p.slot_first = a->slot_count > 0 ? a->slot_first : 0;
+  p.slot_count = a->slot_count > 0 ? a->slot_count : a->heads;
   hipStream_t st = (hipStream_t)hip_stream;
-  const int H = a->heads;
-  hipError_t e = hipMemsetAsync(a->ws, 0, sizeof(float) * (2 * H + H * D), st);
+  const int H = a->heads, h0 = p.slot_first, hn = p.slot_count;
+  // abs-max slots of the heads this call converts: amax_q[h], amax_k[h], amax_v[h][:]
+  hipError_t e = hipMemsetAsync(a->ws + h0, 0, sizeof(float) * hn, st);
+  if (e == hipSuccess) e = hipMemsetAsync(a->ws + H + h0, 0, sizeof(float) * hn, st);
+  if (e == hipSuccess && n_which == 3) e = hipMemsetAsync(a->ws + 2 * H + (size_t)h0 * D, 0, sizeof(float) * hn * D, st);
   if (e != hipSuccess) return vorta_set_hip_error(e);
   // enough workgroups to fill the chip several times over, few enough that the atomics stay cheap
   p.rows_per_block = 1024;
@@ -301,21 +324,29 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   if (p.seg_len > 0) {
     p.chunks_per_seg = (p.seg_len + p.rows_per_block - 1) / p.rows_per_block;
     const int64_t n_seg = ((int64_t)a->n_tokens + p.seg_len - 1) / p.seg_len;
-    if (n_seg * p.chunks_per_seg > 0x7fffffffll) return VORTA_EINVAL;
-    grid = dim3((unsigned)(n_seg * p.chunks_per_seg), 1, 3);
-    p.mean_stride = (int)((int64_t)a->n_tokens / ((int64_t)MEAN_SAMPLES * H));
+    const int64_t n_sg = (n_seg + H - 1) / H;  // segment groups: one segment per head slot each
+    if (n_sg * hn * p.chunks_per_seg > 0x7fffffffll) return VORTA_EINVAL;
+    grid = dim3((unsigned)(n_sg * hn * p.chunks_per_seg), 1, (unsigned)n_which);
   } else {
     p.chunks_per_seg = 1;
-    grid = dim3((unsigned)((a->n_tokens + p.rows_per_block - 1) / p.rows_per_block), (unsigned)H, 3);
-    p.mean_stride = a->n_tokens / MEAN_SAMPLES;
+    grid = dim3((unsigned)((a->n_tokens + p.rows_per_block - 1) / p.rows_per_block), (unsigned)H, (unsigned)n_which);
   }
+  // centre: ~MEAN_SAMPLES evenly spaced tokens of the head (an odd stride: one that divides the segment length would
+  // sample the same offsets of every segment)
+  int64_t head_tokens = a->n_tokens;
+  if (p.seg_len > 0) {
+    const int64_t data_rows = has_tail ? (int64_t)a->tail_first : (int64_t)a->n_tokens;
+    p.video_tokens = (data_rows / p.seg_len / H) * p.seg_len;
+    head_tokens = p.video_tokens + p.tail_len;
+  }
+  p.mean_stride = (int)(head_tokens / MEAN_SAMPLES);
   if (p.mean_stride < 1) p.mean_stride = 1;
-  // an odd stride: a stride that divides the segment length would sample the same offsets of every segment
   p.mean_stride |= 1;
+  p.mean_cand = (int)((head_tokens + p.mean_stride - 1) / p.mean_stride);
   const bool bf = a->dtype == VORTA_BF16;
   if (p.center_k) {
-    if (bf) hipLaunchKernelGGL((fp8_kmean_kernel<__bf16>), dim3((unsigned)H, MEAN_BLOCKS), dim3(1024), 0, st, p);
-    else hipLaunchKernelGGL((fp8_kmean_kernel<_Float16>), dim3((unsigned)H, MEAN_BLOCKS), dim3(1024), 0, st, p);
+    if (bf) hipLaunchKernelGGL((fp8_kmean_kernel<__bf16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((fp8_kmean_kernel<_Float16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return vorta_set_hip_error(e);
   }
@@ -323,7 +354,7 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   else hipLaunchKernelGGL((fp8_absmax_kernel<_Float16>), grid, dim3(256), 0, st, p);
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
-  hipLaunchKernelGGL(fp8_scales_kernel, dim3((unsigned)H), dim3(128), 0, st, p);
+  hipLaunchKernelGGL(fp8_scales_kernel, dim3((unsigned)hn), dim3(128), 0, st, p);
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
   if (bf) hipLaunchKernelGGL((fp8_convert_kernel<__bf16>), grid, dim3(256), 0, st, p);
@@ -331,4 +362,136 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
   return VORTA_OK;
+}
+
+// ---- V on its own (include/vorta_hip.h vorta_fp8_v_absmax / vorta_fp8_v_convert): the sender side of the Ulysses exchange
+// converts its sequence shard of V with the scales of the WHOLE sequence (abs-max all-reduced over the ranks in between the
+// two calls), so V travels as e4m3 and lands ready for the attention kernels.
+namespace {
+
+struct VParams {
+  const char* x; int64_t x_sh, x_ss;  // bytes
+  char* y; int64_t y_sh, y_ss;
+  int heads, n_tokens, rows_per_block, per_head;
+  const int32_t* src_map;
+  float* amax; float* v_descale;
+};
+
+// grid (row chunks, heads): amax[h][d] = max(amax[h][d], max_rows |v[h][row][d]|)
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_v_absmax_kernel(const VParams p) {
+  typedef __attribute__((ext_vector_type(8))) T T8;
+  const int h = blockIdx.y;
+  const int r0 = blockIdx.x * p.rows_per_block, r1 = min(r0 + p.rows_per_block, p.n_tokens);
+  const int t = threadIdx.x, cc = t & 15, rl = t >> 4;
+  const char* base = p.x + (int64_t)h * p.x_sh + cc * 16;
+  float m[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[i] = 0.f;
+  for (int r = r0 + rl; r < r1; r += 16) {
+    const T8 v = *(const T8*)(base + (int64_t)r * p.x_ss);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(to_f(v[i])));
+  }
+  __shared__ float red[16][D + 1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = m[i];
+  __syncthreads();
+  if (t < D) {
+    float cm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) cm = fmaxf(cm, red[j][t]);
+    atomicMax((unsigned*)p.amax + h * D + t, __float_as_uint(cm));
+  }
+}
+
+// grid (row chunks, heads): v8[h] = e4m3(v[src] * 240 / amax[src]) with src = src_map ? src_map[h] : h; the first row
+// chunk of a head also writes v_descale[h] (the same expressions as fp8_scales_kernel / fp8_convert_kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_v_convert_kernel(const VParams p) {
+  typedef __attribute__((ext_vector_type(8))) T T8;
+  const int h = blockIdx.y, hs = p.src_map ? p.src_map[h] : h;
+  const int r0 = blockIdx.x * p.rows_per_block, r1 = min(r0 + p.rows_per_block, p.n_tokens);
+  const int t = threadIdx.x, cc = t & 7, rl = t >> 3;
+  float mul[16];
+  float ph = 0.f;
+  if (p.per_head) {
+    for (int d = 0; d < D; ++d) ph = fmaxf(ph, p.amax[hs * D + d]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float mv = p.per_head ? ph : p.amax[hs * D + cc * 16 + i];
+    mul[i] = mv > 0.f ? V_TARGET / mv : 0.f;
+  }
+  if (p.v_descale && blockIdx.x == 0 && t < D) {
+    const float mv = p.per_head ? ph : p.amax[hs * D + t];
+    p.v_descale[h * D + t] = mv / V_TARGET;
+  }
+  const char* src = p.x + (int64_t)hs * p.x_sh + cc * 32;
+  char* dst = p.y + (int64_t)h * p.y_sh + cc * 16;
+  for (int r = r0 + rl; r < r1; r += 32) {
+    const T8 a = *(const T8*)(src + (int64_t)r * p.x_ss);
+    const T8 b = *(const T8*)(src + (int64_t)r * p.x_ss + 16);
+    float f[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f[i] = clamp448(to_f(a[i]) * mul[i]);
+      f[8 + i] = clamp448(to_f(b[i]) * mul[8 + i]);
+    }
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
+      o[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], lo, true);
+    }
+    *(u32x4*)(dst + (int64_t)r * p.y_ss) = o;
+  }
+}
+
+int v_params(const vorta_fp8_v_args* a, bool convert, VParams& p) {
+  if (!a || a->struct_size != sizeof(vorta_fp8_v_args)) return VORTA_EINVAL;
+  if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
+  if (a->head_dim != D) return VORTA_EUNSUPPORTED;
+  if (a->heads < 0 || a->n_tokens < 0) return VORTA_EINVAL;
+  if (a->heads == 0 || a->n_tokens == 0) return 1;
+  if (!a->amax || !a->v.ptr || ((uintptr_t)a->v.ptr & 15) || (a->v.stride_s % 8) || (a->v.stride_h % 8) || a->v.stride_s < D)
+    return VORTA_EINVAL;
+  p.x = (const char*)a->v.ptr; p.x_sh = a->v.stride_h * 2; p.x_ss = a->v.stride_s * 2;
+  if (convert) {
+    if (!a->v8.ptr || ((uintptr_t)a->v8.ptr & 15) || (a->v8.stride_s % 16) || (a->v8.stride_h % 16) || a->v8.stride_s < D)
+      return VORTA_EINVAL;
+    p.y = (char*)a->v8.ptr; p.y_sh = a->v8.stride_h; p.y_ss = a->v8.stride_s;
+  }
+  p.heads = a->heads; p.n_tokens = a->n_tokens;
+  p.rows_per_block = 1024;
+  p.per_head = a->flags & 1;
+  p.src_map = convert ? a->src_map : nullptr;
+  p.amax = a->amax; p.v_descale = convert ? a->v_descale : nullptr;
+  return VORTA_OK;
+}
+
+}  // namespace
+
+extern "C" int vorta_fp8_v_absmax(const vorta_fp8_v_args* a, void* hip_stream) {
+  VParams p{};
+  const int rc = v_params(a, false, p);
+  if (rc) return rc < 0 ? rc : VORTA_OK;
+  const dim3 grid((unsigned)((p.n_tokens + p.rows_per_block - 1) / p.rows_per_block), (unsigned)p.heads);
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (a->dtype == VORTA_BF16) hipLaunchKernelGGL((fp8_v_absmax_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fp8_v_absmax_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
+}
+
+extern "C" int vorta_fp8_v_convert(const vorta_fp8_v_args* a, void* hip_stream) {
+  VParams p{};
+  const int rc = v_params(a, true, p);
+  if (rc) return rc < 0 ? rc : VORTA_OK;
+  const dim3 grid((unsigned)((p.n_tokens + p.rows_per_block - 1) / p.rows_per_block), (unsigned)p.heads);
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (a->dtype == VORTA_BF16) hipLaunchKernelGGL((fp8_v_convert_kernel<__bf16>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((fp8_v_convert_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
 }

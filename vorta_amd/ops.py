@@ -238,24 +238,50 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
 def attn_fwd_batch(calls) -> None:
     """vorta_attn_fwd_batch: `calls` is a list of dicts of attn_fwd arguments (q,k,v,out + keywords, optional tag /
     flops).  Launches that all resolve to the 256-row pipelined kernel are fused into one grid, in list order
-    (put the longest key loops first); otherwise they are launched one by one."""
-    built = []
+    (put the longest key loops first); otherwise they are launched one by one.
+    Two optional per-call hints apply ONLY to a call that does enter a fused grid (a stand-alone launch keeps the
+    arguments it was given): `fused_n_splits` = at most this many key splits there (inside a fused grid a few-row launch
+    need not fill the chip by itself), `fused_first` = dispatch it ahead of the other launches of the grid."""
+    built, hints = [], []
+
+    def build(c, n_splits=None):
+        kw = {key: val for key, val in c.items() if key not in ("q", "k", "v", "out")}
+        if n_splits is not None:
+            kw["n_splits"] = n_splits
+        return _attn_args(c["q"], c["k"], c["v"], c["out"], **kw)
+
     for c in calls:
         c = dict(c)
         tag, flops = c.pop("tag", ""), c.pop("flops", 0.0)
-        q, k, v, out = c.pop("q"), c.pop("k"), c.pop("v"), c.pop("out")
-        a, ws = _attn_args(q, k, v, out, **c)
+        splits, first = c.pop("fused_n_splits", None), bool(c.pop("fused_first", False))
+        own = c.get("n_splits", 1)
+        hinted = splits is not None and own > max(1, splits)
+        hints.append((hinted, first, c))
+        # built for the fused grid first (the usual outcome; the stand-alone form would allocate a split-key workspace of
+        # hundreds of MB just to drop it)
+        a, ws = build(c, max(1, splits) if hinted else None)
         built.append((a, ws, tag, flops))
     if not built:
         return
-    ok = [_plan(a)[0] == 256 and a.variant != 1 and not (a._ext is not None and a._ext.flags & 1) for a, _, _, _ in built]
-    fusable = 1 < len(built) <= 4 and all(ok)
-    if not fusable and 2 <= sum(ok) <= 4 and sum(ok) < len(built):
-        # mixed workgroup sizes: fuse the 256-row launches, run the others on their own (in list order after them)
-        attn_fwd_batch_built([b for b, o in zip(built, ok) if o])
-        attn_fwd_batch_built([b for b, o in zip(built, ok) if not o], fuse=False)
+
+    def fusable_one(a):
+        return _plan(a)[0] == 256 and a.variant != 1 and not (a._ext is not None and a._ext.flags & 1)
+
+    ok = [fusable_one(a) for a, _, _, _ in built]
+    fuse_all = 1 < len(built) <= 4 and all(ok)
+    fuse_some = not fuse_all and 2 <= sum(ok) <= 4 and sum(ok) < len(built)
+    in_grid = [o and (fuse_all or fuse_some) for o in ok]
+    for i, (hinted, _, c) in enumerate(hints):
+        if hinted and not in_grid[i]:  # stand-alone after all: the caller's own split count
+            a, ws = build(c)
+            built[i] = (a, ws, built[i][2], built[i][3])
+    if fuse_all or fuse_some:
+        fused = sorted((i for i in range(len(built)) if in_grid[i]), key=lambda i: (not hints[i][1], i))
+        attn_fwd_batch_built([built[i] for i in fused])
+        # mixed workgroup sizes: the others run on their own, in list order after the fused grid
+        attn_fwd_batch_built([b for b, g in zip(built, in_grid) if not g], fuse=False)
         return
-    attn_fwd_batch_built(built, fuse=fusable)
+    attn_fwd_batch_built(built, fuse=False)
 
 
 def attn_fwd_batch_built(built, fuse: bool = True) -> None:
@@ -321,14 +347,21 @@ class Fp8Operands:
         return self.ws[base:base + H * D].view(H, D)
 
 
-def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, *,
+def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], scale: Optional[float] = None, *,
                      out: Optional[Fp8Operands] = None, v_per_head: bool = False, center_k: bool = False,
-                     heads: Optional[int] = None, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0) -> Fp8Operands:
+                     heads: Optional[int] = None, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0,
+                     slots: Optional[Tuple[int, int]] = None) -> Fp8Operands:
     """vorta_fp8_quantize_qkv: (H,S,D) bf16/fp16 views -> e4m3 copies (contiguous (H,S,D) uint8) with the softmax scale
     and log2(e) folded into q/k.  `out` = a previous result to overwrite (same shapes).  `center_k`: subtract a per-head
     centre from the keys first (softmax-invariant; see include/vorta_hip.h).  `seg_len > 0`: q,k,v are (1,rows,D) row
     arrays in which row r belongs to head (r // seg_len) % heads (the Ulysses receive layout); from row `tail_first` on
-    only the first `tail_len` rows of a segment hold data."""
+    only the first `tail_len` rows of a segment hold data; `slots` = (first, end): only those head slots of it.
+    `v=None`: q and k only (flags bit2) -- `out.v` / `out.v_descale` are left to `fp8_v_convert`."""
+    skip_v = v is None
+    if skip_v:
+        if out is None:
+            raise ValueError("fp8_quantize_qkv(v=None) needs `out`: its v / v_descale are filled by fp8_v_convert")
+        v = q
     _require_gpu(q, k, v)
     if q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype):
         raise ValueError("q,k,v must share dtype bf16 or fp16")
@@ -358,10 +391,64 @@ def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: O
     a.q, a.k, a.v = _tensor(q), _tensor(k), _tensor(v)
     a.q8, a.k8, a.v8 = _tensor(out.q), _tensor(out.k), _tensor(out.v)
     a.v_descale, a.ws = out.v_descale.data_ptr(), out.ws.data_ptr()
-    a.flags = (1 if v_per_head else 0) | (2 if center_k else 0)
+    a.flags = (1 if v_per_head else 0) | (2 if center_k else 0) | (4 if skip_v else 0)
     a.seg_len, a.tail_first, a.tail_len = seg_len, tail_first, tail_len
+    if slots is not None:
+        if seg_len <= 0 or not (0 <= slots[0] < slots[1] <= H):
+            raise ValueError(f"fp8_quantize_qkv: slots {slots} need the segmented layout and 0 <= first < end <= {H}")
+        a.slot_first, a.slot_count = slots[0], slots[1] - slots[0]
     _C.check(_C.lib().vorta_fp8_quantize_qkv(C.byref(a), _stream()), "vorta_fp8_quantize_qkv")
     return out
+
+
+def _fp8_v_args(v: torch.Tensor, amax: torch.Tensor, per_head: bool):
+    _require_gpu(v, amax)
+    if v.dtype not in _DT or v.dim() != 3:
+        raise ValueError("fp8_v_*: v must be a (H,rows,D) bf16 / fp16 view")
+    if amax.dtype != torch.float32 or not amax.is_contiguous() or amax.dim() != 2 or amax.shape[1] != v.shape[2]:
+        raise ValueError("fp8_v_*: amax must be a contiguous float32 (heads, D) tensor")
+    a = _C.Fp8VArgs()
+    a.struct_size = C.sizeof(_C.Fp8VArgs)
+    a.dtype, a.head_dim, a.heads, a.n_tokens = _DT[v.dtype], v.shape[2], v.shape[0], v.shape[1]
+    a.flags = 1 if per_head else 0
+    a.v = _tensor(v)
+    a.amax = amax.data_ptr()
+    return a
+
+
+def fp8_v_absmax(v: torch.Tensor, amax: torch.Tensor, *, per_head: bool = False) -> torch.Tensor:
+    """vorta_fp8_v_absmax: amax[h][d] = max(amax[h][d], max over rows |v[h][row][d]|) -- the caller zeroes `amax` (H,D)
+    first; several calls accumulate.  Under sequence parallelism the ranks all-reduce it with MAX afterwards."""
+    if amax.shape[0] < v.shape[0]:
+        raise ValueError("fp8_v_absmax: amax has fewer heads than v")
+    a = _fp8_v_args(v, amax, per_head)
+    _C.check(_C.lib().vorta_fp8_v_absmax(C.byref(a), _stream()), "vorta_fp8_v_absmax")
+    return amax
+
+
+def fp8_v_convert(v: torch.Tensor, amax: torch.Tensor, v8: torch.Tensor, *, src_map: Optional[torch.Tensor] = None,
+                  v_descale: Optional[torch.Tensor] = None, per_head: bool = False) -> torch.Tensor:
+    """vorta_fp8_v_convert: v8[h] = e4m3(v[src] * 240 / amax[src]), src = src_map[h] (identity without a map); `v_descale`
+    (heads of v8, D) receives amax[src] / 240.  v8: (heads, rows, D) uint8 view (any head / row strides that keep rows
+    16-byte aligned)."""
+    a = _fp8_v_args(v, amax, per_head)
+    _require_gpu(v8, src_map, v_descale)
+    if v8.dtype != FP8_STORAGE or v8.dim() != 3 or v8.shape[1:] != v.shape[1:]:
+        raise ValueError("fp8_v_convert: v8 must be a (heads, rows, D) uint8 view with v's rows and channels")
+    a.heads = v8.shape[0]
+    a.v8 = _tensor(v8)
+    if src_map is not None:
+        if src_map.dtype != torch.int32 or not src_map.is_contiguous() or src_map.numel() != v8.shape[0]:
+            raise ValueError("fp8_v_convert: src_map must be a contiguous int32 tensor with one entry per head of v8")
+        a.src_map = src_map.data_ptr()
+    elif v8.shape[0] != v.shape[0]:
+        raise ValueError("fp8_v_convert: without a source map v8 needs as many heads as v")
+    if v_descale is not None:
+        if v_descale.dtype != torch.float32 or not v_descale.is_contiguous() or tuple(v_descale.shape) != (v8.shape[0], v.shape[2]):
+            raise ValueError("fp8_v_convert: v_descale must be a contiguous float32 (heads of v8, D) tensor")
+        a.v_descale = v_descale.data_ptr()
+    _C.check(_C.lib().vorta_fp8_v_convert(C.byref(a), _stream()), "vorta_fp8_v_convert")
+    return v8
 
 
 def coreset_select(x: torch.Tensor, latent: Sequence[int], group: Sequence[int], n_keep: int, *,

@@ -267,6 +267,14 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
             # text queries see every valid key (sliding_attn_flex.py:108); padded ones see nothing -> zeros
             txt = dict(base, out=o_e[2], n_q=T, q_valid=te, n_kv=S + te, n_splits=_auto_splits(sl["n_heads"], T, S + te),
                        tag="sliding_text", flops=nheads(2) * 4.0 * D * te * (S + te), **sl)
+            if FUSED_TEXT_FIRST:
+                # hints for ops.attn_fwd_batch, honoured only if this call joins a fused grid: there the one query block
+                # per head need not fill the chip, only not be the grid's tail -- dispatched FIRST and unsplit it is as
+                # long as a full-attention workgroup, with no partials to write and no combine launch.  A stand-alone
+                # launch (T not a multiple of 256, variant 1, ...) keeps the 64-232 key splits above.  Measured on one
+                # box, splits 0(last, auto) / 8 / 4 / 2 / 1: rank of 8 549.5 / 542.2 / 540.0 | 557.0 (4) / 553.9 / 552.8 ms;
+                # one GPU 4 130 / 4 115 (8) | 4 226 (4) / 4 208 (1)
+                txt.update(fused_n_splits=FUSED_TEXT_SPLITS, fused_first=True)
             if rm is None:
                 txt.update(q_row_offset=S)
             else:
@@ -276,7 +284,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
 
     def launch(calls):
         for c in calls:
-            c = dict(c)
+            c = {key: val for key, val in c.items() if key not in ("fused_n_splits", "fused_first")}
             ops.attn_fwd(c.pop("q"), c.pop("k"), c.pop("v"), c.pop("out"), **c)
 
     if fused and not concurrent and sliding_block_rows == 0:
@@ -287,16 +295,6 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     if not concurrent:
         calls = [c for fn, on in experts if on for c in fn()]
         if fused:
-            if FUSED_TEXT_FIRST:
-                # the text-query launch of the sliding expert (one query block per head against every key) does not have
-                # to fill the chip inside a fused grid, only not to be its tail: scheduled FIRST and unsplit it is as long
-                # as a full-attention workgroup, with no partials to write and no combine launch (the stand-alone launch
-                # cuts the keys 64-232 ways).  Measured on one box, splits 0(last, auto) / 8 / 4 / 2 / 1: rank of 8
-                # 549.5 / 542.2 / 540.0 | 557.0 (4) / 553.9 / 552.8 ms; one GPU 4 130 / 4 115 (8) | 4 226 (4) / 4 208 (1)
-                for c in calls:
-                    if c.get("tag") == "sliding_text":
-                        c["n_splits"] = min(c["n_splits"], FUSED_TEXT_SPLITS)
-                calls.sort(key=lambda c: c.get("tag") != "sliding_text")
             ops.attn_fwd_batch(calls)
         else:
             launch(calls)
@@ -333,8 +331,9 @@ def soft_mixture_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, ro
     if out is None:
         out = torch.empty_like(q)
     bufs = [torch.empty_like(out) for _ in range(3)]
+    # fp8=False: the training-time forward feeds a loss; the e4m3 switch is an inference-time option of the routed op
     routed_attention(q, k, v, HeadRouting.every_head_everywhere(H, q.device), geom, model=model, text_len=text_len,
-                     text_valid=text_valid, scale=scale, expert_outs=bufs)
+                     text_valid=text_valid, scale=scale, expert_outs=bufs, fp8=False)
     ops.mix_experts([b[0] if b.dim() == 4 else b for b in bufs], routing_score, out[0] if out.dim() == 4 else out)
     return out
 

@@ -35,46 +35,59 @@ TRANSPORT = __import__("os").environ.get("VORTA_SP_TRANSPORT", "a2a")
 HIP_STAGING = __import__("os").environ.get("VORTA_SP_STAGING", "hip") != "torch"
 
 
+def group_sizes(Hl: int, groups: int) -> List[int]:
+    """sizes of `groups` slot groups of Hl local heads: as equal as possible, the larger ones first (5 -> 3 + 2)"""
+    groups = max(1, min(int(groups), Hl))
+    base, rem = divmod(Hl, groups)
+    return [base + 1] * rem + [base] * (groups - rem)
+
+
 def balanced_head_order(experts: Sequence[int], cost_of_expert: Sequence[float], P: int, groups: int = 1) -> List[int]:
     """Heads grouped by destination rank (rank j owns order[j*Hl:(j+1)*Hl]): exactly Hl heads per rank,
     greedy longest-processing-time on the expert costs.  Inside a rank the heads are ascending (groups = 1) or,
-    for the overlapped exchange, split the same way into `groups` equal slot groups of near-equal cost (ascending
-    inside a group).  Deterministic, so every rank computes the same order without communicating."""
+    for the overlapped exchange, split the same way into `groups` slot groups (`group_sizes`) of near-equal cost per head
+    slot (ascending inside a group).  Deterministic, so every rank computes the same order without communicating."""
     H = len(experts)
     assert H % P == 0, f"heads {H} must be divisible by the sequence-parallel size {P}"
     Hl = H // P
-    assert Hl % groups == 0, f"{Hl} heads per rank do not split into {groups} slot groups"
 
-    def lpt(heads, n_bins, size):
-        load = [0.0] * n_bins
-        bins: List[List[int]] = [[] for _ in range(n_bins)]
+    def lpt(heads, sizes):
+        load = [0.0] * len(sizes)
+        bins: List[List[int]] = [[] for _ in sizes]
         for h in sorted(heads, key=lambda i: (-cost_of_expert[int(experts[i])], i)):
-            j = min((r for r in range(n_bins) if len(bins[r]) < size), key=lambda r: (load[r], r))
+            # fill by load per slot, so a larger group takes proportionally more work
+            j = min((r for r in range(len(sizes)) if len(bins[r]) < sizes[r]), key=lambda r: (load[r] / sizes[r], r))
             bins[j].append(h)
             load[j] += cost_of_expert[int(experts[h])]
         return bins
 
     order: List[int] = []
-    for b in lpt(range(H), P, Hl):
-        if groups == 1:
+    sizes = group_sizes(Hl, groups)
+    for b in lpt(range(H), [Hl] * P):
+        if len(sizes) == 1:
             order += sorted(b)
         else:
-            for g in lpt(b, groups, Hl // groups):
+            for g in lpt(b, sizes):
                 order += sorted(g)
     return order
 
 
 def slot_groups(Hl: int, groups: int) -> List[tuple]:
-    n = Hl // groups
-    return [(g * n, (g + 1) * n) for g in range(groups)]
+    out, g0 = [], 0
+    for n in group_sizes(Hl, groups):
+        out.append((g0, g0 + n))
+        g0 += n
+    return out
 
 
-def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, groups, attend, out_shard, out_text):
+def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, groups, attend, out_shard, out_text,
+                        vwire: Optional["VWire"] = None):
     """One layer under sequence parallelism.  `groups` = slot ranges of the local heads; `attend(g0, g1, index)`
     enqueues the attention over local head slots [g0, g1) of the layout buffers.  With one group this is
     scatter -> attention -> gather.  With several, the exchange of group g+1 and the return of group g-1 are in
-    flight while group g computes (both run on the communicator's stream, the attention on the current one)."""
-    handles = lay.scatter_heads_start(shards, bufs[:3], head_order, texts, groups)
+    flight while group g computes (both run on the communicator's stream, the attention on the current one).
+    `vwire`: v travels as e4m3 (converted on this side with the scales of the whole sequence) into `vwire.buf`."""
+    handles = lay.scatter_heads_start(shards, bufs[:3], head_order, texts, groups, vwire=vwire)
     state = lay.gather_heads_begin(out_shard, head_order)
     back = []
     for gi, (g0, g1) in enumerate(groups):
@@ -84,6 +97,28 @@ def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, g
     for h in back:
         lay._finish(h)
     lay.gather_heads_end(bufs[3], state, out_text)
+
+
+class VWire:
+    """State of `v on the wire as e4m3` for one layout (fp8 attention under sequence parallelism): the sender converts
+    its sequence shard of v with the scales of the WHOLE sequence -- per-(head, channel) abs-max of the shard
+    (`ops.fp8_v_absmax`), one MAX all-reduce of H x D floats, `ops.fp8_v_convert` straight into destination head order
+    -- so v crosses the links at half the bytes and lands as the kernels read it: 3.5 instead of 4 tensor-volumes per
+    layer on the wire, and the receive-side quantiser touches q and k only.  The bytes and `v_descale` are the ones the
+    receive-side conversion of the 16-bit sequence would produce (abs-max over shards = abs-max over the sequence)."""
+
+    def __init__(self, lay: "UlyssesLayout", buf: torch.Tensor):
+        dev = lay.device
+        self.buf = buf  # (rows_total, D) uint8 receive buffer = the v8 operand of the attention kernels
+        self.amax = torch.zeros((lay.H, lay.D), dtype=torch.float32, device=dev)
+        self.descale_all = torch.zeros((lay.H, lay.D), dtype=torch.float32, device=dev)  # in head_order
+        self.stage = torch.empty((lay.H, lay.Sl, lay.D), dtype=torch.uint8, device=dev)
+        self.lay = lay
+
+    def descale(self, g0: int, g1: int) -> torch.Tensor:
+        """v_descale rows of the local head slots [g0, g1)"""
+        b = self.lay.rank * self.lay.Hl
+        return self.descale_all[b + g0:b + g1]
 
 
 def make_row_map(S: int, T: int, P: int, Hl: int, device) -> torch.Tensor:
@@ -119,18 +154,34 @@ class UlyssesLayout:
         # takes the abs-max of the whole buffer
         return torch.zeros((self.rows_total, self.D), dtype=self.dtype, device=self.device)
 
-    def fp8_views(self, bufs: Sequence[torch.Tensor], scale: Optional[float] = None, out=None):
+    def fp8_operands(self) -> "ops.Fp8Operands":
+        """e4m3 operand buffers of the receive layout (allocated once per layout; `fp8_views(out=...)` fills them)"""
+        nws = ops._C.lib().vorta_fp8_quant_ws_floats(self.Hl, self.D)
+        return ops.Fp8Operands(*(torch.zeros((1, self.rows_total, self.D), dtype=torch.uint8, device=self.device) for _ in range(3)),
+                               torch.zeros((self.Hl, self.D), dtype=torch.float32, device=self.device),
+                               torch.zeros(nws, dtype=torch.float32, device=self.device))
+
+    def fp8_views(self, bufs: Sequence[torch.Tensor], scale: Optional[float] = None, out=None,
+                  slots: Optional[Sequence[int]] = None, vwire: Optional["VWire"] = None):
         """e4m3 copies of the q, k, v receive buffers for the fp8 attention kernels: ONE conversion of each whole buffer
         (the head views overlap, so converting per view would redo it Hl times) in the quantiser's segmented row layout
         -- row r belongs to head slot (r // Sl) % Hl, text rows behind the video rows -- so every local head keeps its
-        own scales and key centre.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
+        own scales and key centre.  `slots` = (g0, g1): only the rows of those head slots (the slot group that has
+        landed; scales are per head, so the bytes are the ones a single call writes).  `vwire`: v arrived as e4m3
+        (`out.v` is its receive buffer): q and k only.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
         from ..routed import FP8_CENTER_K
         x = [b.view(1, self.rows_total, self.D) for b in bufs[:3]]
+        if vwire is not None:
+            if out is None or out.v.data_ptr() != vwire.buf.data_ptr():
+                raise ValueError("fp8_views(vwire=...): `out` must be the operands whose v is the e4m3 receive buffer")
+            x[2] = None
         f8 = ops.fp8_quantize_qkv(*x, scale, out=out, center_k=FP8_CENTER_K, heads=self.Hl, seg_len=self.Sl,
-                                  tail_first=self.rows_video, tail_len=self.T)
+                                  tail_first=self.rows_video, tail_len=self.T,
+                                  slots=None if slots is None or tuple(slots) == (0, self.Hl) else tuple(slots))
         shape, stride = (self.Hl, self.rows_total - (self.Hl - 1) * self.Sl, self.D), (self.Sl * self.D, self.D, 1)
         hv = lambda t: t[0].as_strided(shape, stride)
-        return hv(f8.q), hv(f8.k), hv(f8.v), f8.v_descale, f8
+        vd = f8.v_descale if vwire is None else vwire.descale(0, self.Hl)
+        return hv(f8.q), hv(f8.k), hv(f8.v), vd, f8
 
     def head_view(self, buf: torch.Tensor) -> torch.Tensor:
         """(Hl, rows, D) overlapping view: head slot i starts i*Sl rows into the buffer."""
@@ -192,6 +243,17 @@ class UlyssesLayout:
             o.copy_(ho)
         return None
 
+    def _start_allreduce_max(self, x: torch.Tensor):
+        """MAX all-reduce of a small float tensor over the sequence-parallel group; handle for `_finish`"""
+        if self.loopback or self.P == 1:
+            return None
+        if not self._staged():
+            return ("works", [dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.group, async_op=True)])
+        h = x.detach().to("cpu")
+        dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+        x.copy_(h)
+        return None
+
     def _head_map(self, heads: Sequence[int]) -> torch.Tensor:
         """int32 device copy of a head list for `ops.permute_heads`, built once per distinct list (a host-to-device copy
         per layer would stall the stream)."""
@@ -232,14 +294,27 @@ class UlyssesLayout:
 
     def scatter_heads_start(self, shards: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor],
                             head_order: Sequence[int], texts: Optional[Sequence[torch.Tensor]] = None,
-                            groups: Optional[Sequence[Sequence[int]]] = None):
+                            groups: Optional[Sequence[Sequence[int]]] = None, vwire: Optional[VWire] = None):
         """`scatter_heads` split by local head slots: `groups` = [(slot0, slot1), ...] (default: one group with all
         Hl slots).  One point-to-point group is started per slot group, in order; returns their handles, so the
         attention over the slots of group g can be enqueued after `_finish(handles[g])` while later groups are still
-        in flight."""
+        in flight.  `vwire`: the third tensor (v) is converted to e4m3 on this side and travels into `vwire.buf`
+        (bufs[2] is not used): abs-max of the shard, MAX all-reduce (in flight under the q/k staging pass), conversion
+        into destination head order (under the q/k transfers when they are one collective)."""
         Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
         blk = Hl * Sl
         groups = [(0, Hl)] if groups is None else [tuple(g) for g in groups]
+        red = None
+        v_shard = v_text = None
+        if vwire is not None:
+            v_shard, v_text = shards[2], (texts[2] if texts is not None and self.T else None)
+            shards, bufs = shards[:2], bufs[:2]
+            texts = texts[:2] if texts is not None else None
+            vwire.amax.zero_()
+            ops.fp8_v_absmax(v_shard, vwire.amax)
+            if v_text is not None:  # replicated: every rank adds the same rows
+                ops.fp8_v_absmax(v_text, vwire.amax)
+            red = self._start_allreduce_max(vwire.amax)
         srcs = []
         staged = []
         for t, (x, buf) in enumerate(zip(shards, bufs)):
@@ -259,8 +334,8 @@ class UlyssesLayout:
                 idx = torch.as_tensor(list(head_order), device=staged[0][0].device)
                 for x, y in staged:
                     torch.index_select(x, 0, idx, out=y)
+        mine = head_order[me * Hl:(me + 1) * Hl]
         if texts is not None and self.T:  # texts[t]: (H, T, D) replicated; its rows follow each local head slot's video
-            mine = head_order[me * Hl:(me + 1) * Hl]
             if texts[0].is_cuda and HIP_STAGING:
                 dsts = [buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1)) for buf in bufs]
                 ops.permute_heads(list(texts), dsts, src_map=self._head_map(mine))
@@ -269,10 +344,27 @@ class UlyssesLayout:
                     for i in range(Hl):
                         r0 = self.rows_video + i * Sl
                         buf[r0:r0 + self.T].copy_(t[mine[i]])
+
+        def convert_v():
+            self._finish(red)
+            ops.fp8_v_convert(v_shard, vwire.amax, vwire.stage, src_map=self._head_map(head_order),
+                              v_descale=vwire.descale_all)
+            if v_text is not None:
+                dst = vwire.buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1))
+                ops.fp8_v_convert(v_text, vwire.amax, dst, src_map=self._head_map(mine))
+            return (vwire.stage, [j * Hl for j in range(P)], vwire.buf)
+
         in_rank_order = all(first == [j * Hl for j in range(P)] for _, first, _ in srcs)
         if TRANSPORT == "a2a" and groups == [(0, Hl)] and in_rank_order and P > 1:
             # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides
-            return [self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs])]
+            h = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs])
+            if vwire is not None:  # converted while q and k are on the links
+                src, _, buf = convert_v()
+                hv = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk])])
+                h = None if h is None and hv is None else ("works", (h[1] if h else []) + (hv[1] if hv else []))
+            return [h]
+        if vwire is not None:
+            srcs.append(convert_v())
         for src, first, buf in srcs:
             buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D).copy_(src[first[me]:first[me] + Hl])
         handles = []
@@ -358,11 +450,10 @@ class UlyssesRoutedAttention:
 
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
                  rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
-                 sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False, fp8: bool = False):
+                 sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False, fp8: bool = False,
+                 v_wire: bool = True):
         from ..routed import HeadRouting, RoutedGeometry
-        if fp8 and groups != 1:
-            raise ValueError("fp8 converts the receive buffers after the whole exchange: one slot group")
-        self.fp8, self.f8 = fp8, None
+        self.fp8, self.f8, self.vwire = fp8, None, None
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
         self.cfg, self.P, self.rank = cfg, P, rank
@@ -391,6 +482,12 @@ class UlyssesRoutedAttention:
         if loopback:  # the chunks no peer will fill: finite values of the same distribution
             for b in self.bufs[:3]:
                 b.normal_()
+        if fp8:
+            self.f8 = self.lay.fp8_operands()
+            if v_wire:  # v travels as e4m3 straight into the operand buffer
+                self.vwire = VWire(self.lay, self.f8.v[0])
+                if loopback:
+                    self.f8.v.random_(0, 120)  # finite e4m3 bytes in the chunks no peer fills
         self.out_shard = torch.empty((H, self.lay.Sl, 128), dtype=dtype, device=device)
         self.out_text = torch.empty((H, T, 128), dtype=dtype, device=device) if T else None
         if self.te or cfg["model"] == "wan":
@@ -403,12 +500,12 @@ class UlyssesRoutedAttention:
 
         def attend(g0, g1, gi):
             views = None
-            if self.fp8:
-                q8, k8, v8, vd, self.f8 = self.lay.fp8_views(self.bufs, out=self.f8)
+            if self.fp8:  # the slot group that has landed is converted while the next one is in flight
+                q8, k8, v8, vd, self.f8 = self.lay.fp8_views(self.bufs, out=self.f8, slots=(g0, g1), vwire=self.vwire)
                 views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
             routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], self.geom, model=self.cfg["model"],
                              text_len=self.cfg["text"], text_valid=self.te, out=o[g0:g1], concurrent=self.concurrent,
                              fused=self.fused, sliding_block_rows=self.sliding_block_rows, fp8=False, fp8_views=views)
 
         exchange_and_attend(self.lay, shards, self.bufs, self.orders[l], texts, self.groups, attend, self.out_shard,
-                            self.out_text)
+                            self.out_text, vwire=self.vwire)
