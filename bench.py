@@ -43,6 +43,8 @@ CONFIGS = {
                        tile=(7, 9, 8), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
     "wan14b-77f": dict(model="wan", latent=(20, 45, 80), heads=40, layers=40, fwd_per_step=2, text=0, text_valid=0,
                        tile=(5, 9, 8), window=(3, 3, 3), group=(2, 3, 2), rate=0.5, dtype="bf16"),
+    "wan-tiny": dict(model="wan", latent=(9, 12, 16), heads=8, layers=4, fwd_per_step=2, text=0, text_valid=0,
+                     tile=(3, 6, 8), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
     # tiny, for rehearsals
     "tiny": dict(model="hunyuan", latent=(9, 12, 16), heads=8, layers=4, fwd_per_step=1, text=64, text_valid=40,
                  tile=(3, 6, 8), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
@@ -162,6 +164,117 @@ def cpu_baseline(cfg, layer_ids):
                       f"{cfg['fwd_per_step']} forward(s) per step"}
 
 
+def processor_level(cfg, mix, dev, dt, fp8):
+    """The production call path of one denoising step (hunyuan.py:521-610 / wan.py:308-386 behind
+    modeling_hunyuan.py:491-499,555-563): modules of the model's real width with random weights (the shapes of
+    diffusers' Attention: to_q/k/v, norm_q/k, add_*_proj + norm_added_* + to_add_out in a dual-stream block, to_out),
+    one Router per block whose bias encodes the layer's synthetic route (weights 0: softmax(bias) puts 0.999 on the
+    chosen expert), the step's routes from ONE RoutePlan.compute inside the timed step, every layer's processor called
+    the way BoundProcessor calls it (patch/_engine.py:148-154: scores + device head lists of the plan).
+    Returns (one_step, info)."""
+    from torch import nn
+
+    import vorta_amd
+    from vorta_amd.attention import (HunyuanVideoFlashAttnProcessorTripleEval, WanAttnProcessorTripleEval,
+                                     create_sliding_tile_attn_mask_func)
+    from vorta_amd.patch._engine import RoutePlan
+    from vorta_amd.patch.router import Router
+    from vorta_amd.patch.utils import prepare_hunyuan_self_attn_kwargs, prepare_wan_self_attn_kwargs
+    H, L, T, te = cfg["heads"], cfg["layers"], cfg["text"], cfg["text_valid"]
+    S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
+    hy = cfg["model"] == "hunyuan"
+    width = H * 128
+    vorta_amd.set_attention_precision("fp8" if fp8 else "native")
+    gen = torch.Generator(device=dev).manual_seed(1234)
+
+    def lin(i, o):
+        m = nn.Linear(i, o, bias=True, device=dev, dtype=dt)
+        with torch.no_grad():
+            m.weight.normal_(0.0, i ** -0.5, generator=gen)
+            m.bias.normal_(0.0, 0.02, generator=gen)
+        return m.requires_grad_(False)
+
+    def rms(n):
+        return nn.RMSNorm(n, eps=1e-6, device=dev, dtype=dt).requires_grad_(False)
+
+    class Attn(nn.Module):
+        def __init__(self, dual):
+            super().__init__()
+            self.heads = H
+            self.to_q, self.to_k, self.to_v = lin(width, width), lin(width, width), lin(width, width)
+            self.norm_q, self.norm_k = (rms(128), rms(128)) if hy else (rms(width), rms(width))
+            self.add_q_proj = self.add_k_proj = self.add_v_proj = None
+            self.norm_added_q = self.norm_added_k = self.to_add_out = None
+            if dual:
+                self.add_q_proj, self.add_k_proj, self.add_v_proj = lin(width, width), lin(width, width), lin(width, width)
+                self.norm_added_q, self.norm_added_k = rms(128), rms(128)
+                self.to_add_out = lin(width, width)
+            # single-stream Hunyuan blocks are `pre_only` (no to_out: proj_out of the block follows); Wan always projects
+            self.to_out = nn.ModuleList([lin(width, width), nn.Dropout(0.0)]) if (dual or not hy) else None
+
+    # HunyuanVideo: 20 dual-stream + 40 single-stream blocks (public config); Wan: every block alike
+    n_dual = L // 3 if hy else 0
+    dual_attn, single_attn = (Attn(True) if n_dual else None), Attn(False)
+    layer_ids = [layer_experts(cfg, mix, l) for l in range(L)]
+    routers = []
+    for e in layer_ids:
+        r = Router(width, H).to(device=dev, dtype=torch.bfloat16)
+        with torch.no_grad():
+            r.linear.weight.zero_()
+            b = torch.zeros(H, 3)
+            b[torch.arange(H), torch.as_tensor(e)] = 8.0
+            r.linear.bias.copy_(b.reshape(-1))
+        routers.append(r)
+    plan = RoutePlan(routers)
+    temb = torch.randn((1, width), generator=gen, device=dev, dtype=dt)
+    hidden = torch.randn((1, S, width), generator=gen, device=dev, dtype=dt)
+    tau = 0.5
+    sak = dict(latent_shape=cfg["latent"], window_size=cfg["window"], tile_size=cfg["tile"],
+               lowres_window_size=cfg["group"], lowres_reduction_rate=cfg["rate"])
+    if hy:
+        enc = torch.randn((1, T, width), generator=gen, device=dev, dtype=dt)
+        mask = torch.zeros((1, 1, 1, S + T), dtype=torch.bool, device=dev)
+        mask[..., :S + te] = True
+        ang = torch.rand((S, 64), generator=gen, device=dev) * 6.28
+        rope = (ang.cos().repeat_interleave(2, dim=1).contiguous(), ang.sin().repeat_interleave(2, dim=1).contiguous())
+        kw = prepare_hunyuan_self_attn_kwargs(sak, dev, tau_sparse=tau)
+        # per prompt, outside the step (pipeline_hunyuan.py:378-392)
+        kw["flex_attn_mask_func"] = create_sliding_tile_attn_mask_func(cfg["latent"], cfg["window"], cfg["tile"], T, te, dev)
+        proc = HunyuanVideoFlashAttnProcessorTripleEval()
+    else:
+        ang = torch.rand((1, 1, S, 64), generator=gen, device=dev, dtype=torch.float64) * 6.28
+        rope = torch.polar(torch.ones_like(ang), ang)
+        kw = prepare_wan_self_attn_kwargs(sak, dev, tau_sparse=tau)
+        proc = WanAttnProcessorTripleEval()
+    sink = []
+
+    def one_step():
+        plan.compute(temb, tau)
+        for _ in range(cfg["fwd_per_step"]):
+            for l in range(L):
+                if hy:
+                    a = dual_attn if l < n_dual else single_attn
+                    out = proc(a, hidden, enc, mask, rope, routing_score=plan.scores(l), head_routing=plan.routing(l), **kw)
+                else:
+                    out = proc(single_attn, hidden, None, None, rope, routing_score=plan.scores(l),
+                               head_routing=plan.routing(l), **kw)
+        sink[:] = [out]
+
+    def fingerprint_tensor():
+        o = sink[0]
+        return o[0] if isinstance(o, tuple) else o
+
+    # the plan must reproduce the synthetic routes exactly (checked once, outside the timed region)
+    plan.compute(temb, tau)
+    got = plan._out[1].cpu().numpy()
+    assert (got == np.stack(layer_ids)).all(), "route plan does not reproduce the synthetic routing mix"
+    info = {"level": "processor", "width": width, "blocks": (f"{n_dual} dual-stream + {L - n_dual} single-stream" if hy
+                                                            else f"{L} self-attention"),
+            "routes": "device-resident (RoutePlan.routing: head lists + counts, every expert grid sized for H slots)",
+            "sync_debug_mode": "error"}
+    return one_step, fingerprint_tensor, layer_ids, info
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
     <same arguments>` as a child (one rank per GPU, rendezvous on 127.0.0.1 at a free port) and pass its stdout / stderr
@@ -210,6 +323,12 @@ def main():
     ap.add_argument("--sliding-block-rows", type=int, default=0, choices=[0, 128, 256],
                     help="query rows per workgroup of the sliding-tile launch (0 = library heuristic; 256 lets it join "
                          "the fused grid)")
+    ap.add_argument("--level", default="attention", choices=["attention", "processor"],
+                    help="attention (default, the BASELINE line): the routed-attention op on resident post-RoPE q,k,v with the "
+                         "routes given (SURVEY.md section 8d).  processor: the call path the inference scripts take -- per "
+                         "denoising step ONE vorta_route_plan call, then every block's attention processor __call__ "
+                         "(q/k/v projections at the model's width, qk-norm + RoPE, device-resident routes from the plan, "
+                         "routed attention, output projection) -- under torch.cuda.set_sync_debug_mode('error')")
     ap.add_argument("--experts", default="fused", choices=["fused", "serial", "concurrent"],
                     help="fused: the experts of a layer as ONE grid (vorta_attn_fwd_batch); serial: one launch per "
                          "expert on one stream; concurrent: experts on side HIP streams")
@@ -273,7 +392,12 @@ def main():
         if world != 1:
             raise SystemExit("--emulate-rank runs on one GPU")
         P = emu
-    if P == 1:
+    proc_info = None
+    if args.level == "processor":
+        if P != 1:
+            raise SystemExit("--level processor runs on one GPU")
+        one_step, fp_tensor, layer_ids, proc_info = processor_level(cfg, args.mix, dev, dt, fp8)
+    elif P == 1:
         geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], dev)
         routings = [HeadRouting.from_expert_ids(e, dev) for e in layer_ids]
         sets = []
@@ -314,9 +438,15 @@ def main():
     barrier()
     tl = ops.Timeline()
     ops.set_timeline(tl)
+    if proc_info is not None:  # any host-device synchronisation inside the step raises
+        torch.cuda.set_sync_debug_mode("error")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    try:
+        for _ in range(args.steps):
+            one_step()
+    finally:
+        if proc_info is not None:
+            torch.cuda.set_sync_debug_mode("default")
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_timeline(None)
@@ -327,7 +457,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     # order-independent fingerprint of the last layer's output (all ranks): lets two runs of one workload -- other slot
     # groups, v on the wire or not -- be compared bit for bit from their JSON lines
-    fp_t = (out if P == 1 else sp.out_shard).contiguous().view(torch.int16).to(torch.int64)
+    fp_t = (fp_tensor() if proc_info is not None else out if P == 1 else sp.out_shard).contiguous().view(torch.int16).to(torch.int64)
     fingerprint = (fp_t * (torch.arange(fp_t.numel(), device=dev).view(fp_t.shape) % 8191 + 1)).sum().reshape(1)
     if world > 1:
         fingerprint = fingerprint * (rank + 1)
@@ -343,6 +473,10 @@ def main():
         d["ms"] += v["ms"]; d["flops"] += v["flops"]; d["launches"] += v["launches"]
     dom_sym = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
     dom = by_kernel[dom_sym]
+    if proc_info is not None and dom["flops"] == 0.0:
+        # device-resident routes: the launches do not know their head counts on the host; every attention launch of a
+        # layer is in the fused grid, whose work is the layer's algorithmic work
+        dom["flops"] = step_flops * args.steps
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     roofline = {"bound": "mfma", "kernel": dom_sym,
                 "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
@@ -387,6 +521,8 @@ def main():
                    **({"fp8": "e4m3 q,k,v and probabilities on the fp8 MFMA; conversion (per-head scales, key centring "
                               + ("on" if __import__("vorta_amd.routed", fromlist=["x"]).FP8_CENTER_K else "off")
                               + ") inside the timed step; bf16 in / out"} if fp8 else {}),
+                   **({"call_path": proc_info, "ms_per_layer": round(ms_per_step / (L * cfg["fwd_per_step"]), 3)}
+                      if proc_info is not None else {}),
                    "step_algorithmic_pflop": round(step_flops / 1e15, 3),
                    "step_tflops_per_gpu": round(step_flops / (ms_per_step * 1e-3) / 1e12 / (emu or world), 1)},
         "roofline": roofline,
@@ -416,7 +552,7 @@ def main():
             roofline["library_gemm_tflops"] = None
             roofline["library_gemm_error"] = f"{type(exc).__name__}: {exc}"[:200]
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not emu:
+        if world == 1 and not args.no_cpu_baseline and not emu and proc_info is None:
             res["cpu_baseline"] = cpu_baseline(cfg, layer_ids)
         print(json.dumps(res), flush=True)
     if world > 1:

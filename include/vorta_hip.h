@@ -257,6 +257,13 @@ typedef struct vorta_coreset_args {
   int64_t keep_rows_stride_h;
   int32_t* drop_rows; /* may be NULL (K side needs no drop list) */
   int64_t drop_rows_stride_h;
+  /* ABI 4: optional second keep list for the KEY side, same length as keep_rows: per group its centre and kept margins
+   * together, in ascending token order, groups in order, then the tail -- the same SET of rows as keep_rows in an order
+   * that keeps the gathered K/V rows of a tile close in memory (the softmax does not depend on key order; the query
+   * side must keep the packed order: positions < G are the centres the duplicate list refers to).  keep_rows may be NULL
+   * when only this list is wanted. */
+  int32_t* keep_rows_kv;
+  int64_t keep_rows_kv_stride_h;
 } vorta_coreset_args;
 
 int vorta_coreset_select(const vorta_coreset_args* args, void* hip_stream);

@@ -90,3 +90,15 @@ def test_bench_emulated_rank_fp8_line():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["emulated_rank_of"] == 2 and j["dtype"] == "fp8" and j["roofline"]["kernel"].startswith("attn8_")
+
+
+def test_bench_processor_level_line():
+    """--level processor: the route plan and every block's processor __call__ inside the timed step, under
+    torch.cuda.set_sync_debug_mode("error") -- a host synchronisation anywhere on that path fails the run."""
+    for extra in ([], ["--dtype", "fp8"], ["--config", "wan-tiny"]):
+        r = subprocess.run([sys.executable, "bench.py", "--config", "tiny", "--steps", "2", "--warmup", "1", "--level", "processor",
+                            "--no-gemm-ceiling"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (extra, r.stderr[-3000:])
+        j = _line(r.stdout)
+        assert j["config"]["call_path"]["level"] == "processor" and j["config"]["call_path"]["sync_debug_mode"] == "error"
+        assert j["value"] > 0 and "cpu_baseline" not in j and j["roofline"]["achieved"] > 0

@@ -268,13 +268,66 @@ def test_device_side_routing_is_sync_free_and_equal():
     b = torch.zeros(3 * H, device=dev()).to(dtype)
     q, k, v = (torch.randn((1, H, S + T, 128), device=dev()).to(dtype) for _ in range(3))
     geom = _geom()
-    scores, expert, lists, counts = ops.router_route(temb, w, b, H, 0.3)
-    out_dev = routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,
-                               text_valid=te)
+    geom.sta_launch_tables(te, 256)  # per-prompt tables: built once, outside the sync-checked region
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")  # any host <-> device synchronisation in here raises
+    try:
+        scores, expert, lists, counts = ops.router_route(temb, w, b, H, 0.3)
+        out_dev = routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,
+                                   text_valid=te)
+        out8_dev = routed_attention(q, k, v, HeadRouting.from_device(lists, counts), geom, model="hunyuan", text_len=T,
+                                    text_valid=te, fp8=True)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    with pytest.raises(RuntimeError):  # the mode does catch a read-back
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            counts.cpu()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(out8_dev.float()).all()
     out_host = routed_attention(q, k, v, HeadRouting.from_expert_ids(expert.cpu().tolist(), dev()), geom,
                                 model="hunyuan", text_len=T, text_valid=te)
     assert torch.equal(out_dev, out_host)
     assert len(set(expert.cpu().tolist())) >= 2  # the draw exercises more than one expert
+
+
+def test_text_launch_is_unsplit_only_inside_a_fused_grid(monkeypatch):
+    """The sliding expert's text-query launch: inside the fused layer grid it runs first and unsplit; when it cannot
+    join one (T not a multiple of the 256-row workgroup -> 128-row kernel) it stays a stand-alone launch WITH its key
+    splits (a few workgroups looping over every key would be a multi-millisecond tail)."""
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.bfloat16
+    # sizes at which the planner gives every expert launch 256-row workgroups (the fused grid's condition) with T = 64 too
+    latent, tile, window, group = (10, 12, 16), (2, 6, 8), (3, 3, 3), (2, 3, 2)
+    Sx = 10 * 12 * 16
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    seen = []
+    fused_orig, one_orig = ops.attn_fwd_batch_built, ops._launch_one
+
+    def spy_batch(built, fuse=True):
+        seen.append(("fused" if fuse and len(built) > 1 else "alone", [(t, a.n_splits) for a, _, t, _ in built]))
+        return fused_orig(built, fuse)
+
+    monkeypatch.setattr(ops, "attn_fwd_batch_built", spy_batch)
+    torch.manual_seed(3)
+    res = {}
+    for T, te in ((256, 200), (64, 40)):
+        q, k, v = (torch.randn((1, 6, Sx + T, 128), device=dev()).to(dtype) for _ in range(3))
+        seen.clear()
+        out = routed_attention(q, k, v, HeadRouting.from_expert_ids([0, 1, 2, 2, 1, 2], dev()), geom, model="hunyuan",
+                               text_len=T, text_valid=te)
+        res[T] = [(kind, calls) for kind, calls in seen if calls]
+        # same numbers as one launch per expert (where the text launch keeps its splits)
+        ref = routed_attention(q, k, v, HeadRouting.from_expert_ids([0, 1, 2, 2, 1, 2], dev()), geom, model="hunyuan",
+                               text_len=T, text_valid=te, fused=False)
+        assert float((out.float() - ref.float()).abs().max()) <= 2e-2
+    kind, calls = res[256][0]
+    assert kind == "fused" and calls[0] == ("sliding_text", 1) and len(calls) == 4, res[256]
+    alone = [c for kind, calls in res[64] if kind == "alone" for c in calls]
+    assert [t for t, _ in alone] == ["sliding_text"] and alone[0][1] > 1, res[64]
+    assert any(kind == "fused" and "sliding_text" not in [t for t, _ in calls] for kind, calls in res[64]), res[64]
 
 
 @pytest.mark.parametrize("model", ["hunyuan", "wan"])

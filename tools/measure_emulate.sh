@@ -1,6 +1,7 @@
 # One rank's share of a P-GPU Ulysses step on one GPU (bench.py --emulate-rank), same box as the 1-GPU line.
 # Run on the GPU box:  bash tools/measure_emulate.sh   (writes gpurun_out/r2/e/*.json; copy what is kept into profiles/)
-set -x
+set -eux
+: "${GRAFT_REPO_ROOT:?run through gpurun (it exports GRAFT_REPO_ROOT)}"
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2/e
 mkdir -p $O

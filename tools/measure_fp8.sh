@@ -1,8 +1,9 @@
 # The fp8 part of tools/measure_round.sh + the emulated rank of 8, for re-taking those artefacts after an fp8-only change.
-set -x
+set -eux
+: "${GRAFT_REPO_ROOT:?run through gpurun (it exports GRAFT_REPO_ROOT)}"
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2/f8
-rm -rf $O && mkdir -p $O
+rm -rf "$O" && mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 for c in "wan14b-81f bf16" "wan14b-81f fp8" "hunyuan-129f bf16" "hunyuan-129f fp8"; do set -- $c; python3 $R/bench.py --config $1 --dtype $2 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_$1_$2.json 2>> $O/err.txt; done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_fp8 -- python3 $R/bench.py --config wan14b-81f --dtype fp8 --steps 1 --warmup 1 --no-cpu-baseline --no-gemm-ceiling > $O/bench_wan14b-81f_fp8_under_rocprof.json 2> $O/stats_fp8.err

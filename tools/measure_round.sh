@@ -1,4 +1,5 @@
-set -x
+set -eux
+: "${GRAFT_REPO_ROOT:?run through gpurun (it exports GRAFT_REPO_ROOT)}"
 mkdir -p gpurun_out/r2/m
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2/m

@@ -49,6 +49,7 @@ class CoresetArgs(C.Structure):
         ("row_map", _vp),
         ("keep_rows", _vp), ("keep_rows_stride_h", _i64),
         ("drop_rows", _vp), ("drop_rows_stride_h", _i64),
+        ("keep_rows_kv", _vp), ("keep_rows_kv_stride_h", _i64),
     ]
 
 

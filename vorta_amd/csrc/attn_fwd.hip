@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
   const int qb = rest % n_qb;
-  const int y = rest / n_qb;
+  const int y = p.n_heads_dev ? spread_slot(rest / n_qb, p.n_heads) : rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
   int grp, p0, pend;
@@ -309,7 +309,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
   const int qb = rest % n_qb;
-  const int y = rest / n_qb;
+  const int y = p.n_heads_dev ? spread_slot(rest / n_qb, p.n_heads) : rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
   int grp, p0, pend;

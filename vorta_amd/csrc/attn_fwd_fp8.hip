@@ -52,25 +52,16 @@ struct MultiParams8 {
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(max(a, b), c); }
 
 __device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
-#ifdef VORTA_DIAG_NOMFMA  // timing diagnostic (wrong results): no matrix instructions at all
-  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
-  return c;
-#else
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // cbsz = blgp = 0: e4m3 x e4m3, no block scale
-#endif
 }
 
 template <typename TO> struct OutT;
 template <> struct OutT<__bf16> { using v4 = bf16x4; };
 template <> struct OutT<_Float16> { using v4 = f16x4; };
 
-// LDS: K ring of 2 tiles, V ring of 3 tiles (8 KiB each), one workgroup barrier per key block.
-// -DVORTA_SYNC2=1: rings of 4 + 4 tiles and one barrier per TWO key blocks (block j requests K(j+3) and V(j+1); everything a
-// block reads was requested at least two blocks earlier, and the barrier behind every odd block separates the last read
-// of a slot from the request that refills it).
-#ifndef VORTA_SYNC2
-#define VORTA_SYNC2 0
-#endif
+// LDS: K ring of 2 tiles, V ring of 3 tiles (8 KiB each), one workgroup barrier per key block.  (Rings of 4 + 4 tiles with
+// one barrier per TWO key blocks were built and measured at the same speed -- 11.25 vs 11.29 ms on the dense launch,
+// DESIGN.md (f).1 -- and removed in round 3.)
 // VORTA_DMA_SPLIT bit0 (default): the waves whose step starts with the matrix part request their tile pieces BEHIND it
 // instead of right after the barrier -- they go from the barrier straight into their MFMAs (no address arithmetic, no
 // request issue in the head of the segment) and the requests of the two roles no longer queue up together.  Same box,
@@ -84,11 +75,7 @@ template <> struct OutT<_Float16> { using v4 = f16x4; };
 #ifndef VORTA_DMA_SPLIT
 #define VORTA_DMA_SPLIT 1
 #endif
-#if VORTA_SYNC2
-constexpr int K_SLOTS = 4, V_SLOTS = 4;
-#else
 constexpr int K_SLOTS = 2, V_SLOTS = 3;
-#endif
 constexpr int SMEM8 = (K_SLOTS + V_SLOTS) * TILE8;
 
 template <typename TO, int NW, bool KVTAB, bool LMFMA, bool SWAP = false>
@@ -96,21 +83,15 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   const Params& p = pp.p;
   using O4 = typename OutT<TO>::v4;
   constexpr int QB = NW * 32;
-  // -DVORTA_XLOAD8=1 (experiment, measured neutral): the tiles are requested by the first four waves only (2 of a tile's
-  // 8 1-KiB pieces each) -- in the 8-wave workgroup the waves whose step starts with the matrix part and who reach the
-  // barrier ~170 cycles before their partners.  tools/trace_fp8.py: a piece costs its wave 60-80 cycles of issue; with
-  // four loaders the partners' barrier wait drops from 165 to 76 cycles and the loaders' from 332 to 95, the step stays
-  // at ~1 700 cycles: the loop is bound by the SIMD's issue slots, not by either role's critical path.
-#ifndef VORTA_XLOAD8
-#define VORTA_XLOAD8 0
-#endif
-  constexpr int LW = VORTA_XLOAD8 ? 4 : NW;  // loader waves
-  constexpr int CH = 8 / LW;                 // 1-KiB DMA pieces (8 tile rows) of one tile per loader wave
+  // every wave is a loader.  (Four loader waves, 2 of a tile's 8 1-KiB pieces each, measured neutral: the barrier waits
+  // shrink, the step stays at ~1 700 cycles -- the loop is bound by the SIMD's issue slots, profiles/r02_fp8_loop_trace.txt.)
+  constexpr int LW = NW;      // loader waves
+  constexpr int CH = 8 / LW;  // 1-KiB DMA pieces (8 tile rows) of one tile per loader wave
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
   const int qb = rest % n_qb;
-  const int y = rest / n_qb;
+  const int y = p.n_heads_dev ? spread_slot(rest / n_qb, p.n_heads) : rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
   int grp, p0, pend;
@@ -157,19 +138,8 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(p.v + (int64_t)head * p.v_sh), 0, 0x7fffffff, 0x00020000);
   const int k_ss32 = (int)p.k_ss, v_ss32 = (int)p.v_ss;
-#if VORTA_XLOAD8 == 2  // the waves whose step starts with the VALU part are the loaders
-  const bool loader = NW == 8 ? wave >= NW / 2 : true;
-  const int lwave = loader ? (NW == 8 ? wave - NW / 2 : wave) : 0;
-#elif VORTA_XLOAD8 == 1
-  const bool loader = wave < LW;  // wave-uniform
-  const int lwave = loader ? wave : 0;
-#elif defined(VORTA_LOADER_RUNTIME)  // (experiment: the round's earlier form, a run-time wave test)
-  const bool loader = wave < LW;
-  const int lwave = loader ? wave : 0;
-#else
-  constexpr bool loader = true;   // every wave (a compile-time fact: no branch, no join around the requests)
+  constexpr bool loader = true;   // a compile-time fact: no branch, no join around the requests (see VORTA_DMA_SPLIT)
   const int lwave = wave;
-#endif
   int k_col[CH], v_col[CH];  // source byte offset inside the row for the chunk this lane lands in
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
@@ -178,9 +148,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     v_col[i] = ((lane & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4;
   }
   int rowK[CH], rowV[CH];
-#if VORTA_SYNC2
-  int rowV1[CH];  // V lags K by two blocks: rows(j+3) -> rowV1 -> rowV
-#endif
 #define ROWS_OF(dst_, blk_)                                                       \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
     const int pos_ = min((blk_) * KVB + 8 * (CH * lwave + i_) + (lane >> 3), n_kv - 1); \
@@ -240,16 +207,12 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #pragma unroll
   for (int i = 0; i < 8; ++i) pb_[i] = 0;
 
-#ifdef VORTA_DIAG_NOLDSRD  // timing diagnostic (wrong results): fragments are never read from LDS
-#define KFRAG(dst_, slot_, t_, ks_) dst_ = qf[ks_];
-#else
 #define KFRAG(dst_, slot_, t_, ks_)                                                \
   {                                                                               \
     const i32x4 lo_ = *(const i32x4*)(smem + (slot_) * TILE8 + (t_) * 32 * ROWB8 + k_rd[ks_][0]); \
     const i32x4 hi_ = *(const i32x4*)(smem + (slot_) * TILE8 + (t_) * 32 * ROWB8 + k_rd[ks_][1]); \
     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { dst_[e_] = lo_[e_]; dst_[4 + e_] = hi_[e_]; } \
   }
-#endif
 #define KFRAGS0(slot_)                                                            \
   i32x8 kf00_, kf10_;                                                             \
   KFRAG(kf00_, slot_, 0, 0)                                                       \
@@ -258,16 +221,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   i32x8 kf01_, kf11_;                                                             \
   KFRAG(kf01_, slot_, 0, 1)                                                       \
   KFRAG(kf11_, slot_, 1, 1)
-#ifdef VORTA_DIAG_NODEP  // timing diagnostic (wrong results): the MFMAs do not wait for the fragment reads
-#define QK_FRAGS(d0_, d1_)                                                        \
-  {                                                                               \
-    d0_ = mfma8(qf[0], qf[0], minit);                                             \
-    d1_ = mfma8(qf[1], qf[0], minit);                                             \
-    d0_ = mfma8(qf[0], qf[1], d0_);                                               \
-    d1_ = mfma8(qf[1], qf[1], d1_);                                               \
-    asm volatile("" :: "v"(kf00_), "v"(kf10_), "v"(kf01_), "v"(kf11_));           \
-  }
-#else
 #define QK_FRAGS(d0_, d1_)                                                        \
   {                                                                               \
     d0_ = mfma8(kf00_, qf[0], minit);                                             \
@@ -275,29 +228,15 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     d0_ = mfma8(kf01_, qf[1], d0_);                                               \
     d1_ = mfma8(kf11_, qf[1], d1_);                                               \
   }
-#endif
-#ifdef VORTA_DIAG_NOMFMA
-#define ONES_MFMA_(a_, b_, c_) mfma8(a_, b_, c_)
-#else
 #define ONES_MFMA_(a_, b_, c_) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c_, 4, 0, 0, 0, 0, 0)
-#endif
-#ifdef VORTA_DIAG_NODEP
-#define PVA_(dt_) qf[(dt_) & 1]
-#define PVKEEP_() asm volatile("" :: "v"(vf_[0]), "v"(vf_[1]), "v"(vf_[2]), "v"(vf_[3]));
-#else
 #define PVA_(dt_) vf_[dt_]
 #define PVKEEP_()
-#endif
-#ifdef VORTA_DIAG_NOLDSRD
-#define VFRAG(dt_, slot_) vf_[dt_] = qf[(dt_) & 1];
-#else
 #define VFRAG(dt_, slot_)                                                         \
   _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                              \
     const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                      \
         (LDS_AS i32x2*)(smem + (slot_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8));   \
     vf_[dt_][2 * n_] = t_[0]; vf_[dt_][2 * n_ + 1] = t_[1];                       \
   }
-#endif
   // the fragments of the first two channel tiles are requested ahead of the part (before the rare branches), those of
   // the other two under the first two MFMAs -- 16 live fragment registers instead of 32
 #define VFRAGS_HEAD(slot_) i32x8 vf_[4]; VFRAG(0, slot_) VFRAG(1, slot_)
@@ -309,9 +248,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     PVKEEP_()                                                                     \
     if constexpr (LMFMA) lacc = ONES_MFMA_(ones, pb_, lacc);                      \
   }
-#if defined(VORTA_DIAG_NOEXP)
-#define EXP_BLOCK(c0_, c1_)
-#else
 #define EXP_BLOCK(c0_, c1_)                                                       \
   {                                                                               \
     float lsum_ = 0.f;                                                            \
@@ -322,12 +258,8 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     }                                                                             \
     if constexpr (!LMFMA) lacc[0] += lsum_;                                       \
   }
-#endif
   // v_cvt_pk_fp8_f32 writes half of its destination and keeps the other half: feed it the stale word of the previous
   // block instead of a zero (the second convert overwrites the rest)
-#if defined(VORTA_DIAG_NOCVT)
-#define PACK_BLOCK(c0_, c1_) asm volatile("" : "+v"(pb_) : "v"(c0_), "v"(c1_));
-#else
 #define PACK_BLOCK(c0_, c1_)                                                      \
   _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                              \
     pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_], c0_[4 * w_ + 1], pb_[w_], false); \
@@ -335,7 +267,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_], c1_[4 * w_ + 1], pb_[4 + w_], false); \
     pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_ + 2], c1_[4 * w_ + 3], pb_[4 + w_], true); \
   }
-#endif
 #define ROW_MAX(dst_, a_, b_)                                                      \
   {                                                                               \
     float mx_ = a_[0];                                                            \
@@ -347,9 +278,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   // answered by a SIGNED-INTEGER max over the float bit patterns (order-preserving for the non-negative floats, and
   // any negative result reads as "not above"): v_max3_i32 needs no canonicalising v_max x,x of the MFMA outputs,
   // and two chains halve the dependent latency.  (-inf of masked keys is a negative integer; there are no NaNs.)
-#if defined(VORTA_DIAG_NOMAX)
-#define ROW_MAX_POS(dst_, a_, b_) asm volatile("" :: "v"(a_), "v"(b_));
-#else
 #define ROW_MAX_POS(dst_, a_, b_)                                                  \
   {                                                                               \
     int m0_ = imax3(__float_as_int(a_[0]), __float_as_int(a_[1]), __float_as_int(a_[2])); \
@@ -363,7 +291,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m0_, false, false); \
     dst_ = __int_as_float(max((int)r_[0], (int)r_[1]));                           \
   }
-#endif
 #define MASK_TAIL(c0_, c1_, jabs_)                                                \
   _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                             \
     const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                           \
@@ -372,19 +299,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   }
   // requests of a step: K(j+2) into the slot K(j) left, V(j+1) into the slot V(j-2) left; both are read in the next
   // step (V(j+1) by role Y), so the end-of-step wait covers both
-#if defined(VORTA_DIAG_NODMA)
-#define STAGE_DMA(kw_, vw_, jabs_)
-#else
-#if VORTA_SYNC2
-#define STAGE_DMA(kw_, vw_, jabs_)                                                \
-  if (loader) {                                                                   \
-    DMA_K(kw_)                                                                    \
-    DMA_V(vw_)                                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) { rowV[i_] = rowV1[i_]; rowV1[i_] = rowK[i_]; } \
-    ROWS_OF(rowK, (jabs_) + 4)                                                    \
-  }                                                                               \
-  __builtin_amdgcn_sched_barrier(0);
-#else
 #define STAGE_DMA(kw_, vw_, jabs_)                                                \
   if (loader) {                                                                   \
     DMA_K(kw_)                                                                    \
@@ -393,15 +307,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     ROWS_OF(rowK, (jabs_) + 3)                                                    \
   }                                                                               \
   __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
-#if defined(VORTA_DIAG_NOBAR)  // timing diagnostics only (results are wrong): no workgroup barrier / no wait at all
-#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#elif defined(VORTA_DIAG_NOSYNC)
-#define STEP_SYNC() asm volatile("" ::: "memory");
-#else
 #define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 #ifndef VORTA_SCHED8
 #define VORTA_SCHED8 1
 #endif
@@ -476,32 +382,14 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     QK_FRAGS(n0_, n1_)                                                            \
     PRIO_LO()                                                                     \
   }
-  // -DVORTA_TRACE8=i (diagnostic builds, tools/trace_fp8.py; one interval per build -- the loop has no registers to
-  // spare): shader cycles between stamps i-1 and i of every step, summed per wave, go to ws_ml of an unsplit launch.
-  //   0 step start | 1 before the matrix part | 2 after it | 3 before the end-of-step wait | 4 before the barrier | 5 after
-#ifdef VORTA_TRACE8
-  unsigned tr_sum_ = 0, tr_t0_ = 0;
-#define TR_(i_)                                                                   \
-  if constexpr ((i_) == VORTA_TRACE8 - 1) {                                       \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    tr_t0_ = (unsigned)__builtin_readcyclecounter();                              \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-  } else if constexpr ((i_) == VORTA_TRACE8) {                                    \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    tr_sum_ += (unsigned)__builtin_readcyclecounter() - tr_t0_;                   \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-  }
-#undef STEP_SYNC
-#define STEP_SYNC()                                                               \
-  {                                                                               \
-    TR_(3)                                                                        \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
-    TR_(4)                                                                        \
-    asm volatile("s_barrier" ::: "memory");                                       \
-    TR_(5)                                                                        \
-  }
-#else
+  // Diagnostic builds only (suffixed libraries, vorta_amd/build.py; never the product): -DVORTA_FP8_DIAG pulls in the
+  // in-loop cycle stamps (-DVORTA_TRACE8=i, tools/trace_fp8.py) and the wrong-result timing ablations (-DVORTA_DIAG_*),
+  // which re-define the macros above.
 #define TR_(i_)
+#define TR_FLUSH_()
+#define ROLE_Y_ (NW == 8 && (SWAP ? wave < NW / 2 : wave >= NW / 2))
+#ifdef VORTA_FP8_DIAG
+#include "attn_fwd_fp8_diag.inc"
 #endif
 #define STEP_(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_, sync_)                \
   {                                                                               \
@@ -526,34 +414,11 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #define STEP(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_) STEP_(c0_, c1_, n0_, n1_, kw_, kr_, vw_, vr_, jabs_, true)
 
   const int nsteps = blk1 - blk0;
-#if defined(VORTA_DIAG_ALLX)
-  const bool role_y = false;
-#else
   // which half of the workgroup starts its steps with the VALU part (wave-uniform).  SWAP = the earlier-dispatched half:
   // measured per kernel -- the table-free body of the fused layer kernel runs 2.5-3.6 % faster that way (dense-only
   // fused launch 11.13 -> 10.86 ms), its table body 0-1 % slower, the single-launch kernels 0.5-1 % slower
-  const bool role_y = NW == 8 && (SWAP ? wave < NW / 2 : wave >= NW / 2);
-#endif
-#if VORTA_PRIO8 == 2  // experiment: static priority for the later-dispatched half, no flips
-  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
+  const bool role_y = ROLE_Y_;
   if (nsteps > 0) {
-#if VORTA_SYNC2
-    // ---- prologue: K(0), V(0), K(1), K(2); the scores of block 0 fix the reference point ----
-    if (loader) {
-      ROWS_OF(rowK, blk0)
-      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-      DMA_K(0)
-      DMA_V(0)
-      ROWS_OF(rowK, blk0 + 1)
-      DMA_K(1)
-      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];   // rows(1): V(1), requested by step 0
-      ROWS_OF(rowK, blk0 + 2)
-      DMA_K(2)
-      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV1[i_] = rowK[i_];  // rows(2): V(2), requested by step 1
-      ROWS_OF(rowK, blk0 + 3)
-    }
-#else
     // ---- prologue: K(0), V(0), K(1); the scores of block 0 fix the reference point ----
     if (loader) {
       ROWS_OF(rowK, blk0)
@@ -565,7 +430,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
       _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
       ROWS_OF(rowK, blk0 + 2)
     }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave_active) {
@@ -583,7 +447,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
     __syncthreads();  // every wave has read K(0) before its slot is overwritten
     {  // step 0: no PV yet -- the scores of block 1, then (first role) the VALU part of block 0
       TR_(0)
-      STAGE_DMA(VORTA_SYNC2 ? 3 : 0, 1, blk0)
+      STAGE_DMA(0, 1, blk0)
       if (wave_active) {
         TR_(1)
         KFRAGS0(1)
@@ -593,23 +457,8 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
         TR_(2)
         if (!role_y) VALU_PART(sA0, sA1, sB0, sB1)
       }
-#if !VORTA_SYNC2  // (with the deeper rings step 1 reads and refills nothing that step 0 touches)
       STEP_SYNC()
-#endif
     }
-#if VORTA_SYNC2
-    // slots of step j: K written (j+3)&3, K read (j+1)&3, V written (j+1)&3, V read (j+3)&3; a barrier behind odd steps
-    for (int jj = 1; jj < nsteps; jj += 4) {
-      STEP_(sB0, sB1, sA0, sA1, 0, 2, 2, 0, blk0 + jj, true)
-      if (jj + 1 >= nsteps) break;
-      STEP_(sA0, sA1, sB0, sB1, 1, 3, 3, 1, blk0 + jj + 1, false)
-      if (jj + 2 >= nsteps) break;
-      STEP_(sB0, sB1, sA0, sA1, 2, 0, 0, 2, blk0 + jj + 2, true)
-      if (jj + 3 >= nsteps) break;
-      STEP_(sA0, sA1, sB0, sB1, 3, 1, 1, 3, blk0 + jj + 3, false)
-    }
-    STEP_SYNC()  // the last block's V tile may have been requested behind the last barrier
-#else
     // K slots cycle with period 2, V slots with period 3, score roles with period 2: unrolled by 6
     for (int jj = 1; jj < nsteps; jj += 6) {
       STEP(sB0, sB1, sA0, sA1, 1, 0, 2, 0, blk0 + jj)
@@ -624,7 +473,6 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
       if (jj + 5 >= nsteps) break;
       STEP(sA0, sA1, sB0, sB1, 0, 1, 1, 2, blk0 + jj + 5)
     }
-#endif
     // ---- drain: the second role still owes the VALU part of the last block; then PV of the last block ----
     if (wave_active) {
       if (role_y) {
@@ -660,13 +508,10 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #undef DMA_V
 #undef SCHED_M
 #undef SG_
+  TR_FLUSH_()
 #undef TR_
-#ifdef VORTA_TRACE8
-  if (p.n_splits == 1 && p.ws_ml && lane == 0) {
-    unsigned* tr = (unsigned*)p.ws_ml + ((int64_t)wg * NW + wave) * 2;
-    tr[0] = tr_sum_; tr[1] = (unsigned)(nsteps - 1);
-  }
-#endif
+#undef TR_FLUSH_
+#undef ROLE_Y_
 
   if (!wave_active) return;
   // ---------------- epilogue ----------------

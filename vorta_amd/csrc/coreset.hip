@@ -25,6 +25,7 @@ struct CParams {
   const int32_t* row_map;
   int32_t* keep_rows; int64_t keep_sh;
   int32_t* drop_rows; int64_t drop_sh;
+  int32_t* kv_rows; int64_t kv_sh;  // optional second keep list in group-major, token-ascending order (key side)
 };
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256) void coreset_select_kernel(const CParams p) {
   if (!valid) return;
 
   // stable ascending rank of every margin (lane m owns margin m)
-  int32_t* keep = p.keep_rows + (int64_t)y * p.keep_sh;
+  int32_t* keep = p.keep_rows ? p.keep_rows + (int64_t)y * p.keep_sh : nullptr;
+  int32_t* kvl = p.kv_rows ? p.kv_rows + (int64_t)y * p.kv_sh : nullptr;
+  bool kept = false;
+  int row = 0, idx = 0;
   if (lane < nm) {
     const float mine = sims[wave][lane];
     int rank = 0;
@@ -105,19 +109,35 @@ __global__ __launch_bounds__(256) void coreset_select_kernel(const CParams p) {
       const float o = sims[wave][i];
       rank += (o < mine || (o == mine && i < lane)) ? 1 : 0;
     }
-    const int idx = lane < p.centre ? lane : lane + 1;
-    const int row = row_of(token_of(idx));
-    if (rank < p.n_keep) {
-      keep[p.n_groups + gidx * p.n_keep + rank] = row;
+    idx = lane < p.centre ? lane : lane + 1;
+    row = row_of(token_of(idx));
+    kept = rank < p.n_keep;
+    if (kept) {
+      if (keep) keep[p.n_groups + gidx * p.n_keep + rank] = row;
     } else if (p.drop_rows) {
       p.drop_rows[(int64_t)y * p.drop_sh + (int64_t)gidx * (nm - p.n_keep) + (rank - p.n_keep)] = row;
     }
   }
-  if (lane == 0) keep[gidx] = row_of(ctok);
+  if (lane == 0 && keep) keep[gidx] = row_of(ctok);
+  if (kvl) {
+    // key side: the softmax does not depend on the order of the keys, so the group's centre and kept margins stay
+    // together, in ascending token order -- the K/V tiles of the attention kernel then gather rows that are neighbours
+    // in memory instead of striding through all G centres first (coreset_select.py:116-124 packs [centres | margins])
+    const uint64_t km = __ballot(kept);  // by margin number
+    const uint64_t lowm = (1ull << p.centre) - 1;
+    const uint64_t ki = (km & lowm) | ((km >> p.centre) << (p.centre + 1)) | (1ull << p.centre);  // by in-window index
+    int32_t* dst = kvl + (int64_t)gidx * (1 + p.n_keep);
+    if (kept) dst[__popcll(ki & ((1ull << idx) - 1))] = row;
+    if (lane == 0) dst[__popcll(ki & lowm)] = row_of(ctok);
+  }
   // the tail (text tokens) is appended once per head slot by group 0
   if (gidx == 0) {
     const int base = p.n_groups * (1 + p.n_keep);
-    for (int i = lane; i < p.n_tail; i += 64) keep[base + i] = row_of(p.tail_first + i);
+    for (int i = lane; i < p.n_tail; i += 64) {
+      const int r = row_of(p.tail_first + i);
+      if (keep) keep[base + i] = r;
+      if (kvl) kvl[base + i] = r;
+    }
   }
 }
 
@@ -129,7 +149,7 @@ extern "C" int vorta_coreset_select(const vorta_coreset_args* a, void* hip_strea
   if (a->head_dim != 128) return VORTA_EUNSUPPORTED;
   if (a->n_heads < 0) return VORTA_EINVAL;
   if (a->n_heads == 0) return VORTA_OK;
-  if (!a->x.ptr || !a->keep_rows) return VORTA_EINVAL;
+  if (!a->x.ptr || (!a->keep_rows && !a->keep_rows_kv)) return VORTA_EINVAL;
   if (((uintptr_t)a->x.ptr & 15) || (a->x.stride_s % 8) || (a->x.stride_h % 8) || a->x.stride_s < 128) return VORTA_EINVAL;
   CParams p{};
   p.g = 1;
@@ -151,6 +171,7 @@ extern "C" int vorta_coreset_select(const vorta_coreset_args* a, void* hip_strea
   p.tail_first = a->tail_first; p.n_tail = a->n_tail; p.row_map = a->row_map;
   p.keep_rows = a->keep_rows; p.keep_sh = a->keep_rows_stride_h;
   p.drop_rows = a->drop_rows; p.drop_sh = a->drop_rows_stride_h;
+  p.kv_rows = a->keep_rows_kv; p.kv_sh = a->keep_rows_kv_stride_h;
   const int64_t items = (int64_t)p.n_heads * p.n_groups;
   const int64_t blocks = (items + 3) / 4;
   if (blocks > 0x7fffffff) return VORTA_EINVAL;

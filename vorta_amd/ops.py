@@ -454,15 +454,19 @@ def fp8_v_convert(v: torch.Tensor, amax: torch.Tensor, v8: torch.Tensor, *, src_
 def coreset_select(x: torch.Tensor, latent: Sequence[int], group: Sequence[int], n_keep: int, *,
                    head_list: Optional[torch.Tensor] = None, n_heads: Optional[int] = None,
                    n_heads_dev: Optional[torch.Tensor] = None, tail_first: int = 0, n_tail: int = 0,
-                   row_map: Optional[torch.Tensor] = None, want_drop: bool = True
-                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """vorta_coreset_select: returns keep_rows (slots, G*(1+n_keep)+n_tail) and drop_rows (slots, G, g-1-n_keep)."""
+                   row_map: Optional[torch.Tensor] = None, want_drop: bool = True, want_keep: bool = True,
+                   want_kv: bool = False):
+    """vorta_coreset_select: returns keep_rows (slots, G*(1+n_keep)+n_tail) [packed: centres, kept margins, tail] and
+    drop_rows (slots, G, g-1-n_keep); with `want_kv` a third tensor, the same rows in group-major ascending order (the
+    key-side list: order is free there and neighbours in memory stay neighbours in the list)."""
     _require_gpu(x)
     if n_heads is None:
         n_heads = head_list.numel() if head_list is not None else x.shape[0]
     g = group[0] * group[1] * group[2]
     G = (latent[0] // group[0]) * (latent[1] // group[1]) * (latent[2] // group[2])
-    keep = torch.empty((n_heads, G * (1 + n_keep) + n_tail), dtype=torch.int32, device=x.device)
+    n_list = G * (1 + n_keep) + n_tail
+    keep = torch.empty((n_heads, n_list), dtype=torch.int32, device=x.device) if want_keep else None
+    kv = torch.empty((n_heads, n_list), dtype=torch.int32, device=x.device) if want_kv else None
     drop = torch.empty((n_heads, G, g - 1 - n_keep), dtype=torch.int32, device=x.device) if want_drop else None
     a = _C.CoresetArgs()
     a.struct_size = C.sizeof(_C.CoresetArgs)
@@ -473,11 +477,14 @@ def coreset_select(x: torch.Tensor, latent: Sequence[int], group: Sequence[int],
     a.group = (C.c_int32 * 3)(*group)
     a.n_keep, a.tail_first, a.n_tail = n_keep, tail_first, n_tail
     a.row_map = _ptr(row_map)
-    a.keep_rows, a.keep_rows_stride_h = keep.data_ptr(), keep.stride(0)
+    if keep is not None:
+        a.keep_rows, a.keep_rows_stride_h = keep.data_ptr(), keep.stride(0)
+    if kv is not None:
+        a.keep_rows_kv, a.keep_rows_kv_stride_h = kv.data_ptr(), kv.stride(0)
     if drop is not None:
         a.drop_rows, a.drop_rows_stride_h = drop.data_ptr(), drop.stride(0)
     _C.check(_C.lib().vorta_coreset_select(C.byref(a), _stream()), "vorta_coreset_select")
-    return keep, drop
+    return (keep, drop, kv) if want_kv else (keep, drop)
 
 
 def sta_table_sizes(latent, tile, window, t_eff: int = 0) -> Tuple[int, int, int]:

@@ -151,6 +151,9 @@ DEFAULT_FP8 = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lowe
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
 # the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
 FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
+# coreset expert: key-side row list in group-major ascending order (VORTA_CORESET_KV_ORDER=packed: the reference's
+# [centres | margins] order, A/B)
+CORESET_KV_GROUP_MAJOR = __import__("os").environ.get("VORTA_CORESET_KV_ORDER", "group") != "packed"
 # fused grid: the sliding expert's text-query segment goes first with at most this many key splits (0: as round 1 -- last,
 # with the stand-alone launch's split count; A/B)
 FUSED_TEXT_SPLITS = int(__import__("os").environ.get("VORTA_FUSED_TEXT_SPLITS", "1"))
@@ -239,13 +242,20 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     # ---- expert 1: coreset attention (hunyuan.py:410-457 / wan.py:243-270) ----
     def expert_lowres():
         sl = routing.slot_args(1, H)
-        keep_q, drop_q = ops.coreset_select(q3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T,
-                                            row_map=rm, **sl)
+        # key side: the same rows as the reference's packed [centres | margins] list (coreset_select.py:116-124) in
+        # group-major ascending order -- softmax does not see the order of the keys, the K/V gather does
+        gm = CORESET_KV_GROUP_MAJOR
         if hy:  # K matched on its own, V follows K (hunyuan.py:433-438)
-            keep_k, _ = ops.coreset_select(k3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=te,
-                                           row_map=rm, want_drop=False, **sl)
-        else:   # K and V follow Q's matching (wan.py:250-255)
-            keep_k = keep_q
+            keep_q, drop_q = ops.coreset_select(q3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T,
+                                                row_map=rm, **sl)
+            kk = ops.coreset_select(k3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=te, row_map=rm,
+                                    want_drop=False, want_keep=not gm, want_kv=gm, **sl)
+            keep_k = kk[2] if gm else kk[0]
+        else:   # K and V follow Q's matching (wan.py:250-255): one selection, both lists
+            kq = ops.coreset_select(q3, geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T, row_map=rm,
+                                    want_kv=gm, **sl)
+            keep_q, drop_q = kq[0], kq[1]
+            keep_k = kq[2] if gm else keep_q
         return [dict(base, out=o_e[1], n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te, q_rows=keep_q,
                      kv_rows=keep_k, dup_rows=drop_q, n_dup_pos=geom.G, tag="lowres",
                      flops=nheads(1) * 4.0 * (geom.S_low + te) ** 2 * D, **sl)]
