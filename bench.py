@@ -527,6 +527,10 @@ def main():
                    "step_tflops_per_gpu": round(step_flops / (ms_per_step * 1e-3) / 1e12 / (emu or world), 1)},
         "roofline": roofline,
         "per_launch": per_tag,
+        # behaviour switches in effect: every VORTA_* variable of the environment and the library's build info (a
+        # variant build lists its -D flags there)
+        "switches": {"env": {k_: v_ for k_, v_ in sorted(os.environ.items()) if k_.startswith("VORTA_")},
+                     "library": __import__("vorta_amd._C", fromlist=["lib"]).lib().vorta_build_info().decode()},
     }
     if world == 1 and not args.no_gemm_ceiling:
         # context for `frac`: what a plain library GEMM (hipBLASLt via torch.matmul, same dtype) sustains on THIS

@@ -89,6 +89,18 @@ def test_coreset_select_indices(golden, dtype):
     if dtype == torch.bfloat16:  # the fp32 golden indices themselves (tie-free fixture), where rounding did not reorder
         same = (kept[0] == g["unpooled_argsort"][0]).all(-1)
         assert same.mean() > 0.9
+    # the optional key-side list: the same rows, each group's centre and kept margins together in ascending order
+    k2, d2, kv = ops.coreset_select(to_dev(x, dtype), LATENT, GROUP, gi.n_keep_margin, tail_first=S, n_tail=5, want_kv=True)
+    only = ops.coreset_select(to_dev(x, dtype), LATENT, GROUP, gi.n_keep_margin, tail_first=S, n_tail=5, want_kv=True,
+                              want_keep=False, want_drop=False)
+    assert np.array_equal(k2.cpu().numpy(), keep) and np.array_equal(d2.cpu().numpy(), drop)
+    assert only[0] is None and only[1] is None and torch.equal(only[2], kv)
+    kv = kv.cpu().numpy()
+    assert np.array_equal(kv[:, -5:], keep[:, -5:])
+    per_group = kv[:, :G * (1 + nk)].reshape(2, G, 1 + nk)
+    assert (np.diff(per_group, axis=-1) > 0).all()
+    want = np.sort(np.concatenate([keep[:, :G, None], got_k], axis=-1), axis=-1)
+    assert np.array_equal(per_group, want)
 
 
 def test_coreset_bad_geometry():

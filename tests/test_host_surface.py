@@ -29,6 +29,9 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.vorta_abi_version() == _C.ABI_VERSION
+    # the product library carries no experiment knob (variant builds list their -D flags here, vorta_amd/build.py
+    # refuses extra flags without a suffix)
+    assert "-DVORTA" not in lib.vorta_build_info().decode()
     assert b"gfx950" in lib.vorta_build_info()
     for which, st in enumerate((_C.Tensor, _C.AttnArgs, _C.CoresetArgs, _C.StaArgs, _C.RouterArgs, _C.NormRopeArgs)):
         assert lib.vorta_sizeof(which) == ctypes.sizeof(st)

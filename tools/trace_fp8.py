@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Diagnostic: where the waves of the e4m3 attention loop spend their cycles.  Needs the -DVORTA_TRACE8=i builds
 (i = 1, 2, 4, 5; one interval per build: the loop has no registers to spare), e.g.
-    for i in 1 2 4 5; do VORTA_BUILD_SUFFIX=_tr8$i VORTA_EXTRA_FLAGS=-DVORTA_TRACE8=$i python -m vorta_amd.build; done
+    for i in 1 2 4 5; do VORTA_BUILD_SUFFIX=_tr8$i VORTA_EXTRA_FLAGS="-DVORTA_FP8_DIAG -DVORTA_TRACE8=$i" python -m vorta_amd.build; done
     python tools/trace_fp8.py            # runs itself once per library (child processes)
 Interval i = shader cycles per step between stamps i-1 and i:
   0 step start | 1 before the matrix part | 2 after it | 3 before the end-of-step wait | 4 before the barrier | 5 after it"""

@@ -67,6 +67,10 @@ def _joint_projectable(x: torch.Tensor, e: torch.Tensor, lins) -> bool:
         return False
     if e.dtype != x.dtype or not all(type(m) is torch.nn.Linear and m.weight.dtype == x.dtype for m in lins):
         return False
+    # writing through lin.weight bypasses Linear.forward: only when nothing hangs on that forward (accelerate's offload
+    # hooks keep the weights on meta / CPU until it runs; user hooks would be skipped)
+    if any(m.weight.device != x.device or hasattr(m, "_hf_hook") or m._forward_hooks or m._forward_pre_hooks for m in lins):
+        return False
     # `out=` is an inference-only form: autograd refuses it as soon as an argument requires grad
     return not (torch.is_grad_enabled() and (x.requires_grad or e.requires_grad or
                                              any(m.weight.requires_grad for m in lins)))

@@ -37,7 +37,8 @@ def build(force: bool = False, verbose: bool = True, extra_flags=None, suffix: s
         raise SystemExit("VORTA_EXTRA_FLAGS needs VORTA_BUILD_SUFFIX: experimental flags are never built into "
                          "libvorta_hip.so itself")
     lib = LIB if not suffix else os.path.join(CSRC, f"libvorta_hip{suffix}.so")
-    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(INCLUDE, "vorta_hip.h")]
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "attn_fwd_fp8_diag.inc"),
+            os.path.join(INCLUDE, "vorta_hip.h")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -49,21 +49,23 @@ __device__ __forceinline__ void q_block_of(const Params& p, int qb, int rows_per
   }
 }
 
-// Device-resident head counts (n_heads_dev) leave the TRAILING slots of a launch empty, and the XCD-aware order hands
-// each XCD one contiguous eighth of the logical workgroup ids -- slot-major -- so with 8 live slots of 24 three XCDs
-// would do all the work (measured: the device-routed fused layer launch took 201 ms against 68 ms with host counts).
-// Spread the slots instead: the y-th slot in dispatch order is slot c + 8 j, with c the eighth it falls into, so the
-// live slots (the first *n_heads_dev) land on all eight XCDs, each XCD running its live slots first.
-__device__ __forceinline__ int spread_slot(int y, int n) {
-  const int q = n >> 3, r = n & 7;
-  const int big = r * (q + 1);
-  if (y < big) {
-    const int c = y / (q + 1);
-    return c + 8 * (y - c * (q + 1));
+// Logical workgroup id of physical block b of a launch (or of a fused segment) with n ids; -1 = nothing to do.
+// XCD-aware order: workgroups whose ids are equal mod 8 share an XCD (round-robin dispatch), so each such class gets a
+// contiguous chunk of the logical ids (same head, neighbouring query blocks: one L2 serves the K/V stream instead of
+// eight).  With a device-resident head count (n_heads_dev) the grid is sized for every head slot but only the first
+// *n_heads_dev are live: the chunks are cut from the LIVE ids, so all eight XCDs share the live work to within one
+// workgroup, and the dead blocks leave at once.  (Cut from all n ids -- slot-major -- the live third of a uniform
+// Hunyuan layer landed on three XCDs: the device-routed fused launch took 201 ms against 68 ms with host counts;
+// spreading whole slots instead left 14 live slots of 40 at 2 + 2 + ... + 1 + 1 per XCD, 13 % over the host-count time.)
+__device__ __forceinline__ int live_order(const Params& p, int b, int n, bool remap) {
+  if (p.n_heads_dev) {
+    const int per_slot = p.n_groups * p.blocks_per_group * p.n_splits;
+    n = min(n, max(*p.n_heads_dev, 0) * per_slot);
+    if (b >= n) return -1;
   }
-  if (q == 0) return y;
-  const int t = y - big, c = t / q;
-  return r + c + 8 * (t - c * q);
+  if (!remap) return b;
+  const int xcd = b & 7, qd = n >> 3, r = n & 7;
+  return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
 }
 
 constexpr int MAX_SEGMENTS = 4;  // launches fused into one grid (vorta_attn_fwd_batch)

@@ -34,19 +34,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF_BYTES];
 
   // ---- work decomposition (XCD-aware: consecutive logical ids share an XCD's L2) ----
-  const int nwg = gridDim.x;
-  int wg;
-  if (p.xcd_remap) {
-    const int b = blockIdx.x, xcd = b & 7, qd = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
-  } else {
-    wg = blockIdx.x;
-  }
+  const int wg = live_order(p, blockIdx.x, gridDim.x, p.xcd_remap);
+  if (wg < 0) return;
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
   const int qb = rest % n_qb;
-  const int y = p.n_heads_dev ? spread_slot(rest / n_qb, p.n_heads) : rest / n_qb;
+  const int y = rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
   int grp, p0, pend;
@@ -309,7 +303,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
   const int qb = rest % n_qb;
-  const int y = p.n_heads_dev ? spread_slot(rest / n_qb, p.n_heads) : rest / n_qb;
+  const int y = rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
   int grp, p0, pend;
@@ -735,14 +729,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   constexpr int NS = NW == 8 ? VORTA_RING : 2;  // 8 waves = the CU's whole wave budget at this VGPR count: 96 of its 160 KiB
   __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE_BYTES];
   // XCD-aware work order: consecutive logical ids (same head, neighbouring query blocks) share an XCD's L2
-  const int nwg = gridDim.x;
-  int wg;
-  if (p.xcd_remap) {
-    const int b = blockIdx.x, xcd = b & 7, qd = nwg >> 3, r = nwg & 7;
-    wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
-  } else {
-    wg = blockIdx.x;
-  }
+  const int wg = live_order(p, blockIdx.x, gridDim.x, p.xcd_remap);
+  if (wg < 0) return;
   attn_pipe_dma_body<T, NW, KVTAB, NS>(p, smem, wg);
 #endif
 }
@@ -765,9 +753,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParam
   // dispatch), so give each such class a contiguous chunk of the segment's logical ids (same head,
   // neighbouring query blocks -> one L2 serves the K/V stream instead of eight).  Every XCD still gets 1/8 of
   // every segment, which keeps the chip balanced across segments of different cost.
-  const int l = b - mp.start[s], n = mp.start[s + 1] - mp.start[s];
-  const int xcd = l & 7, qd = n >> 3, r = n & 7;
-  const int wg = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (l >> 3);
+  const int wg = live_order(p, b - mp.start[s], mp.start[s + 1] - mp.start[s], true);
+  if (wg < 0) return;
   if (p.kv_rows) attn_pipe_dma_body<T, 8, true, VORTA_RING>(p, smem, wg);
   else attn_pipe_dma_body<T, 8, false, VORTA_RING>(p, smem, wg);
 #endif

@@ -91,7 +91,7 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
   const int qb = rest % n_qb;
-  const int y = p.n_heads_dev ? spread_slot(rest / n_qb, p.n_heads) : rest / n_qb;
+  const int y = rest / n_qb;
   if (p.n_heads_dev && y >= *p.n_heads_dev) return;
   const int head = p.head_list ? p.head_list[y] : y;
   int grp, p0, pend;
@@ -564,17 +564,12 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
   }
 }
 
-__device__ __forceinline__ int xcd_order(int b, int n) {
-  // workgroups whose ids are equal mod 8 share an XCD: give each class a contiguous chunk of the logical ids
-  const int xcd = b & 7, qd = n >> 3, r = n & 7;
-  return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
-}
-
 template <typename TO, int NW, bool KVTAB, bool LMFMA>
 __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const Params8 pp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) char smem[SMEM8];
-  const int wg = pp.p.xcd_remap ? xcd_order(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int wg = live_order(pp.p, blockIdx.x, gridDim.x, pp.p.xcd_remap);  // XCD-aware order over the live workgroups
+  if (wg < 0) return;
   attn8_body<TO, NW, KVTAB, LMFMA>(pp, smem, wg);
 #endif
 }
@@ -588,7 +583,8 @@ __global__ __launch_bounds__(512, 2) void attn8_multi_kernel(const MultiParams8 
 #pragma unroll
   for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
   const Params8& pp = mp.seg[s];
-  const int wg = xcd_order(b - mp.start[s], mp.start[s + 1] - mp.start[s]);
+  const int wg = live_order(pp.p, b - mp.start[s], mp.start[s + 1] - mp.start[s], true);
+  if (wg < 0) return;
 #ifndef VORTA_MULTI_SWAP
 #define VORTA_MULTI_SWAP 1  /* see attn8_body: which half of the workgroup starts its steps with the VALU part; bit0 the body
                                without row tables, bit1 the body with them.  One box, fp8 step in ms, 0 / 1 / 2 / 3:

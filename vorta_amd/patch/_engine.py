@@ -115,6 +115,7 @@ class StepContext:
     forwards: int = 0
     needs_tau: bool = True       # hard top-1 dispatch (Eval processors); False for the soft mixture (Train)
     sp_token_shard: bool = False  # pipeline calls: the model gets the WHOLE latent and shards its token sequence itself
+    sp_coherent: bool = False     # this pipeline call's ranks were seen to hold the same tokens (install_token_shard)
 
 
 class BoundProcessor:
@@ -267,7 +268,8 @@ def install_sp_rope(rope: nn.Module, model: nn.Module, frame_dim: int = 2) -> No
     add_hook(model, rope.register_forward_pre_hook(pre))
 
 
-def install_token_shard(model: nn.Module, first_block: nn.Module, gather_before: nn.Module) -> None:
+def install_token_shard(model: nn.Module, first_block: nn.Module, gather_before: Optional[nn.Module] = None,
+                        gather_after: Optional[nn.Module] = None) -> None:
     """Token-level sequence-parallel shard INSIDE the transformer (replaces the frame shard of
     pipeline_hunyuan.py:367-369 for pipeline calls).  The reference shards the latent FRAMES, which refuses every frame
     count P does not divide (129 frames -> 33 latent frames: P = 2, 4, 8 all fail) -- while the token count divides
@@ -275,9 +277,16 @@ def install_token_shard(model: nn.Module, first_block: nn.Module, gather_before:
     whole latent; the stock forward embeds it, builds the global rotary table and the global attention mask as in the
     single-process case; the token sequence is cut to this rank's contiguous chunk [r S/P, (r+1) S/P) at the first
     block's input and concatenated again (all-gather along tokens) in front of `gather_before` (the output norm).  The
-    blocks in between see exactly what they see under a frame shard: a contiguous S/P chunk + the replicated text."""
+    blocks in between see exactly what they see under a frame shard: a contiguous S/P chunk + the replicated text.
+    `gather_after` instead of `gather_before`: concatenate the OUTPUT of that module (Wan: the last block, whose 16-bit
+    output the stock forward widens to fp32 in front of the output norm -- gathering there moves half the bytes).
+    Every rank must enter with the same tokens: the first cut of a pipeline call compares a checksum of the sequence
+    over the group and refuses to continue on a mismatch (a generator seeded per rank would otherwise make every rank
+    denoise a different video outside its own chunk)."""
     from ..ulysses import all_gather
     ctx = context_of(model)
+    if (gather_before is None) == (gather_after is None):
+        raise ValueError("install_token_shard takes exactly one of gather_before / gather_after")
 
     def _swap(args, kwargs, fn):
         if "hidden_states" in kwargs:
@@ -294,6 +303,14 @@ def install_token_shard(model: nn.Module, first_block: nn.Module, gather_before:
             S = x.shape[1]
             if S % P:
                 raise ValueError(f"{S} video tokens do not divide over {P} sequence-parallel ranks")
+            if not ctx.sp_coherent:  # once per pipeline call: one read-back of 2 P floats
+                sums = torch.stack([x.float().sum(), x.float().abs().sum()]).reshape(1, 2)
+                every = all_gather(sums, dim=0)
+                if not bool((every == every[:1]).all()):
+                    raise RuntimeError(
+                        "sequence-parallel ranks entered the transformer with different latents (checksums "
+                        f"{every.tolist()}): pass the pipeline a generator seeded identically on every rank, or none")
+                ctx.sp_coherent = True
             n = S // P
             return x[:, r * n:(r + 1) * n]
         return _swap(args, kwargs, f)
@@ -303,5 +320,15 @@ def install_token_shard(model: nn.Module, first_block: nn.Module, gather_before:
             return None
         return _swap(args, kwargs, lambda x: all_gather(x.contiguous(), dim=1))
 
+    def join_out(module, args, output):
+        if not (SP_STATE.enabled and ctx.sp_token_shard):
+            return None
+        if isinstance(output, tuple):
+            return (all_gather(output[0].contiguous(), dim=1),) + tuple(output[1:])
+        return all_gather(output.contiguous(), dim=1)
+
     add_hook(model, first_block.register_forward_pre_hook(cut, with_kwargs=True))
-    add_hook(model, gather_before.register_forward_pre_hook(join, with_kwargs=True))
+    if gather_before is not None:
+        add_hook(model, gather_before.register_forward_pre_hook(join, with_kwargs=True))
+    else:
+        add_hook(model, gather_after.register_forward_hook(join_out))

@@ -80,6 +80,7 @@ def run(pipe, args, kwargs, *, decode: Callable, self_attention_kwargs: Optional
     # them before decoding (:457-458), which refuses 33 latent frames (129-frame video) on 2, 4 or 8 ranks; the token
     # count of every BASELINE configuration divides by 8.
     ctx.sp_token_shard = bool(sp)
+    ctx.sp_coherent = False  # checked at the first cut of this call
     params["return_dict"] = False
     try:
         out = orig(pipe, **params)

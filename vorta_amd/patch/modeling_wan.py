@@ -49,7 +49,8 @@ def apply_vorta_transformer(model, train_router: bool = False, checkpoint_file: 
     E.install_forward_protocol(model, ctx)
     E.install_timestep_capture(model.condition_embedder.time_embedder, model, ctx)
     E.install_sp_rope(model.rope, model)
-    E.install_token_shard(model, model.blocks[0], model.norm_out)
+    # gather the last block's 16-bit output: the stock forward hands norm_out an fp32 copy (twice the bytes)
+    E.install_token_shard(model, model.blocks[0], gather_after=model.blocks[-1])
     if checkpoint_file is not None:
         load_router_checkpoint(checkpoint_file, model)
     return model
@@ -63,5 +64,6 @@ def apply_sp_flashattn_transformer(model):
         E.set_processor(block.attn1, WanAttnProcessor2_0())
         E.set_processor(block.attn2, WanAttnProcessor2_0())
     E.install_sp_rope(model.rope, model)
-    E.install_token_shard(model, model.blocks[0], model.norm_out)
+    # gather the last block's 16-bit output: the stock forward hands norm_out an fp32 copy (twice the bytes)
+    E.install_token_shard(model, model.blocks[0], gather_after=model.blocks[-1])
     return model

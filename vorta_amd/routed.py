@@ -151,9 +151,12 @@ DEFAULT_FP8 = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lowe
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
 # the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
 FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
-# coreset expert: key-side row list in group-major ascending order (VORTA_CORESET_KV_ORDER=packed: the reference's
-# [centres | margins] order, A/B)
-CORESET_KV_GROUP_MAJOR = __import__("os").environ.get("VORTA_CORESET_KV_ORDER", "group") != "packed"
+# coreset expert, key side: VORTA_CORESET_KV_ORDER=group reads K/V through a group-major ascending row list (the same rows
+# as the reference's packed [centres | margins] list; softmax does not see key order).  Measured NEUTRAL at Hunyuan-129f
+# fp16 (coreset launch 1 111 vs 1 109 TFLOP/s, fused step 4 099 vs 4 094 ms, profiles/r03_coreset_kv_order.txt): the
+# launch's distance from the full-attention one is its tail (7.3 rounds of workgroups) and the row tables, not the
+# gather's locality -- so the default stays the reference's order.
+CORESET_KV_GROUP_MAJOR = __import__("os").environ.get("VORTA_CORESET_KV_ORDER", "packed") == "group"
 # fused grid: the sliding expert's text-query segment goes first with at most this many key splits (0: as round 1 -- last,
 # with the stand-alone launch's split count; A/B)
 FUSED_TEXT_SPLITS = int(__import__("os").environ.get("VORTA_FUSED_TEXT_SPLITS", "1"))
