@@ -35,6 +35,7 @@ struct Params {
   int xcd_remap;
   float defer_log2;  // online-softmax rescale is skipped while the row max grows by <= this (log2 units)
   const int32_t* q_block_table;  // optional [n_groups * blocks_per_group][3] = (group, first position, end position)
+  int wg_per_slot;               // workgroups of one head slot = n_groups * blocks_per_group * n_splits
 };
 
 // query block qb of a launch -> its group (key list), first position and the end of its positions
@@ -49,21 +50,18 @@ __device__ __forceinline__ void q_block_of(const Params& p, int qb, int rows_per
   }
 }
 
-// Logical workgroup id of physical block b of a launch (or of a fused segment) with n ids; -1 = nothing to do.
+// Logical workgroup id of physical block b of a launch (or of a fused segment) with n ids.
 // XCD-aware order: workgroups whose ids are equal mod 8 share an XCD (round-robin dispatch), so each such class gets a
 // contiguous chunk of the logical ids (same head, neighbouring query blocks: one L2 serves the K/V stream instead of
 // eight).  With a device-resident head count (n_heads_dev) the grid is sized for every head slot but only the first
 // *n_heads_dev are live: the chunks are cut from the LIVE ids, so all eight XCDs share the live work to within one
-// workgroup, and the dead blocks leave at once.  (Cut from all n ids -- slot-major -- the live third of a uniform
+// workgroup; a dead block keeps its own id, which decodes to a slot >= *n_heads_dev, and leaves through the body's slot
+// check (no second exit path: one in the kernel wrappers cost the single-launch e4m3 kernels 36-100 B of scratch).  (Cut from all n ids -- slot-major -- the live third of a uniform
 // Hunyuan layer landed on three XCDs: the device-routed fused launch took 201 ms against 68 ms with host counts;
 // spreading whole slots instead left 14 live slots of 40 at 2 + 2 + ... + 1 + 1 per XCD, 13 % over the host-count time.)
 __device__ __forceinline__ int live_order(const Params& p, int b, int n, bool remap) {
-  if (p.n_heads_dev) {
-    const int per_slot = p.n_groups * p.blocks_per_group * p.n_splits;
-    n = min(n, max(*p.n_heads_dev, 0) * per_slot);
-    if (b >= n) return -1;
-  }
-  if (!remap) return b;
+  if (p.n_heads_dev) n = min(n, max(*p.n_heads_dev, 0) * p.wg_per_slot);
+  if (!remap || b >= n) return b;
   const int xcd = b & 7, qd = n >> 3, r = n & 7;
   return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
 }

@@ -35,7 +35,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
 
   // ---- work decomposition (XCD-aware: consecutive logical ids share an XCD's L2) ----
   const int wg = live_order(p, blockIdx.x, gridDim.x, p.xcd_remap);
-  if (wg < 0) return;
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
@@ -730,7 +729,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
   __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE_BYTES];
   // XCD-aware work order: consecutive logical ids (same head, neighbouring query blocks) share an XCD's L2
   const int wg = live_order(p, blockIdx.x, gridDim.x, p.xcd_remap);
-  if (wg < 0) return;
   attn_pipe_dma_body<T, NW, KVTAB, NS>(p, smem, wg);
 #endif
 }
@@ -754,7 +752,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParam
   // neighbouring query blocks -> one L2 serves the K/V stream instead of eight).  Every XCD still gets 1/8 of
   // every segment, which keeps the chip balanced across segments of different cost.
   const int wg = live_order(p, b - mp.start[s], mp.start[s + 1] - mp.start[s], true);
-  if (wg < 0) return;
   if (p.kv_rows) attn_pipe_dma_body<T, 8, true, VORTA_RING>(p, smem, wg);
   else attn_pipe_dma_body<T, 8, false, VORTA_RING>(p, smem, wg);
 #endif
@@ -887,6 +884,7 @@ int vorta_attn::fill_params(const vorta_attn_args* a, Params& p, int& block_rows
   }
   const int nblk = (p.n_kv + KVB - 1) / KVB;
   p.blocks_per_split = (nblk + p.n_splits - 1) / p.n_splits;
+  p.wg_per_slot = p.n_groups * p.blocks_per_group * p.n_splits;
   return VORTA_OK;
 }
 

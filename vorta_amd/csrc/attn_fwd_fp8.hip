@@ -569,7 +569,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn8_kernel(const Params8 pp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ __attribute__((aligned(16))) char smem[SMEM8];
   const int wg = live_order(pp.p, blockIdx.x, gridDim.x, pp.p.xcd_remap);  // XCD-aware order over the live workgroups
-  if (wg < 0) return;
   attn8_body<TO, NW, KVTAB, LMFMA>(pp, smem, wg);
 #endif
 }
@@ -584,7 +583,6 @@ __global__ __launch_bounds__(512, 2) void attn8_multi_kernel(const MultiParams8 
   for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
   const Params8& pp = mp.seg[s];
   const int wg = live_order(pp.p, b - mp.start[s], mp.start[s + 1] - mp.start[s], true);
-  if (wg < 0) return;
 #ifndef VORTA_MULTI_SWAP
 #define VORTA_MULTI_SWAP 1  /* see attn8_body: which half of the workgroup starts its steps with the VALU part; bit0 the body
                                without row tables, bit1 the body with them.  One box, fp8 step in ms, 0 / 1 / 2 / 3:
