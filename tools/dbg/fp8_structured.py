@@ -76,6 +76,15 @@ def psnr(x, ref):
     return f(rng), f(peak), math.sqrt(mse / torch.mean(ref ** 2).item())
 
 
+def smoothed(q, k):
+    """per-channel smoothing q diag(s), k diag(1/s) with s = sqrt(amax_k / amax_q) (SmoothQuant-style): exact for the
+    scores; would help a FIXED-point format, and is expected to do nothing for a floating-point one (the relative
+    rounding error of every product is the same before and after)"""
+    aq, ak = q.abs().amax(1, keepdim=True).float(), k.abs().amax(1, keepdim=True).float()
+    s = (ak / aq).sqrt()
+    return (q.float() * s), (k.float() / s)
+
+
 names = ["full", "coreset", "sliding"]
 print(f"{args.geometry} {args.dtype}: PSNR over data range dB | PSNR over max|x| dB | rel rms")
 for name, q, k, v in families():
@@ -89,4 +98,14 @@ for name, q, k, v in families():
         a, b, c = psnr(out[0, h, :S + te], ref[0, h, :S + te])
         row.append(f"{names[h]} {a:5.1f} | {b:5.1f} | {c:.4f}")
     print(f"{name:70s} " + "   ".join(row), flush=True)
+    if "outlier" in name:
+        qs, ks = smoothed(q[0], k[0])
+        out = routed_attention(qs.to(dt)[None], ks.to(dt)[None], v, routing, geom, fp8=True, **kw)
+        ref2 = routed_attention(qs.to(dt)[None], ks.to(dt)[None], v, routing, geom, **kw)
+        torch.cuda.synchronize()
+        row = []
+        for h in (0, 2):  # (the coreset expert ranks by cosine similarity, which smoothing changes: not comparable)
+            a, b, c = psnr(out[0, h, :S + te], ref2[0, h, :S + te])
+            row.append(f"{names[h]} {a:5.1f} | {b:5.1f} | {c:.4f}")
+        print(f"{'    the same with q diag(s), k diag(1/s) per channel':70s} " + "   ".join(row), flush=True)
     del q, k, v, ref, out

@@ -10,8 +10,8 @@ $B --config hunyuan-129f --steps 2 --warmup 1 > $O/hunyuan_fp16_attention.json 2
 $B --config hunyuan-129f --steps 2 --warmup 1 --level processor > $O/hunyuan_fp16_processor.json 2>> $O/err.txt
 $B --config wan14b-81f --steps 2 --warmup 1 --level processor > $O/wan14b_bf16_processor.json 2>> $O/err.txt
 $B --config wan14b-81f --dtype fp8 --steps 2 --warmup 1 --level processor > $O/wan14b_fp8_processor.json 2>> $O/err.txt
-python3 tools/dbg/fp8_structured.py --geometry wan14b-81f > $O/fp8_structured_wan14b.txt 2>> $O/err.txt
-python3 tools/dbg/fp8_structured.py --geometry hunyuan-129f > $O/fp8_structured_hunyuan.txt 2>> $O/err.txt
+
+
 python3 - <<'PY'
 import json, glob, os
 for f in sorted(glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out/r3/c/*.json"))):
@@ -21,4 +21,4 @@ for f in sorted(glob.glob(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_ou
     except Exception as e:
         print(os.path.basename(f), "-", str(e)[:60])
 PY
-cat $O/fp8_structured_wan14b.txt $O/fp8_structured_hunyuan.txt
+
