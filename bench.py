@@ -484,13 +484,29 @@ def main():
                 "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                 "flops_per_launch": dom["flops"] / max(dom["launches"], 1),
                 "share_of_step": round(dom["ms"] / (ms_per_step * args.steps), 3)}
-    # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself);
-    # only valid for the workload they were collected on
+    # bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself), keyed by
+    # workload: `traffic` = bytes leaving the L2s (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md 'HBM'); the Infinity
+    # Cache sits behind that interface, the memory controllers' own activity (tools/umc_activity.py) gives the DRAM side
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
-        if pmc["workload"] == f"{args.config} {args.mix} {cfg['dtype']}" and world == 1:
-            roofline["traffic"] = round(pmc["kernels"][dom_sym]["hbm_bytes_per_launch"])
-            roofline["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_pmc_hbm_traffic.json)"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
+        wl = pmc["workloads"].get(f"{args.config} {args.mix} {cfg['dtype']}")
+        if wl is not None and world == 1 and not emu and proc_info is None:
+            mangled = {"attn_fwd_multi_kernel": "attn_fwd_multi_kernel", "attn8_multi_kernel": "attn8_multi_kernel",
+                       "attn_fwd_pipe_kernel": "attn_fwd_pipe_kernel", "attn8_kernel": "attn8_kernel"}
+            base = dom_sym.split("<")[0]
+            hit = [v for k_, v in wl["kernels"].items() if mangled.get(base, base) in k_]
+            if len(hit) == 1:
+                roofline["traffic"] = hit[0]["l2_miss_bytes_per_launch"]
+                roofline["traffic_unit"] = ("bytes per launch leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE, "
+                                            "profiles/r03_pmc_traffic.json)")
+                roofline["traffic_over_minimum"] = round(hit[0]["l2_miss_bytes_per_launch"] /
+                                                         wl["algorithmic_min_bytes_per_fused_launch"], 2)
+        umc = os.path.join(ROOT, "profiles", f"r03_umc_activity_{args.config}_{cfg['dtype']}.json")
+        if os.path.exists(umc) and args.mix == "uniform" and world == 1 and not emu and proc_info is None:
+            u = json.load(open(umc))
+            roofline["traffic_dram_estimate"] = u["from_percent"]["bytes_per_layer"]
+            roofline["traffic_dram_unit"] = ("HBM bytes per launch from the memory controllers' activity (coarse: integer "
+                                             "percent; tools/umc_activity.py)")
     except Exception:
         pass
     per_tag = {f"{tag}: {sym}": {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),

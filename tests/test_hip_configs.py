@@ -4,8 +4,8 @@ sampled rows against the oracle (the oracle cannot hold an S x S score matrix at
   configs[0]  Wan-2.1 1.3B 49x320x512  (13,20,32)  S =   8 320  native (dense) attention, 12 heads
   configs[1]  Wan-2.1 1.3B 81x480x832  (21,30,52)  S =  32 760  routed, tile (7,6,4), coreset (3,3,2)
   configs[2]  HunyuanVideo 129x720x1280 (33,45,80) S = 118 800  routed: tests/test_hip_experts.py::test_full_size_*
-  configs[4]  Wan-2.1 14B 81x720x1280  (21,45,80)  S =  75 600  routed, tile (7,9,8), coreset (3,3,2), 40 heads (bf16;
-              the fp8 MFMA path of that config is not built)
+  configs[4]  Wan-2.1 14B 81x720x1280  (21,45,80)  S =  75 600  routed, tile (7,9,8), coreset (3,3,2), 40 heads (bf16, and
+              one rank of eight through the e4m3 kernels: test_config4_one_rank_of_eight_fp8_at_full_size)
 """
 import numpy as np
 import pytest

@@ -446,3 +446,53 @@ def test_fp8_operator_psnr_wan14b_81f_geometry():
     assert not torch.isnan(out).any()
     for n, (p_range, p_peak, rel) in table.items():
         assert p_range >= 40.0 and p_peak >= 39.0 and rel <= 0.06, (n, p_range, p_peak, rel)
+
+
+# Gates of the structured-input families (tests/_fp8_inputs.py), dB of PSNR over max|x| of the 16-bit result -- the stricter
+# of the two conventions -- per expert, measured at both geometries (profiles/r03_fp8_structured_inputs.txt) and held 1 dB
+# under the worst of them.  What e4m3 operands can and cannot do: a score is a sum of 128 products whose rounding errors
+# (2^-4 relative at most, 2.6 % rms, for each e4m3 operand) add up to 3.7 % of the ROOT SUM OF SQUARES of the products, so
+# the absolute error of a logit grows with the logits themselves.  Flat softmax (white noise, smooth fields, heavy tails,
+# common components -- the key centring removes the k side, the q side is a per-key constant times a small error):
+# >= 40 dB.  Peaked softmax (logit spread x 4): 36-38 dB.  Outlier channels from norm weights (6 channels carry the logits):
+# 29-32 dB, 21-26 dB with a common part on top -- and per-channel smoothing of q and k, exact for the scores, changes
+# nothing (a floating-point format keeps its relative error under any rescaling): an 8-bit path that holds 40 dB there
+# needs more mantissa in q k^T, not other scales.
+FAMILY_GATES = {"white": 39.0, "common3": 40.0, "student_t3": 42.0, "smooth": 55.0, "peaked": 34.5, "outlier_w": 27.5,
+                "outlier_w_common": 19.5}
+
+
+@pytest.mark.parametrize("geometry", ["wan14b-81f", "hunyuan-129f"])
+def test_fp8_operator_psnr_on_structured_inputs(geometry):
+    """gate (ii) beyond white noise, at BASELINE configs[4]'s geometry and at the headline's (with text rows): every expert,
+    fp8 against the bf16 kernels on the same bf16 inputs, both PSNR conventions printed, the stricter one gated."""
+    from _fp8_inputs import NAMES, families, psnr, smoothed
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.bfloat16
+    if geometry == "wan14b-81f":
+        latent, tile, window, group, model, T, te = (21, 45, 80), (7, 9, 8), (3, 3, 3), (3, 3, 2), "wan", 0, 0
+    else:
+        latent, tile, window, group, model, T, te = (33, 45, 80), (11, 9, 8), (3, 3, 3), (3, 3, 2), "hunyuan", 256, 96
+    S = latent[0] * latent[1] * latent[2]
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    routing = HeadRouting.from_expert_ids([0, 1, 2], dev())
+    gen = torch.Generator(device=dev()).manual_seed(1234)
+    kw = dict(model=model, text_len=T, text_valid=te)
+    experts = ["full", "coreset", "sliding"]
+    for key, q, k, v in families(latent, 3, T, gen, dev()):
+        q16, k16, v16 = (x.to(dtype)[None].contiguous() for x in (q, k, v))
+        ref = routed_attention(q16, k16, v16, routing, geom, **kw)
+        out = routed_attention(q16, k16, v16, routing, geom, fp8=True, **kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all(), key
+        table = {experts[h]: psnr(out[0, h, :S + te], ref[0, h, :S + te]) for h in range(3)}
+        print(f"fp8 vs bf16 [{geometry}] {NAMES[key]}: " + ", ".join(f"{n} {a:.1f} / {b:.1f} dB rel {c:.3f}" for n, (a, b, c) in table.items()))
+        for n, (p_range, p_peak, rel) in table.items():
+            assert p_peak >= FAMILY_GATES[key] and p_range >= p_peak, (geometry, key, n, p_range, p_peak, rel)
+        if key == "outlier_w":  # per-channel smoothing of q, k: exact for the scores, no help for a floating-point format
+            qs, ks = (x.to(dtype)[None].contiguous() for x in smoothed(q, k))
+            ref2 = routed_attention(qs, ks, v16, routing, geom, **kw)
+            out2 = routed_attention(qs, ks, v16, routing, geom, fp8=True, **kw)
+            for h in (0, 2):  # (the coreset ranking itself changes under the rescaling: not comparable)
+                gain = psnr(out2[0, h, :S + te], ref2[0, h, :S + te])[1] - table[experts[h]][1]
+                assert abs(gain) < 2.5, (geometry, experts[h], gain)

@@ -26,8 +26,8 @@ def sample():
         d = json.loads(out)
         card = next(iter(d.values()))
         mem = next((float(v) for k, v in card.items() if "Read/Write Activity" in k), None)
-        use = next((float(v) for k, v in card.items() if k.startswith("GPU use")), None)
-        return mem, use
+        acc = next((float(v) for k, v in card.items() if k.strip() == "Memory Activity"), None)  # accumulated counter
+        return mem, acc
     except Exception as e:  # noqa: BLE001
         return None, None
 
@@ -97,6 +97,20 @@ def main():
     copy_tbs = n * 2 * src.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e12
     sm.phase = "idle"
     time.sleep(1.0)
+    # (A') a second calibration point near the rate in question: the same copy at a ~6 % duty cycle
+    sm.phase = "slowcopy"
+    small_s, small_d = src[:256 << 20], dst[:256 << 20]
+    n = 0
+    t0 = time.time()
+    t_end = t0 + args.seconds
+    while time.time() < t_end:
+        small_d.copy_(small_s)
+        torch.cuda.synchronize()
+        n += 1
+        time.sleep(0.0017)
+    slow_tbs = n * 2 * small_s.numel() / (time.time() - t0) / 1e12
+    sm.phase = "idle"
+    time.sleep(1.0)
     # (B) the fused layer launches back to back
     sm.phase = "attention"
     n = 0
@@ -119,15 +133,29 @@ def main():
         v = v[1:-1] if len(v) > 4 else v  # drop the edges of the phase
         return (sum(v) / len(v), min(v), max(v), len(v)) if v else (None, None, None, 0)
 
-    a, b, i = stats("copy"), stats("attention"), stats("idle")
-    res = {"workload": f"{args.config} uniform {args.dtype}", "copy_TBps": round(copy_tbs, 3),
-           "umc_activity_percent": {"copy": a, "attention": b, "idle": i}, "attention_ms_per_layer": round(ms_per_layer, 3)}
+    def acc_rate(phase):
+        """accumulated-activity counter per second over the phase (finer than the integer percent)"""
+        v = [(t, a) for t, p, _, a in sm.rows if p == phase and a is not None]
+        v = v[1:-1] if len(v) > 4 else v
+        return (v[-1][1] - v[0][1]) / (v[-1][0] - v[0][0]) if len(v) >= 2 and v[-1][0] > v[0][0] else None
+
+    a, b, i, sl = stats("copy"), stats("attention"), stats("idle"), stats("slowcopy")
+    ra, rb, ri, rs = acc_rate("copy"), acc_rate("attention"), acc_rate("idle"), acc_rate("slowcopy")
+    res = {"workload": f"{args.config} uniform {args.dtype}", "copy_TBps": round(copy_tbs, 3), "slow_copy_TBps": round(slow_tbs, 3),
+           "umc_activity_percent": {"copy": a, "slowcopy": sl, "attention": b, "idle": i},
+           "memory_activity_counter_per_s": {"copy": ra, "slowcopy": rs, "attention": rb, "idle": ri},
+           "attention_ms_per_layer": round(ms_per_layer, 3),
+           "algorithmic_min_bytes_per_layer": (S + T) * H * 128 * ((3 if fp8 else 6) + 2)}
     if a[0] and b[0] is not None:
         per_pct = copy_tbs / a[0]  # TB/s of HBM traffic per percent of UMC activity
         bw = b[0] * per_pct
-        res["attention_hbm_TBps_estimate"] = round(bw, 3)
-        res["attention_hbm_bytes_per_layer_estimate"] = round(bw * 1e12 * ms_per_layer * 1e-3)
-        res["algorithmic_min_bytes_per_layer"] = 4 * (S + T) * H * 128 * 2
+        res["from_percent"] = {"attention_hbm_TBps": round(bw, 3), "bytes_per_layer": round(bw * 1e12 * ms_per_layer * 1e-3),
+                               "slowcopy_check_TBps": round(sl[0] * per_pct, 3) if sl[0] is not None else None}
+    if ra and rb is not None and ri is not None and ra > ri:
+        per = copy_tbs / (ra - ri)
+        bw = max(rb - ri, 0.0) * per
+        res["from_counter"] = {"attention_hbm_TBps": round(bw, 3), "bytes_per_layer": round(bw * 1e12 * ms_per_layer * 1e-3),
+                               "slowcopy_check_TBps": round(max(rs - ri, 0.0) * per, 3) if rs is not None else None}
     print(json.dumps(res))
     if args.json:
         json.dump(res, open(args.json, "w"), indent=1)
