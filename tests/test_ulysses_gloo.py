@@ -246,6 +246,13 @@ def _token_shard_worker(rank, world, port, ret):
         pipe(**dict(args, height=1, width=1, num_frames=world + 1), generator=torch.Generator().manual_seed(7))
     except ValueError:
         refused = True
+    incoherent = False
+    try:  # a generator seeded per rank: every rank would denoise another video outside its own chunk -- refused at the first cut
+        pipe(**args, generator=torch.Generator().manual_seed(100 + rank))
+    except RuntimeError as e:
+        incoherent = "different latents" in str(e)
+    again = pipe(**args, generator=torch.Generator().manual_seed(7))[0]  # and the model is usable afterwards
+    refused = refused and incoherent and torch.equal(again, part)
     ret[rank] = (err, float(full.abs().max()), tuple(part.shape), all(torch.equal(gathered[0], x) for x in gathered), refused)
     dist.barrier()
     SP_STATE.cleanup()
