@@ -460,14 +460,18 @@ def fp8_quantize_qkv(q: np.ndarray, k: np.ndarray, v: np.ndarray, scale: Optiona
     """include/vorta_hip.h vorta_fp8_quantize_qkv on (H,S,D) arrays holding bf16/fp16-representable values.
     The multipliers are computed in float32 like the kernel (fp8_quant.hip: fp8_scales_kernel), the products too.
     `k_center` (H,D) float32: the centre subtracted from the keys (flags bit1; any vector is legitimate -- softmax over
-    the keys does not see it -- so tests pass the kernel's own, after checking it against `fp8_center_rows`)."""
+    the keys does not see it -- so tests pass the kernel's own, after checking it against `fp8_center_rows`).
+    The abs-max of q and of the centred k is taken over the head's SAMPLE (the tokens of `fp8_center_rows`: the multipliers
+    of q and k only balance the two operand ranges); v's per-channel abs-max is over every token."""
     f32 = np.float32
     q, k, v = (np.asarray(a, dtype=f32) for a in (q, k, v))
     if k_center is not None:
         k = (k - np.asarray(k_center, f32)[:, None, :]).astype(f32)
     D = q.shape[-1]
     c0 = f32(f32(1.0 / np.sqrt(D) if scale is None else scale) * f32(1.4426950408889634))
-    mq, mk = np.abs(q).max((1, 2)), np.abs(k).max((1, 2))
+    rows = fp8_center_rows(q.shape[1], q.shape[0])
+    mq = np.stack([np.abs(q[h, rows[h]]).max() for h in range(q.shape[0])]).astype(f32)
+    mk = np.stack([np.abs(k[h, rows[h]]).max() for h in range(k.shape[0])]).astype(f32)
     t = np.ones_like(mq)
     ok = (mq > 0) & (mk > 0)
     t[ok] = np.sqrt((mk[ok] / (c0 * mq[ok]).astype(f32)).astype(f32)).astype(f32)

@@ -237,6 +237,58 @@ def test_hunyuan_triple_eval_vs_oracle(dual):
 
 
 @pytest.mark.parametrize("dual", [True, False])
+@pytest.mark.parametrize("precision", ["native", "fp8"])
+def test_hunyuan_processor_call_is_sync_free_and_graph_capturable(dual, precision):
+    """The production call -- projections into one buffer, qk-norm + RoPE, device-resident routes from the score tensor
+    (no head counts on the host), fused routed attention, output projection -- enqueues without a host synchronisation
+    (torch's sync-debug mode raises on one) and therefore captures into a hipGraph that replays against new activations
+    and NEW routes, equal to the eager call bit for bit."""
+    import vorta_amd
+    from vorta_amd.attention import (HunyuanVideoFlashAttnProcessorTripleEval, create_sliding_tile_attn_mask_func,
+                                     get_group_info)
+    dtype = torch.bfloat16
+    hidden_dim, T, te = 64, 16, 11
+    attn = _HyFakeAttn(hidden_dim, dual, dtype, seed=13 + dual)
+    torch.manual_seed(8)
+    hidden = torch.randn((1, S, hidden_dim), device=dev()).to(dtype)
+    enc = torch.randn((1, T, hidden_dim), device=dev()).to(dtype)
+    ang = torch.rand((S, 64), device=dev()) * 6.28
+    rope = (ang.cos().repeat_interleave(2, dim=1).contiguous(), ang.sin().repeat_interleave(2, dim=1).contiguous())
+    mask = torch.zeros((1, 1, 1, S + T), dtype=torch.bool, device=dev())
+    mask[..., :S + te] = True
+    score = torch.softmax(torch.randn((1, H, 3), device=dev()) * 2, dim=-1)
+    kw = dict(lowres_group_info=get_group_info(LATENT, GROUP, 0.5, dev()), window_size=WINDOW, tile_size=TILE,
+              latent_shape=LATENT, flex_attn_mask_func=create_sliding_tile_attn_mask_func(LATENT, WINDOW, TILE, T, te, dev()))
+    proc = HunyuanVideoFlashAttnProcessorTripleEval()
+    vorta_amd.set_attention_precision(precision)
+    try:
+        call = lambda: proc(attn, hidden, enc, mask, rope, routing_score=score, tau_sparse=0.3, **kw)
+        call()  # warm-up: geometry tables, allocator pools
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            eager = call()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = call()
+        # new activations and new routes at the captured addresses
+        hidden.copy_(torch.randn((1, S, hidden_dim), device=dev()).to(dtype))
+        enc.copy_(torch.randn((1, T, hidden_dim), device=dev()).to(dtype))
+        score.copy_(torch.softmax(torch.randn((1, H, 3), device=dev()) * 2, dim=-1))
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = [x.clone() for x in captured]
+        again = call()
+        assert not torch.equal(replayed[0], eager[0])
+        for a, b in zip(replayed, again):
+            assert torch.equal(a, b)
+    finally:
+        vorta_amd.set_attention_precision("native")
+
+
+@pytest.mark.parametrize("dual", [True, False])
 def test_hunyuan_block_projects_into_one_buffer(dual):
     """SURVEY §8f N1 "+ text concat": the video and text projections land in one (1, S+T, H*D) buffer per tensor (the
     GEMMs write it), qk-norm + RoPE run in place on the row ranges -- the same q, k, v as the reference's route

@@ -37,9 +37,10 @@ def main():
     q, k, v = (torch.randn((H, S + T, 128), device=dev, dtype=torch.bfloat16) for _ in range(3))
     f8 = ops.fp8_quantize_qkv(q, k, v, center_k=True)
     ms = timeit(lambda: ops.fp8_quantize_qkv(q, k, v, out=f8, center_k=True))
-    gb = 3 * q.numel() * 5 / 1e9
-    print(f"vorta_fp8_quantize_qkv bf16 (H={H}, {S + T} tokens; q,k,v: abs-max pass 2 B + convert pass 2 B in / 1 B out "
-          f"per element): {ms:.3f} ms  {gb / ms:.2f} TB/s ({gb:.2f} GB)", flush=True)
+    gb = q.numel() * (2 + 3 * 3) / 1e9
+    print(f"vorta_fp8_quantize_qkv bf16 (H={H}, {S + T} tokens; abs-max pass over v 2 B, convert pass over q,k,v 2 B in / "
+          f"1 B out per element; q/k abs-max from the centre's token sample): {ms:.3f} ms  {gb / ms:.2f} TB/s ({gb:.2f} GB)",
+          flush=True)
 
 
 if __name__ == "__main__":

@@ -15,8 +15,15 @@
 // rows of a segment hold data (the text rows behind each head slot), the rest is skipped; slot_first / slot_count
 // restrict a call to some head slots (the slot group whose exchange has landed).
 //
+// Abs-max of q and k: the multipliers of q and k only BALANCE the two operand ranges (qmul * kmul = c0 whatever they are;
+// both maxima land near sqrt(c0 amax_q amax_k), a factor ~250 inside e4m3's range for unit-variance data), so their abs-max
+// is taken over the same ~1024 sampled tokens as the centre instead of a full pass over q and k: a true maximum a few
+// times the sampled one moves nothing but that headroom (values are clamped to +-448 before the conversion in any case).
+// v is scaled per channel to a target just under the format's maximum, so ITS abs-max is exact (one pass over v).
+//
 // Workspace (floats): amax_q[H] | amax_k[H] | amax_v[H][D] | qmul[H] | kmul[H] | vmul[H][D] | kmean[H][D] |
-//                     ksum[H][MEAN_BLOCKS][D] | kcnt[H][MEAN_BLOCKS]
+//                     ksum[H][MEAN_BLOCKS][D] | kcnt[H][MEAN_BLOCKS] | kmax[H][MEAN_BLOCKS][D] | kmin[H][MEAN_BLOCKS][D] |
+//                     qamax[H][MEAN_BLOCKS]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -51,6 +58,9 @@ template <typename T> __device__ __forceinline__ float to_f(T v) { return (float
 __device__ __forceinline__ float* kmean_of(const QParams& p) { return p.ws + 2 * (2 * p.heads + p.heads * D); }
 __device__ __forceinline__ float* ksum_of(const QParams& p) { return kmean_of(p) + p.heads * D; }
 __device__ __forceinline__ float* kcnt_of(const QParams& p) { return ksum_of(p) + p.heads * MEAN_BLOCKS * D; }
+__device__ __forceinline__ float* kmaxp_of(const QParams& p) { return kcnt_of(p) + p.heads * MEAN_BLOCKS; }
+__device__ __forceinline__ float* kminp_of(const QParams& p) { return kmaxp_of(p) + p.heads * MEAN_BLOCKS * D; }
+__device__ __forceinline__ float* qamaxp_of(const QParams& p) { return kminp_of(p) + p.heads * MEAN_BLOCKS * D; }
 // centre of channel d of head h from the partial sums: the same expression wherever it is needed (bit-identical)
 __device__ __forceinline__ float kcenter(const QParams& p, int h, int d) {
   const float* ks = ksum_of(p) + (int64_t)h * MEAN_BLOCKS * D + d;
@@ -82,20 +92,24 @@ __device__ __forceinline__ void block_rows(const QParams& p, int& r0, int& r1, i
   }
 }
 
-// grid (heads, MEAN_BLOCKS), 1024 threads: partial sums for the centre of the head's keys = mean over its tokens
-// s = i * mean_stride (i < n_cand), the same tokens whether the head is a (S,D) view or scattered over the segments of the
-// Ulysses receive layout (so a head gets the same centre, hence the same e4m3 bytes, on one GPU and on a rank of P).
-// 64 row lanes x 16 channel groups, four rows in flight per lane; fixed reduction order here and in `kcenter`.
+// grid (heads, MEAN_BLOCKS), 1024 threads: the head's SAMPLE -- its tokens s = i * mean_stride (i < mean_cand), the same
+// tokens whether the head is a (S,D) view or scattered over the segments of the Ulysses receive layout (so a head gets the
+// same centre and multipliers, hence the same e4m3 bytes, on one GPU and on a rank of P).  Per block: partial sums of the
+// sampled key rows (the centre), per-channel max / min of them (abs-max of k minus ANY centre follows exactly), abs-max of
+// the sampled q rows.  64 row lanes x 16 channel groups, four rows in flight per lane; fixed reduction order here and in
+// `kcenter` (deterministic).
 template <typename T>
-__global__ __launch_bounds__(1024) void fp8_kmean_kernel(const QParams p) {
+__global__ __launch_bounds__(1024) void fp8_sample_kernel(const QParams p) {
   typedef __attribute__((ext_vector_type(8))) T T8;
   constexpr int RL = 64;
   const int h = p.slot_first + blockIdx.x;
   const int t = threadIdx.x, cc = t & 15, rl = t >> 4;
   const char* base = p.x[1] + (p.seg_len > 0 ? 0 : (int64_t)h * p.x_sh[1]) + cc * 16;
-  float s[8];
+  const char* qbase = p.x[0] + (p.seg_len > 0 ? 0 : (int64_t)h * p.x_sh[0]) + cc * 16;
+  float s[8], kmx[8], kmn[8];
+  float qm = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s[i] = 0.f;
+  for (int i = 0; i < 8; ++i) { s[i] = 0.f; kmx[i] = -3.0e38f; kmn[i] = 3.0e38f; }
   int cnt = 0;
   const int n_cand = p.mean_cand;
   // physical row of token s of head h
@@ -106,107 +120,146 @@ __global__ __launch_bounds__(1024) void fp8_kmean_kernel(const QParams p) {
     return (int64_t)p.tail_first + (int64_t)h * p.seg_len + (tok - p.video_tokens);
   };
   for (int i0 = blockIdx.y * 4 * RL + rl; i0 < n_cand; i0 += MEAN_BLOCKS * 4 * RL) {
-    T8 v[4];
+    T8 v[4], w[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       ok[u] = i0 + u * RL < n_cand;
-      if (ok[u]) v[u] = *(const T8*)(base + row_of(i0 + u * RL) * p.x_ss[1]);
+      if (ok[u]) {
+        const int64_t r = row_of(i0 + u * RL);
+        v[u] = *(const T8*)(base + r * p.x_ss[1]);
+        w[u] = *(const T8*)(qbase + r * p.x_ss[0]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       if (ok[u]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += to_f(v[u][j]);
+        for (int j = 0; j < 8; ++j) {
+          const float kf = to_f(v[u][j]);
+          s[j] += kf;
+          kmx[j] = fmaxf(kmx[j], kf);
+          kmn[j] = fminf(kmn[j], kf);
+          qm = fmaxf(qm, fabsf(to_f(w[u][j])));
+        }
         ++cnt;
       }
   }
   __shared__ float red[RL][D + 1];
   __shared__ int cred[RL];
+  __shared__ float qred[RL];
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = s[i];
   if (cc == 0) cred[rl] = cnt;
+  // q: over the 16 channel groups of a row lane, then over the row lanes
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) qm = fmaxf(qm, __shfl_xor(qm, off));
+  if (cc == 0) qred[rl] = qm;
   __syncthreads();
+  const int64_t part = (int64_t)h * MEAN_BLOCKS + blockIdx.y;
   if (t < D) {
     float a = 0.f;
     int n = 0;
     for (int j = 0; j < RL; ++j) { a += red[j][t]; n += cred[j]; }
-    ksum_of(p)[((int64_t)h * MEAN_BLOCKS + blockIdx.y) * D + t] = a;
-    if (t == 0) kcnt_of(p)[h * MEAN_BLOCKS + blockIdx.y] = (float)n;
+    ksum_of(p)[part * D + t] = a;
+    if (t == 0) {
+      kcnt_of(p)[part] = (float)n;
+      float q = 0.f;
+      for (int j = 0; j < RL; ++j) q = fmaxf(q, qred[j]);
+      qamaxp_of(p)[part] = q;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = kmx[i];
+  __syncthreads();
+  if (t < D) {
+    float a = -3.0e38f;
+    for (int j = 0; j < RL; ++j) a = fmaxf(a, red[j][t]);
+    kmaxp_of(p)[part * D + t] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = kmn[i];
+  __syncthreads();
+  if (t < D) {
+    float a = 3.0e38f;
+    for (int j = 0; j < RL; ++j) a = fminf(a, red[j][t]);
+    kminp_of(p)[part * D + t] = a;
   }
 }
 
-// grid (row chunks, heads or 1, 3): per-head abs-max of q and k (k minus its centre), per-(head, channel) abs-max of v
+// grid (row chunks, heads or 1): per-(head, channel) abs-max of v (exact: v is scaled to just under the format's maximum)
 template <typename T>
 __global__ __launch_bounds__(256) void fp8_absmax_kernel(const QParams p) {
   typedef __attribute__((ext_vector_type(8))) T T8;
-  const int which = blockIdx.z;
+  constexpr int which = 2;
   int r0, r1, h, hphys;
   block_rows(p, r0, r1, h, hphys);
   if (r0 >= r1) return;
   const int t = threadIdx.x, cc = t & 15, rl = t >> 4;
   const char* base = p.x[which] + (int64_t)hphys * p.x_sh[which] + cc * 16;
-  float c[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c[i] = 0.f;
-  if (which == 1 && p.center_k) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) c[i] = kcenter(p, h, cc * 8 + i);
-  }
   float m[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) m[i] = 0.f;
   for (int r = r0 + rl; r < r1; r += 16) {
     const T8 v = *(const T8*)(base + (int64_t)r * p.x_ss[which]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(to_f(v[i]) - c[i]));
+    for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], fabsf(to_f(v[i])));
   }
   __shared__ float red[16][D + 1];
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[rl][cc * 8 + i] = m[i];
   __syncthreads();
-  float cm = 0.f;
   if (t < D) {
+    float cm = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) cm = fmaxf(cm, red[j][t]);
-  }
-  unsigned* ws = (unsigned*)p.ws;
-  const int H = p.heads;
-  if (which == 2) {
-    if (t < D) atomicMax(ws + 2 * H + h * D + t, __float_as_uint(cm));
-    return;
-  }
-  // q / k: one value per head
-  __syncthreads();
-  if (t < D) red[0][t] = cm;
-  __syncthreads();
-  if (t < 64) {
-    float x = fmaxf(red[0][t], red[0][t + 64]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off));
-    if (t == 0) atomicMax(ws + which * H + h, __float_as_uint(x));
+    atomicMax((unsigned*)p.ws + 2 * p.heads + h * D + t, __float_as_uint(cm));
   }
 }
 
-// grid (heads), 128 threads: multipliers from the abs-max slots
+// grid (heads), 128 threads: centre, abs-max of q and of k minus its centre from the sample partials, multipliers
 __global__ __launch_bounds__(128) void fp8_scales_kernel(const QParams p) {
   const int h = p.slot_first + blockIdx.x, d = threadIdx.x, H = p.heads;
-  const float mq = p.ws[h], mk = p.ws[H + h];
+  const float c = p.center_k ? kcenter(p, h, d) : 0.f;
+  kmean_of(p)[h * D + d] = c;
+  // per channel: max over the sampled keys of |k - c| = max(kmax - c, c - kmin) (fl(x - c) is monotone in x: exactly what
+  // a pass over the same rows computing |k - c| would give)
+  float kmx = -3.0e38f, kmn = 3.0e38f;
+#pragma unroll
+  for (int b = 0; b < MEAN_BLOCKS; ++b) {
+    kmx = fmaxf(kmx, kmaxp_of(p)[((int64_t)h * MEAN_BLOCKS + b) * D + d]);
+    kmn = fminf(kmn, kminp_of(p)[((int64_t)h * MEAN_BLOCKS + b) * D + d]);
+  }
+  float ak = kmx >= kmn ? fmaxf(kmx - c, c - kmn) : 0.f;  // (no sample at all: 0)
+  __shared__ float red[D];
+  red[d] = ak;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (d < s) red[d] = fmaxf(red[d], red[d + s]);
+    __syncthreads();
+  }
+  const float mk = red[0];
+  __syncthreads();
   float* qmul = p.ws + 2 * H + H * D;
   float* kmul = qmul + H;
   float* vmul = kmul + H;
   if (d == 0) {
+    float mq = 0.f;
+#pragma unroll
+    for (int b = 0; b < MEAN_BLOCKS; ++b) mq = fmaxf(mq, qamaxp_of(p)[h * MEAN_BLOCKS + b]);
+    p.ws[h] = mq;
+    p.ws[H + h] = mk;
     // q8 . k8 = c0 * q . k with both operand maxima at sqrt(c0 * mq * mk)
     float t = 1.f;
     if (mq > 0.f && mk > 0.f) t = sqrtf(mk / (p.c0 * mq));
     qmul[h] = p.c0 * t;
     kmul[h] = 1.f / t;
   }
-  kmean_of(p)[h * D + d] = p.center_k ? kcenter(p, h, d) : 0.f;
   if (p.n_which < 3) return;  // v: vorta_fp8_v_convert wrote (or will write) v8 and v_descale
   float mv = p.ws[2 * H + h * D + d];
   if (p.v_per_head) {
-    __shared__ float red[D];
     red[d] = mv;
     __syncthreads();
     for (int s = 64; s > 0; s >>= 1) {
@@ -273,7 +326,8 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
 
 extern "C" int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim) {
   if (heads <= 0 || head_dim != D) return VORTA_EINVAL;
-  return 2 * (2 * heads + heads * head_dim) + heads * head_dim + heads * MEAN_BLOCKS * (head_dim + 1);
+  return 2 * (2 * heads + heads * head_dim) + heads * head_dim + heads * MEAN_BLOCKS * (head_dim + 1) +
+         2 * heads * MEAN_BLOCKS * head_dim + heads * MEAN_BLOCKS;
 }
 
 extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_stream) {
@@ -313,10 +367,9 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   p.slot_count = a->slot_count > 0 ? a->slot_count : a->heads;
   hipStream_t st = (hipStream_t)hip_stream;
   const int H = a->heads, h0 = p.slot_first, hn = p.slot_count;
-  // abs-max slots of the heads this call converts: amax_q[h], amax_k[h], amax_v[h][:]
-  hipError_t e = hipMemsetAsync(a->ws + h0, 0, sizeof(float) * hn, st);
-  if (e == hipSuccess) e = hipMemsetAsync(a->ws + H + h0, 0, sizeof(float) * hn, st);
-  if (e == hipSuccess && n_which == 3) e = hipMemsetAsync(a->ws + 2 * H + (size_t)h0 * D, 0, sizeof(float) * hn * D, st);
+  // abs-max slots of v for the heads this call converts (q and k: written by the scales kernel from the sample)
+  hipError_t e = hipSuccess;
+  if (n_which == 3) e = hipMemsetAsync(a->ws + 2 * H + (size_t)h0 * D, 0, sizeof(float) * hn * D, st);
   if (e != hipSuccess) return vorta_set_hip_error(e);
   // enough workgroups to fill the chip several times over, few enough that the atomics stay cheap
   p.rows_per_block = 1024;
@@ -326,10 +379,10 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
     const int64_t n_seg = ((int64_t)a->n_tokens + p.seg_len - 1) / p.seg_len;
     const int64_t n_sg = (n_seg + H - 1) / H;  // segment groups: one segment per head slot each
     if (n_sg * hn * p.chunks_per_seg > 0x7fffffffll) return VORTA_EINVAL;
-    grid = dim3((unsigned)(n_sg * hn * p.chunks_per_seg), 1, (unsigned)n_which);
+    grid = dim3((unsigned)(n_sg * hn * p.chunks_per_seg), 1, 1);
   } else {
     p.chunks_per_seg = 1;
-    grid = dim3((unsigned)((a->n_tokens + p.rows_per_block - 1) / p.rows_per_block), (unsigned)H, (unsigned)n_which);
+    grid = dim3((unsigned)((a->n_tokens + p.rows_per_block - 1) / p.rows_per_block), (unsigned)H, 1);
   }
   // centre: ~MEAN_SAMPLES evenly spaced tokens of the head (an odd stride: one that divides the segment length would
   // sample the same offsets of every segment)
@@ -344,19 +397,20 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   p.mean_stride |= 1;
   p.mean_cand = (int)((head_tokens + p.mean_stride - 1) / p.mean_stride);
   const bool bf = a->dtype == VORTA_BF16;
-  if (p.center_k) {
-    if (bf) hipLaunchKernelGGL((fp8_kmean_kernel<__bf16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
-    else hipLaunchKernelGGL((fp8_kmean_kernel<_Float16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
+  if (bf) hipLaunchKernelGGL((fp8_sample_kernel<__bf16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
+  else hipLaunchKernelGGL((fp8_sample_kernel<_Float16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return vorta_set_hip_error(e);
+  if (n_which == 3) {
+    if (bf) hipLaunchKernelGGL((fp8_absmax_kernel<__bf16>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((fp8_absmax_kernel<_Float16>), grid, dim3(256), 0, st, p);
     e = hipGetLastError();
     if (e != hipSuccess) return vorta_set_hip_error(e);
   }
-  if (bf) hipLaunchKernelGGL((fp8_absmax_kernel<__bf16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((fp8_absmax_kernel<_Float16>), grid, dim3(256), 0, st, p);
-  e = hipGetLastError();
-  if (e != hipSuccess) return vorta_set_hip_error(e);
   hipLaunchKernelGGL(fp8_scales_kernel, dim3((unsigned)hn), dim3(128), 0, st, p);
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
+  grid.z = (unsigned)n_which;
   if (bf) hipLaunchKernelGGL((fp8_convert_kernel<__bf16>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((fp8_convert_kernel<_Float16>), grid, dim3(256), 0, st, p);
   e = hipGetLastError();
