@@ -314,6 +314,9 @@ def main():
                          "sequence through the zero-copy receive layout, the send-side staging passes and the un-permute "
                          "of the output included, the transfers themselves left out.  The step still covers the whole sequence, so "
                          "`value` is an upper bound of the P-GPU throughput; not a BASELINE line")
+    ap.add_argument("--placement", default=os.environ.get("VORTA_SP_PLACEMENT", "even"), choices=["even", "uneven"],
+                    help="N>1: heads per rank -- even: H/N on every rank (whole-head LPT under that constraint); uneven: the "
+                         "ranks' head counts follow the layer's routes (LPT on the expert costs alone)")
     ap.add_argument("--no-v-wire", action="store_true",
                     help="N>1 with --dtype fp8: exchange v in 16 bits and convert it on the receive side (A/B; default: v "
                          "is converted on the send side and crosses the links as e4m3)")
@@ -421,7 +424,8 @@ def main():
         from vorta_amd import ulysses
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
                                             concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
-                                            groups=args.sp_groups, loopback=bool(emu), fp8=fp8, v_wire=not args.no_v_wire)
+                                            groups=args.sp_groups, loopback=bool(emu), fp8=fp8, v_wire=not args.no_v_wire,
+                                            placement=args.placement)
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):
@@ -531,7 +535,9 @@ def main():
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
                    "parallelism": "single GPU" if P == 1 else (f"rank 0 of ulysses sp{P}, emulated on one GPU, no transfers"
                                                                if emu else f"ulysses sp{P} (RCCL all-to-all over xGMI)")
-                   + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else ""),
+                   + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else "")
+                   + (f", {args.placement} head placement (heaviest rank / mean cost, worst layer: "
+                      f"{max(sp.max_over_mean):.3f})" if P > 1 else ""),
                    "experts": {"fused": "one fused grid per layer", "serial": "one launch per expert",
                                "concurrent": "experts on side streams"}[args.experts],
                    **({"fp8": "e4m3 q,k,v and probabilities on the fp8 MFMA; conversion (per-head scales, key centring "

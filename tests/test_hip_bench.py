@@ -55,7 +55,8 @@ def test_bench_plain_command_launches_its_ranks_and_fp8_exchange_variants_agree(
     env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     lines = {}
     for name, extra in (("plain", ["--no-v-wire"]), ("vwire", []), ("groups", ["--sp-groups", "2"]),
-                        ("groups16", ["--sp-groups", "2", "--no-v-wire"])):
+                        ("groups16", ["--sp-groups", "2", "--no-v-wire"]),
+                        ("uneven", ["--placement", "uneven"]), ("uneven_groups", ["--placement", "uneven", "--sp-groups", "2"])):
         r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "tiny", "--dtype", "fp8", "--steps", "1",
                             "--warmup", "1", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, capture_output=True, text=True,
                            timeout=900)
@@ -66,7 +67,9 @@ def test_bench_plain_command_launches_its_ranks_and_fp8_exchange_variants_agree(
     assert j["n_gpus"] == 2 and pg["world_size"] == 2 and pg["backend"] == "gloo" and len(pg["ranks"]) == 2
     assert sorted(r["rank"] for r in pg["ranks"]) == [0, 1] and len({r["pid"] for r in pg["ranks"]}) == 2
     fps = {name: l["output_fingerprint"] for name, l in lines.items()}
+    # ... and so do ranks holding different numbers of heads (3 + 5 of the 8 heads, from the layers' routes)
     assert len(set(fps.values())) == 1 and fps["plain"] != 0, fps
+    assert "uneven head placement" in lines["uneven"]["config"]["parallelism"]
 
 
 def test_bench_emulated_rank_and_fp8_lines():

@@ -344,14 +344,26 @@ def _sp_worker(rank, world, port, ret):
     Sl = S // world
     shard = hidden[:, rank * Sl:(rank + 1) * Sl].contiguous()
     part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
-    ret[rank] = float((part.float() - full[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item())
+    err = float((part.float() - full[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item())
+    # ranks holding different numbers of heads (the placement follows the routes), one and two slot groups
+    from vorta_amd.attention import _sp
+    counts = set()
+    for groups in (1, 2):
+        _sp.SP_PLACEMENT, _sp.SP_GROUPS = "uneven", groups
+        _sp._LAYOUTS.clear()
+        part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+        err = max(err, float((part.float() - full[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item()))
+        counts |= {k[-1] for k in _sp._LAYOUTS if isinstance(k[-1], tuple)}
+    _sp.SP_PLACEMENT, _sp.SP_GROUPS = "even", 1
+    ret[rank] = err if any(len(set(c)) > 1 for c in counts) else -1.0  # (-1: the draw never gave unequal head counts)
     dist.barrier()
     SP_STATE.cleanup()
 
 
 def test_processor_under_sequence_parallel_rehearsal():
     """2 ranks sharing this GPU (gloo, host-staged messages): the SP branch of the processor returns exactly
-    the sequence shard of the single-process result."""
+    the sequence shard of the single-process result -- with H/P heads on every rank and with head counts that follow the
+    routes (`balanced_placement`), one and two slot groups."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -388,14 +400,16 @@ def _sp_worker_fp8(rank, world, port, ret):
     SP_STATE.setup_sp_group(world)
     rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
     nat = native[:, rank * Sl:(rank + 1) * Sl].float()
-    for groups, v_wire in ((1, True), (1, False), (2, True), (3, False)):
-        _sp.SP_GROUPS, _sp.SP_V_WIRE = groups, v_wire
+    for groups, v_wire, placement in ((1, True, "even"), (1, False, "even"), (2, True, "even"), (3, False, "even"),
+                                      (1, True, "uneven"), (2, False, "uneven")):
+        _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = groups, v_wire, placement
         _sp._LAYOUTS.clear()
         for center in (False, True):
             routed.FP8_CENTER_K = center
             part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
             ref = full[center][:, rank * Sl:(rank + 1) * Sl].float()
-            res[(groups, v_wire, center)] = (float((part.float() - ref).abs().max()), rel(ref, nat))
+            res[(groups, v_wire, placement, center)] = (float((part.float() - ref).abs().max()), rel(ref, nat))
+    _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = 1, True, "even"
     ret[rank] = res
     dist.barrier()
     SP_STATE.cleanup()
@@ -405,7 +419,8 @@ def test_processor_under_sequence_parallel_rehearsal_fp8():
     """The same with the e4m3 contractions.  Under SP the receive buffers are converted in the quantiser's segmented row
     layout with the per-head abs-max and the key centre (the mean of the same TOKENS) of the single-process call, so the
     result is bit-identical to it -- with the local heads converted in one go or slot group by slot group (2 + 1 and
-    1 + 1 + 1 of the 3 local heads), and with v converted on the send side and exchanged as e4m3 or exchanged in 16 bits."""
+    1 + 1 + 1 of the 3 local heads), with v converted on the send side and exchanged as e4m3 or exchanged in 16 bits, and
+    with the ranks holding equal or different numbers of heads."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -413,7 +428,7 @@ def test_processor_under_sequence_parallel_rehearsal_fp8():
     ret = mp.Manager().dict()
     mp.spawn(_sp_worker_fp8, args=(2, port, ret), nprocs=2, join=True)
     for r in (0, 1):
-        assert len(ret[r]) == 8
+        assert len(ret[r]) == 12
         for key, (d, one) in ret[r].items():
             assert d == 0.0 and 0.0 < one < 0.1, (key, dict(ret[r]))
 

@@ -152,6 +152,83 @@ def test_zero_copy_layout_round_trip(world):
             assert np.array_equal(hv[i][rm[:S]], ref[r][0, i])
 
 
+def _uneven_worker(rank, world, port, ret):
+    """ranks holding DIFFERENT numbers of heads (balanced_placement): every head's full sequence lands on its rank, the
+    identity attention travels back, one group and two slot groups, both transports"""
+    _init(rank, world, port)
+    import vorta_amd.ulysses.engine as E
+    from vorta_amd.ulysses import UlyssesLayout, balanced_placement, exchange_and_attend, slot_groups
+    P = world
+    H, S, T, D = 3 * world + 1, 24 * world, 5, 4
+    experts = ([0, 2, 2, 1, 2, 2, 1] * H)[:H]
+    cost = [7.0, 2.0, 1.0]
+    ok = True
+    hs = torch.arange(H).view(H, 1, 1)
+    dd = torch.arange(D).view(1, 1, D)
+    for groups in (1, 2):
+        order, counts = balanced_placement(experts, cost, P, groups)
+        ok = ok and sorted(order) == list(range(H)) and sum(counts) == H and min(counts) >= 1 and len(set(counts)) > 1
+        lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.float32, counts=counts)
+        Hl, Sl = lay.Hl, lay.Sl
+        ok = ok and Hl == counts[rank] and not lay.even
+        ss = (torch.arange(Sl) + rank * Sl).view(1, Sl, 1)
+        shards = [_tag(hs, ss, dd) + 1e7 * t for t in range(3)]
+        texts = [_tag(hs, torch.arange(T).view(1, T, 1) + 90000, dd) + 1e7 * t for t in range(3)]
+        rm = lay.row_map.long()
+        for transport in ("a2a", "p2p"):
+            E.TRANSPORT = transport
+            bufs = [lay.new_buffer().fill_(-1) for _ in range(4)]
+            sg = slot_groups(Hl, min(groups, min(counts)))
+            seen = []
+
+            def attend(g0, g1, gi):
+                seen.append((g0, g1))
+                for t in range(3):  # every local head slot holds its head's whole sequence + text, in token order
+                    hv = lay.head_view(bufs[t])
+                    for i in range(g0, g1):
+                        h = order[lay.starts[rank] + i]
+                        want = torch.cat([_tag(torch.tensor(float(h)), torch.arange(S).view(S, 1), dd[0]),
+                                          _tag(torch.tensor(float(h)), torch.arange(T).view(T, 1) + 90000, dd[0])]) + 1e7 * t
+                        assert torch.equal(hv[i][rm], want), (transport, groups, t, i)
+                lay.head_view(bufs[3])[g0:g1].copy_(lay.head_view(bufs[0])[g0:g1])
+
+            o, tx = torch.full((H, Sl, D), -2.0), torch.full((H, T, D), -2.0)
+            exchange_and_attend(lay, shards, bufs, order, texts, sg, attend, o, tx)
+            ok = ok and seen == sg and torch.equal(o, shards[0]) and torch.equal(tx, texts[0])
+        E.TRANSPORT = "a2a"
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_uneven_head_placement_round_trip(world):
+    ret = mp.Manager().dict()
+    mp.spawn(_uneven_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_balanced_placement_beats_equal_head_counts_on_skewed_mixes():
+    from vorta_amd.ulysses import balanced_head_order, balanced_placement
+    cost = [7.26, 1.82, 1.33]  # Hunyuan-129f: full / coreset / sliding-tile TFLOP per head
+    rng = np.random.default_rng(5)
+    for n0, n1, n2, P in ((4, 8, 12, 8), (8, 8, 8, 8), (3, 6, 15, 4), (14, 13, 13, 8)):
+        e = rng.permutation([0] * n0 + [1] * n1 + [2] * n2)
+        H = len(e)
+        order, counts = balanced_placement(e, cost, P)
+        assert sorted(order) == list(range(H)) and sum(counts) == H and min(counts) >= 1
+        st = np.cumsum([0] + counts)
+        uneven = max(sum(cost[e[h]] for h in order[st[j]:st[j + 1]]) for j in range(P))
+        o2 = balanced_head_order(e, cost, P)
+        even = max(sum(cost[e[h]] for h in o2[j * (H // P):(j + 1) * (H // P)]) for j in range(P))
+        assert uneven <= even + 1e-9
+        if (n0, n1, n2) == (4, 8, 12):  # 24 heads on 8 ranks, 4 full-attention heads: 1.33 of the mean with 3 heads each
+            mean = sum(cost[x] for x in e) / P
+            assert even / mean > 1.3 and uneven / mean < 1.05
+    order, counts = balanced_placement([0] * 8, cost, 8, groups=3)  # groups clamp to the smallest head count
+    assert counts == [1] * 8
+
+
 def test_balanced_head_order_with_slot_groups():
     from vorta_amd.ulysses import balanced_head_order, slot_groups
     rng = np.random.default_rng(3)

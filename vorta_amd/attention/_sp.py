@@ -13,7 +13,8 @@ import torch
 from .. import ops
 from ..routed import HeadRouting, geometry_for, routed_attention
 from ..ulysses import SP_STATE
-from ..ulysses.engine import UlyssesLayout, VWire, balanced_head_order, exchange_and_attend, slot_groups
+from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balanced_placement, exchange_and_attend,
+                              slot_groups)
 
 _LAYOUTS = {}
 _ROUTINGS = {}  # (local expert ids, device) -> HeadRouting: the device tables are built once per distinct local mix
@@ -21,6 +22,9 @@ SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
 # fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
 # 16-bit exchange with the receive-side conversion (A/B; same bytes in the operand buffers either way)
 SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
+# head placement: "even" = H/P heads on every rank; "uneven" = the ranks' head counts follow the layer's routes
+# (ulysses/engine.py balanced_placement: whole heads are a coarse unit when H/P is small and the mix is skewed)
+SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "even")
 
 
 class _SpBuffers:
@@ -40,12 +44,20 @@ class _SpBuffers:
         return self.f8, self.vwire
 
 
-def _layout(H, S, T, D, device, dtype) -> _SpBuffers:
-    key = (H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, str(device), dtype)
-    if key not in _LAYOUTS:
-        _LAYOUTS[key] = _SpBuffers(UlyssesLayout(H, S, T, D, SP_STATE.sp_size, SP_STATE.group_local_rank, device, dtype,
-                                                 SP_STATE.group))
-    return _LAYOUTS[key]
+def _layout(H, S, T, D, device, dtype, counts=None):
+    """(layout of this layer's head placement, receive buffers of this rank's head-slot count)"""
+    rank, P = SP_STATE.group_local_rank, SP_STATE.sp_size
+    counts = tuple(counts) if counts is not None else (H // P,) * P
+    lkey = (H, S, T, D, P, rank, str(device), dtype, counts)
+    if lkey not in _LAYOUTS:
+        if len(_LAYOUTS) > 512:
+            _LAYOUTS.clear()
+        _LAYOUTS[lkey] = UlyssesLayout(H, S, T, D, P, rank, device, dtype, SP_STATE.group, counts=counts)
+    lay = _LAYOUTS[lkey]
+    bkey = (H, S, T, D, P, rank, str(device), dtype, "buffers", lay.Hl)
+    if bkey not in _LAYOUTS:
+        _LAYOUTS[bkey] = _SpBuffers(lay)
+    return lay, _LAYOUTS[bkey]
 
 
 def _routing(local_experts: tuple, device) -> HeadRouting:
@@ -70,8 +82,6 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     P = SP_STATE.sp_size
     Sl = N - T
     S = Sl * P
-    sb = _layout(H, S, T, D, q.device, q.dtype)
-    lay, bufs = sb.lay, sb.bufs
     if routing_score is None:  # dense for every head
         experts = [0] * H
         te = T
@@ -90,21 +100,28 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     dense_only = lowres_group_info is None
     if dense_only:
         cost = [1.0, 1.0, 1.0]
-        geom = None
-    else:
-        geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
-                            lowres_group_info.reduction_rate, q.device, row_map=lay.row_map)
-        _, _, n_kv = geom.sta_tables(te)
-        cost = [float(S + te) ** 2, float(geom.S_low + te) ** 2, float(S) * n_kv]
+    else:  # expert costs from the geometry alone (the placement comes first: the layout follows from it)
+        gw = tuple(int(x) for x in lowres_group_info.window_size)
+        g = gw[0] * gw[1] * gw[2]
+        s_low = (S // g) * int(g * (1 - lowres_group_info.reduction_rate))
+        _, _, n_kv = ops.sta_table_sizes(latent_shape, tile_size, window_size, te)
+        cost = [float(S + te) ** 2, float(s_low + te) ** 2, float(S) * n_kv]
     # VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot
     # groups (as equal as Hl allows), so the exchange of one group overlaps the attention of another
-    groups = min(SP_GROUPS, lay.Hl)
-    order = balanced_head_order(experts, cost, P, groups)
+    if SP_PLACEMENT == "uneven" and H >= P:
+        order, counts = balanced_placement(experts, cost, P, SP_GROUPS)
+    else:
+        order, counts = balanced_head_order(experts, cost, P, min(SP_GROUPS, H // P)), [H // P] * P
+    lay, sb = _layout(H, S, T, D, q.device, q.dtype, counts)
+    bufs = sb.bufs
+    groups = min(SP_GROUPS, min(counts))
+    geom = None if dense_only else geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
+                                                lowres_group_info.reduction_rate, q.device, row_map=lay.row_map)
     shards = [x[0, :, :Sl] for x in (q, k, v)]
     texts = [x[0, :, Sl:] for x in (q, k, v)] if T else None
     qv, kv, vv, ov = (lay.head_view(b) for b in bufs)
     me = SP_STATE.group_local_rank
-    local = [experts[h] for h in order[me * lay.Hl:(me + 1) * lay.Hl]]
+    local = [experts[h] for h in order[lay.starts[me]:lay.starts[me + 1]]]
     rm = lay.row_map
 
     # the precision switch (set_attention_precision / VORTA_ATTENTION_PRECISION) is about the ROUTED operator; dense
@@ -112,6 +129,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     from .. import routed as _routed
     fp8 = _routed.DEFAULT_FP8 and not dense_only
     f8, vwire = sb.fp8() if fp8 else (None, None)
+    if vwire is not None:
+        vwire.lay = lay  # the layouts of one slot count share the buffers; the head offsets are this layer's
 
     def attend(g0, g1, gi):
         views = None

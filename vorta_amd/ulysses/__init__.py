@@ -2,9 +2,9 @@
 zero-copy engine).  Training-only helpers of the reference (the autograd `all_to_all`, `reduce_loss`,
 `TrainingLog`) are out of scope."""
 from .comm import all_gather, all_to_all_4D, broadcast_sp_group, dist_prefix, set_seed, shrink_dim
-from .engine import (UlyssesLayout, UlyssesRoutedAttention, balanced_head_order, exchange_and_attend, make_row_map,
-                     slot_groups)
+from .engine import (UlyssesLayout, UlyssesRoutedAttention, balanced_head_order, balanced_placement, exchange_and_attend,
+                     make_row_map, slot_groups)
 from .state import SP_STATE, SequenceParallelState
 
 __all__ = ["SP_STATE", "SequenceParallelState", "all_to_all_4D", "all_gather", "shrink_dim", "broadcast_sp_group",
-           "dist_prefix", "set_seed", "UlyssesLayout", "UlyssesRoutedAttention", "balanced_head_order", "make_row_map", "exchange_and_attend", "slot_groups"]
+           "dist_prefix", "set_seed", "UlyssesLayout", "UlyssesRoutedAttention", "balanced_head_order", "balanced_placement", "make_row_map", "exchange_and_attend", "slot_groups"]

@@ -74,6 +74,44 @@ def balanced_head_order(experts: Sequence[int], cost_of_expert: Sequence[float],
     return order
 
 
+def balanced_placement(experts: Sequence[int], cost_of_expert: Sequence[float], P: int, groups: int = 1,
+                       max_heads: Optional[int] = None):
+    """Like `balanced_head_order`, but ranks may hold different NUMBERS of heads: whole heads are a coarse unit when H/P is
+    small and the experts' costs differ by 4-5 x (Wan-14B at P = 8: five heads per rank, 14 full-attention heads -> the
+    heaviest rank carries 2 full + 3 sliding-tile heads, 1.04 of the mean; a trained router's mixes are less even than
+    that).  Greedy longest-processing-time with no equal-count constraint: every head goes to the least-loaded rank (at
+    most `max_heads` per rank, default 2 H/P; at least one head everywhere).  Returns (order, counts): rank j owns
+    order[sum(counts[:j]) : sum(counts[:j + 1])]; inside a rank as `balanced_head_order`.  Deterministic."""
+    H = len(experts)
+    assert H >= P, f"{H} heads cannot cover {P} ranks"
+    cap = max_heads if max_heads is not None else max(2, 2 * ((H + P - 1) // P))
+    assert cap * P >= H
+    load = [0.0] * P
+    bins: List[List[int]] = [[] for _ in range(P)]
+    for h in sorted(range(H), key=lambda i: (-cost_of_expert[int(experts[i])], i)):
+        # an empty rank first (every rank ends with a head), then the least loaded one with room
+        j = min((r for r in range(P) if len(bins[r]) < cap), key=lambda r: (len(bins[r]) > 0, load[r], r))
+        bins[j].append(h)
+        load[j] += cost_of_expert[int(experts[h])]
+    counts = [len(b) for b in bins]
+    n_groups = max(1, min(int(groups), min(counts)))
+    order: List[int] = []
+    for b in bins:
+        if n_groups == 1:
+            order += sorted(b)
+            continue
+        sizes = group_sizes(len(b), n_groups)
+        gl = [0.0] * n_groups
+        gb: List[List[int]] = [[] for _ in sizes]
+        for h in sorted(b, key=lambda i: (-cost_of_expert[int(experts[i])], i)):
+            g = min((r for r in range(n_groups) if len(gb[r]) < sizes[r]), key=lambda r: (gl[r] / sizes[r], r))
+            gb[g].append(h)
+            gl[g] += cost_of_expert[int(experts[h])]
+        for g in gb:
+            order += sorted(g)
+    return order, counts
+
+
 def slot_groups(Hl: int, groups: int) -> List[tuple]:
     out, g0 = [], 0
     for n in group_sizes(Hl, groups):
@@ -108,12 +146,12 @@ def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, g
         if side is None:
             lay._finish(handles[gi])
             attend(g0, g1, gi)
-            back.append(lay.gather_heads_start(bufs[3], state, (g0, g1)))
+            back.append(lay.gather_heads_start(bufs[3], state, (g0, g1), gi, len(groups)))
         else:
             with torch.cuda.stream(side[gi % len(side)]):
                 lay._finish(handles[gi])
                 attend(g0, g1, gi)
-                back.append(lay.gather_heads_start(bufs[3], state, (g0, g1)))
+                back.append(lay.gather_heads_start(bufs[3], state, (g0, g1), gi, len(groups)))
     if side is not None:  # join: everything below (and the caller) is ordered after every group
         for st in side[1:]:
             done = torch.cuda.Event()
@@ -152,7 +190,7 @@ class VWire:
 
     def descale(self, g0: int, g1: int) -> torch.Tensor:
         """v_descale rows of the local head slots [g0, g1)"""
-        b = self.lay.rank * self.lay.Hl
+        b = self.lay.starts[self.lay.rank]
         return self.descale_all[b + g0:b + g1]
 
 
@@ -168,17 +206,35 @@ def make_row_map(S: int, T: int, P: int, Hl: int, device) -> torch.Tensor:
 class UlyssesLayout:
     """Buffer geometry shared by Q, K, V and O of one layer."""
 
-    def __init__(self, H: int, S: int, T: int, D: int, P: int, rank: int, device, dtype, group=None):
-        if H % P or S % P:
-            raise ValueError(f"heads {H} and sequence {S} must be divisible by the sequence-parallel size {P}")
+    _ROW_MAPS: dict = {}
+
+    def __init__(self, H: int, S: int, T: int, D: int, P: int, rank: int, device, dtype, group=None,
+                 counts: Optional[Sequence[int]] = None):
+        """`counts` = heads per rank (default: H / P everywhere).  Rank j owns the heads order[starts[j]:starts[j + 1]] of
+        the head order given to the exchange; this rank's receive layout has Hl = counts[rank] head slots."""
+        if S % P:
+            raise ValueError(f"sequence {S} must be divisible by the sequence-parallel size {P}")
+        if counts is None:
+            if H % P:
+                raise ValueError(f"heads {H} and sequence {S} must be divisible by the sequence-parallel size {P}")
+            counts = [H // P] * P
+        counts = [int(c) for c in counts]
+        if len(counts) != P or sum(counts) != H or min(counts) < 1:
+            raise ValueError(f"head counts {counts} do not place {H} heads on {P} ranks (at least one each)")
         self.H, self.S, self.T, self.D, self.P, self.rank = H, S, T, D, P, rank
-        self.Hl, self.Sl = H // P, S // P
+        self.counts = counts
+        self.starts = [sum(counts[:j]) for j in range(P + 1)]
+        self.even = all(c == counts[0] for c in counts)
+        self.Hl, self.Sl = counts[rank], S // P
         if T > self.Sl:
             raise ValueError("text length must not exceed the per-rank sequence shard")
         self.rows_video = P * self.Hl * self.Sl
         self.rows_total = self.rows_video + self.Hl * self.Sl  # text region keeps the head stride Sl
         self.device, self.dtype, self.group = torch.device(device), dtype, group
-        self.row_map = make_row_map(S, T, P, self.Hl, device)
+        key = (S, T, P, self.Hl, str(self.device))  # one table per slot count (the geometry caches key on its address)
+        if key not in UlyssesLayout._ROW_MAPS:
+            UlyssesLayout._ROW_MAPS[key] = make_row_map(S, T, P, self.Hl, device)
+        self.row_map = UlyssesLayout._ROW_MAPS[key]
         # loopback: every pass of the exchange that runs on THIS rank's GPU (staging gathers, own-chunk copies, text
         # rows, the attention on the received layout, the un-permute) with the transfers themselves left out -- one
         # rank's compute at P > 1 on a single GPU (bench.py --emulate-rank); remote chunks keep what the buffers held
@@ -259,22 +315,27 @@ class UlyssesLayout:
     def _run(self, p2p):
         self._finish(self._start(p2p))
 
-    def _start_a2a(self, pairs):
+    def _start_a2a(self, pairs, in_rows: Optional[Sequence[int]] = None, out_rows: Optional[Sequence[int]] = None):
         """One `all_to_all_single` per (input, output) pair -- the collective the reference uses
-        (vorta/ulysses/utils.py:47,79) -- on (P*n, D) row blocks whose P equal chunks are contiguous on both sides
-        (chunk j of the input goes to rank j, chunk j of the output comes from rank j; the own chunk is copied by the
-        collective).  Asynchronous under RCCL; returns a handle for `_finish`."""
+        (vorta/ulysses/utils.py:47,79) -- on row blocks whose P chunks are contiguous on both sides (chunk j of the
+        input goes to rank j, chunk j of the output comes from rank j; the own chunk is copied by the collective).
+        `in_rows` / `out_rows`: rows per chunk when the ranks hold different numbers of heads (default: equal chunks).
+        Asynchronous under RCCL; returns a handle for `_finish`."""
+        me = self.rank
         if self.loopback:  # the own chunk is what the collective would have copied locally
-            n = pairs[0][0].shape[0] // self.P
             for i, o in pairs:
-                o[self.rank * n:(self.rank + 1) * n].copy_(i[self.rank * n:(self.rank + 1) * n])
+                ni = list(in_rows) if in_rows is not None else [i.shape[0] // self.P] * self.P
+                no = list(out_rows) if out_rows is not None else [o.shape[0] // self.P] * self.P
+                i0, o0 = sum(ni[:me]), sum(no[:me])
+                o[o0:o0 + no[me]].copy_(i[i0:i0 + ni[me]])
             return None
+        kw = {} if in_rows is None else dict(input_split_sizes=list(in_rows), output_split_sizes=list(out_rows))
         if not self._staged():
-            return ("works", [dist.all_to_all_single(o, i, group=self.group, async_op=True) for i, o in pairs])
+            return ("works", [dist.all_to_all_single(o, i, group=self.group, async_op=True, **kw) for i, o in pairs])
         for i, o in pairs:
             hi = i.detach().to("cpu")
             ho = torch.empty(o.shape, dtype=o.dtype)
-            dist.all_to_all_single(ho, hi, group=self.group)
+            dist.all_to_all_single(ho, hi, group=self.group, **kw)
             o.copy_(ho)
         return None
 
@@ -338,7 +399,12 @@ class UlyssesLayout:
         into destination head order (under the q/k transfers when they are one collective)."""
         Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
         blk = Hl * Sl
+        starts, counts = self.starts, self.counts
         groups = [(0, Hl)] if groups is None else [tuple(g) for g in groups]
+        if groups != slot_groups(Hl, len(groups)):
+            raise ValueError(f"slot groups {groups} are not slot_groups({Hl}, {len(groups)})")
+        if len(groups) > min(counts):
+            raise ValueError(f"{len(groups)} slot groups, but a rank holds only {min(counts)} heads")
         red = None
         v_shard = v_text = None
         if vwire is not None:
@@ -353,14 +419,14 @@ class UlyssesLayout:
         srcs = []
         staged = []
         for t, (x, buf) in enumerate(zip(shards, bufs)):
-            direct = x.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
+            direct = self.even and x.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
             if direct:
                 src = x
                 first = [self._run_of(head_order, j * Hl, Hl) for j in range(P)]
             else:
                 src = self._stage(("s", t))
                 staged.append((x, src))
-                first = [j * Hl for j in range(P)]
+                first = list(starts[:P])
             srcs.append((src, first, buf))
         if staged:  # one gather pass orders the heads of every staged tensor
             if staged[0][0].is_cuda and HIP_STAGING:
@@ -369,7 +435,7 @@ class UlyssesLayout:
                 idx = torch.as_tensor(list(head_order), device=staged[0][0].device)
                 for x, y in staged:
                     torch.index_select(x, 0, idx, out=y)
-        mine = head_order[me * Hl:(me + 1) * Hl]
+        mine = head_order[starts[me]:starts[me + 1]]
         if texts is not None and self.T:  # texts[t]: (H, T, D) replicated; its rows follow each local head slot's video
             if texts[0].is_cuda and HIP_STAGING:
                 dsts = [buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1)) for buf in bufs]
@@ -387,15 +453,17 @@ class UlyssesLayout:
             if v_text is not None:
                 dst = vwire.buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1))
                 ops.fp8_v_convert(v_text, vwire.amax, dst, src_map=self._head_map(mine))
-            return (vwire.stage, [j * Hl for j in range(P)], vwire.buf)
+            return (vwire.stage, list(starts[:P]), vwire.buf)
 
-        in_rank_order = all(first == [j * Hl for j in range(P)] for _, first, _ in srcs)
+        in_rank_order = all(first == list(starts[:P]) for _, first, _ in srcs)
         if TRANSPORT == "a2a" and groups == [(0, Hl)] and in_rank_order and P > 1:
-            # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides
-            h = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs])
+            # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides (rows per
+            # chunk follow the ranks' head counts on the send side; every peer sends this rank's Hl heads)
+            splits = (None, None) if self.even else ([c * Sl for c in counts], [blk] * P)
+            h = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs], *splits)
             if vwire is not None:  # converted while q and k are on the links
                 src, _, buf = convert_v()
-                hv = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk])])
+                hv = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk])], *splits)
                 h = None if h is None and hv is None else ("works", (h[1] if h else []) + (hv[1] if hv else []))
             return [h]
         if vwire is not None:
@@ -403,12 +471,13 @@ class UlyssesLayout:
         for src, first, buf in srcs:
             buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D).copy_(src[first[me]:first[me] + Hl])
         handles = []
-        for g0, g1 in groups:
+        for gi, (g0, g1) in enumerate(groups):
             p2p = []
             for src, first, buf in srcs:
                 for j in range(P):
-                    if j != me:
-                        p2p.append(("send", src[first[j] + g0:first[j] + g1], j))
+                    if j != me:  # rank j's slots of ITS group gi
+                        p0, p1 = slot_groups(counts[j], len(groups))[gi]
+                        p2p.append(("send", src[first[j] + p0:first[j] + p1], j))
                 for j in range(P):
                     if j != me:
                         p2p.append(("recv", buf[j * blk + g0 * Sl:j * blk + g1 * Sl], j))
@@ -427,27 +496,31 @@ class UlyssesLayout:
 
     def gather_heads_begin(self, out_shard: torch.Tensor, head_order: Sequence[int]):
         Hl, P = self.Hl, self.P
-        direct = out_shard.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
+        direct = self.even and out_shard.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
         dst = out_shard if direct else self._stage(("g", 0))
-        first = [self._run_of(head_order, j * Hl, Hl) if direct else j * Hl for j in range(P)]
+        first = [self._run_of(head_order, j * Hl, Hl) if direct else self.starts[j] for j in range(P)]
         return dict(out_shard=out_shard, order=list(head_order), direct=direct, dst=dst, first=first)
 
-    def gather_heads_start(self, buf: torch.Tensor, state, slots: Optional[Sequence[int]] = None):
-        """send the attention output of local head slots [slot0, slot1) (default: all) back; returns the handle"""
+    def gather_heads_start(self, buf: torch.Tensor, state, slots: Optional[Sequence[int]] = None, gi: int = 0,
+                           n_groups: int = 1):
+        """send the attention output of local head slots [slot0, slot1) (default: all) -- slot group `gi` of `n_groups`
+        -- back; returns the handle"""
         Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
         blk = Hl * Sl
         g0, g1 = (0, Hl) if slots is None else slots
         dst, first = state["dst"], state["first"]
-        if TRANSPORT == "a2a" and (g0, g1) == (0, Hl) and first == [j * Hl for j in range(P)] and P > 1:
-            return self._start_a2a([(buf[:P * blk], dst.view(self.H * Sl, self.D))])
+        if TRANSPORT == "a2a" and (g0, g1) == (0, Hl) and first == list(self.starts[:P]) and P > 1:
+            splits = (None, None) if self.even else ([blk] * P, [c * Sl for c in self.counts])
+            return self._start_a2a([(buf[:P * blk], dst.view(self.H * Sl, self.D))], *splits)
         dst[first[me] + g0:first[me] + g1].copy_(buf[me * blk + g0 * Sl:me * blk + g1 * Sl].view(g1 - g0, Sl, self.D))
         p2p = []
         for j in range(P):
             if j != me:
                 p2p.append(("send", buf[j * blk + g0 * Sl:j * blk + g1 * Sl], j))
         for j in range(P):
-            if j != me:
-                p2p.append(("recv", dst[first[j] + g0:first[j] + g1], j))
+            if j != me:  # rank j returns ITS slots of its group gi
+                p0, p1 = (0, self.counts[j]) if slots is None else slot_groups(self.counts[j], n_groups)[gi]
+                p2p.append(("recv", dst[first[j] + p0:first[j] + p1], j))
         return self._start(p2p)
 
     def gather_heads_end(self, buf: torch.Tensor, state, out_text: Optional[torch.Tensor] = None):
@@ -460,7 +533,11 @@ class UlyssesLayout:
             else:
                 out_shard.index_copy_(0, torch.as_tensor(head_order, device=out_shard.device), state["dst"])
         if out_text is not None and self.T:
-            local = torch.stack([buf[self.rows_video + i * Sl: self.rows_video + i * Sl + self.T] for i in range(Hl)])
+            cap = max(self.counts)  # equal message sizes for the collective: padded to the largest head count
+            local = torch.empty((cap, self.T, self.D), dtype=buf.dtype, device=buf.device)
+            local[:Hl].copy_(buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1)))
+            if cap > Hl:
+                local[Hl:].zero_()
             parts = [torch.empty_like(local) for _ in range(self.P)]
             if self.loopback:
                 parts = [local] * self.P
@@ -472,75 +549,111 @@ class UlyssesLayout:
                 dist.all_gather(parts, local, group=self.group)
             else:
                 parts = [local]
-            allh = torch.cat(parts, dim=0)  # (H, T, D) in head_order
+            if self.loopback:  # every peer's heads stand in with this rank's rows (timing only)
+                allh = torch.cat([local[torch.arange(c, device=local.device) % Hl] for c in self.counts], dim=0)
+            else:
+                allh = torch.cat([parts[j][:self.counts[j]] for j in range(self.P)], dim=0)  # (H, T, D) in head_order
             if out_text.is_cuda and HIP_STAGING:
                 ops.permute_heads([allh], [out_text], dst_map=self._head_map(head_order))
             else:
                 out_text[torch.as_tensor(list(head_order), device=out_text.device)] = allh
 
 
+class _RankState:
+    """everything of the receive side that depends on how many head slots this rank holds: buffers, e4m3 operands, the
+    routed geometry composed with the layout's row map"""
+
+    def __init__(self, lay: UlyssesLayout, cfg: dict, te: int, fp8: bool, v_wire: bool, loopback: bool):
+        from ..routed import RoutedGeometry
+        self.bufs = [lay.new_buffer() for _ in range(4)]  # q, k, v, o
+        if loopback:  # the chunks no peer will fill: finite values of the same distribution
+            for b in self.bufs[:3]:
+                b.normal_()
+        self.f8 = self.vwire = None
+        if fp8:
+            self.f8 = lay.fp8_operands()
+            if v_wire:  # v travels as e4m3 straight into the operand buffer
+                self.vwire = VWire(lay, self.f8.v[0])
+                if loopback:
+                    self.f8.v.random_(0, 120)  # finite e4m3 bytes in the chunks no peer fills
+        self.geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], lay.device,
+                                   row_map=lay.row_map)
+        if te or cfg["model"] == "wan":
+            self.geom.sta_tables(te)
+
+
 class UlyssesRoutedAttention:
     """bench.py's N>1 step: synthetic sequence shards -> scatter_heads -> routed attention on the local
-    heads (zero-copy layout) -> gather_heads.  Also the template for the attention processors under SP."""
+    heads (zero-copy layout) -> gather_heads.  Also the template for the attention processors under SP.
+    placement = "even": H/P heads on every rank (`balanced_head_order`); "uneven": `balanced_placement` -- the ranks'
+    head counts follow the layer's routes, one layout (and one set of receive buffers) per distinct count."""
 
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
                  rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
                  sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False, fp8: bool = False,
-                 v_wire: bool = True):
-        from ..routed import HeadRouting, RoutedGeometry
-        self.fp8, self.f8, self.vwire = fp8, None, None
+                 v_wire: bool = True, placement: str = "even"):
+        from ..routed import HeadRouting
+        if placement not in ("even", "uneven"):
+            raise ValueError("placement is 'even' or 'uneven'")
+        self.fp8 = fp8
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
         self.cfg, self.P, self.rank = cfg, P, rank
         self.concurrent, self.fused, self.sliding_block_rows = concurrent, fused, sliding_block_rows
         self.te = cfg["text_valid"]
-        self.lay = UlyssesLayout(H, S, T, 128, P, rank, device, dtype, group)
-        self.lay.loopback = loopback
-        self.geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"],
-                                   torch.device(device), row_map=self.lay.row_map)
         costs = [cost_of_expert["full"], cost_of_expert["lowres"], cost_of_expert["sliding"]]
-        self.orders, self.routes = [], []
-        self.groups = slot_groups(self.lay.Hl, groups)  # > 1: exchange of one slot group overlaps another's attention
+        self.orders, self.routes, self.lays, self.groups = [], [], [], []
+        layouts, self.states = {}, {}
+        self.max_over_mean = []  # per layer: heaviest rank's cost / mean cost (1.0 = perfectly balanced)
         for e in layer_experts:
-            order = balanced_head_order(e, costs, P, groups)
+            if placement == "even":
+                order, counts = balanced_head_order(e, costs, P, groups), [H // P] * P
+            else:
+                order, counts = balanced_placement(e, costs, P, groups)
+            key = tuple(counts)
+            if key not in layouts:
+                lay = UlyssesLayout(H, S, T, 128, P, rank, device, dtype, group, counts=counts)
+                lay.loopback = loopback
+                layouts[key] = lay
+                if lay.Hl not in self.states:
+                    self.states[lay.Hl] = _RankState(lay, cfg, self.te, fp8, v_wire, loopback)
+            lay = layouts[key]
+            sg = slot_groups(lay.Hl, min(groups, min(counts)))
+            local = [int(e[h]) for h in order[lay.starts[rank]:lay.starts[rank + 1]]]
             self.orders.append(order)
-            local = [int(e[h]) for h in order[rank * self.lay.Hl:(rank + 1) * self.lay.Hl]]
-            self.routes.append([HeadRouting.from_expert_ids(local[g0:g1], device) for g0, g1 in self.groups])
+            self.lays.append(lay)
+            self.groups.append(sg)
+            self.routes.append([HeadRouting.from_expert_ids(local[g0:g1], device) for g0, g1 in sg])
+            loads = [sum(costs[int(e[h])] for h in order[lay.starts[j]:lay.starts[j + 1]]) for j in range(P)]
+            self.max_over_mean.append(max(loads) * P / sum(loads))
+        self.Sl = S // P
         self.sets = []
         for i in range(n_sets):
             gen = torch.Generator(device=device).manual_seed(1234 + 97 * i + rank)
-            shards = [torch.randn((H, self.lay.Sl, 128), generator=gen, device=device, dtype=dtype) for _ in range(3)]
+            shards = [torch.randn((H, self.Sl, 128), generator=gen, device=device, dtype=dtype) for _ in range(3)]
             tg = torch.Generator(device=device).manual_seed(4321 + i)  # text is replicated: same on every rank
             texts = [torch.randn((H, T, 128), generator=tg, device=device, dtype=dtype) for _ in range(3)] if T else None
             self.sets.append((shards, texts))
-        self.bufs = [self.lay.new_buffer() for _ in range(4)]  # q, k, v, o
-        if loopback:  # the chunks no peer will fill: finite values of the same distribution
-            for b in self.bufs[:3]:
-                b.normal_()
-        if fp8:
-            self.f8 = self.lay.fp8_operands()
-            if v_wire:  # v travels as e4m3 straight into the operand buffer
-                self.vwire = VWire(self.lay, self.f8.v[0])
-                if loopback:
-                    self.f8.v.random_(0, 120)  # finite e4m3 bytes in the chunks no peer fills
-        self.out_shard = torch.empty((H, self.lay.Sl, 128), dtype=dtype, device=device)
+        self.out_shard = torch.empty((H, self.Sl, 128), dtype=dtype, device=device)
         self.out_text = torch.empty((H, T, 128), dtype=dtype, device=device) if T else None
-        if self.te or cfg["model"] == "wan":
-            self.geom.sta_tables(self.te)
 
     def layer(self, l: int):
         from ..routed import routed_attention
         shards, texts = self.sets[l % len(self.sets)]
-        q, k, v, o = (self.lay.head_view(b) for b in self.bufs)
+        lay = self.lays[l]
+        st = self.states[lay.Hl]
+        q, k, v, o = (lay.head_view(b) for b in st.bufs)
+        if st.vwire is not None:
+            st.vwire.lay = lay  # the layouts of one slot count share the state; the head offsets are the layer's
 
         def attend(g0, g1, gi):
             views = None
             if self.fp8:  # the slot group that has landed is converted while the next one is in flight
-                q8, k8, v8, vd, self.f8 = self.lay.fp8_views(self.bufs, out=self.f8, slots=(g0, g1), vwire=self.vwire)
+                q8, k8, v8, vd, st.f8 = lay.fp8_views(st.bufs, out=st.f8, slots=(g0, g1), vwire=st.vwire)
                 views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
-            routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], self.geom, model=self.cfg["model"],
+            routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], st.geom, model=self.cfg["model"],
                              text_len=self.cfg["text"], text_valid=self.te, out=o[g0:g1], concurrent=self.concurrent,
                              fused=self.fused, sliding_block_rows=self.sliding_block_rows, fp8=False, fp8_views=views)
 
-        exchange_and_attend(self.lay, shards, self.bufs, self.orders[l], texts, self.groups, attend, self.out_shard,
-                            self.out_text, vwire=self.vwire)
+        exchange_and_attend(lay, shards, st.bufs, self.orders[l], texts, self.groups[l], attend, self.out_shard,
+                            self.out_text, vwire=st.vwire)
