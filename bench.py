@@ -310,11 +310,12 @@ def main():
                     help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
                          "overlaps the attention of another (1 = exchange, then attend; the measured default)")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
-                    help="on ONE GPU: the work rank 0 of a P-way Ulysses run does per step -- its H/P heads over the whole "
-                         "sequence through the zero-copy receive layout, the send-side staging passes and the un-permute "
-                         "of the output included, the transfers themselves left out.  The step still covers the whole sequence, so "
-                         "`value` is an upper bound of the P-GPU throughput; not a BASELINE line")
-    ap.add_argument("--placement", default=os.environ.get("VORTA_SP_PLACEMENT", "even"), choices=["even", "uneven"],
+                    help="on ONE GPU: the compute side of a P-way Ulysses step -- every layer as the rank that carries the "
+                         "largest expert cost in THAT layer (a P-GPU step waits for its slowest rank layer by layer): its heads "
+                         "over the whole sequence through the zero-copy receive layout, the send-side staging passes and the "
+                         "un-permute of the output included, the transfers themselves left out.  `value` is an upper bound of "
+                         "the P-GPU throughput; not a BASELINE line")
+    ap.add_argument("--placement", default=os.environ.get("VORTA_SP_PLACEMENT", "uneven"), choices=["even", "uneven"],
                     help="N>1: heads per rank -- even: H/N on every rank (whole-head LPT under that constraint); uneven: the "
                          "ranks' head counts follow the layer's routes (LPT on the expert costs alone)")
     ap.add_argument("--no-v-wire", action="store_true",
@@ -425,7 +426,7 @@ def main():
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
                                             concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
                                             groups=args.sp_groups, loopback=bool(emu), fp8=fp8, v_wire=not args.no_v_wire,
-                                            placement=args.placement)
+                                            placement=args.placement, heaviest_rank=bool(emu))
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):
@@ -521,7 +522,7 @@ def main():
         "metric": "video_tokens_per_sec (routed-attention denoising step, HunyuanVideo 720p 129f)"
         if args.config == "hunyuan-129f" else f"video_tokens_per_sec (routed-attention denoising step, {args.config})",
         "value": round(tokens / (ms_per_step * 1e-3), 1), "unit": "video_tokens/s",
-        **({"emulated_rank_of": emu, "note": "one rank's compute of a %d-GPU Ulysses step on one GPU (no transfers): an "
+        **({"emulated_rank_of": emu, "note": "the heaviest rank's compute (layer by layer) of a %d-GPU Ulysses step on one GPU (no transfers): an "
             "upper bound of the %d-GPU value, not a measurement of it" % (emu, emu)} if emu else {}),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
@@ -533,7 +534,7 @@ def main():
         "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
-                   "parallelism": "single GPU" if P == 1 else (f"rank 0 of ulysses sp{P}, emulated on one GPU, no transfers"
+                   "parallelism": "single GPU" if P == 1 else (f"heaviest rank (layer by layer) of ulysses sp{P}, emulated on one GPU, no transfers"
                                                                if emu else f"ulysses sp{P} (RCCL all-to-all over xGMI)")
                    + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else "")
                    + (f", {args.placement} head placement (heaviest rank / mean cost, worst layer: "

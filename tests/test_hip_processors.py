@@ -340,6 +340,12 @@ def _sp_worker(rank, world, port, ret):
     score = torch.tensor(g["routing_score"]).to(dev())
     proc = WanAttnProcessorTripleEval(check_input=True)
     full = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    # a skewed route (one full-attention head, five coreset heads): the placement that follows the routes gives the ranks
+    # 2 and 4 heads
+    score2 = torch.full_like(score, 0.1)
+    for h, e in enumerate([0, 1, 1, 1, 1, 1]):
+        score2[0, h, e] = 0.8
+    full2 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
     SP_STATE.setup_sp_group(world)
     Sl = S // world
     shard = hidden[:, rank * Sl:(rank + 1) * Sl].contiguous()
@@ -348,14 +354,15 @@ def _sp_worker(rank, world, port, ret):
     # ranks holding different numbers of heads (the placement follows the routes), one and two slot groups
     from vorta_amd.attention import _sp
     counts = set()
-    for groups in (1, 2):
-        _sp.SP_PLACEMENT, _sp.SP_GROUPS = "uneven", groups
-        _sp._LAYOUTS.clear()
-        part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
-        err = max(err, float((part.float() - full[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item()))
-        counts |= {k[-1] for k in _sp._LAYOUTS if isinstance(k[-1], tuple)}
-    _sp.SP_PLACEMENT, _sp.SP_GROUPS = "even", 1
-    ret[rank] = err if any(len(set(c)) > 1 for c in counts) else -1.0  # (-1: the draw never gave unequal head counts)
+    for sc, ref in ((score, full), (score2, full2)):
+        for groups in (1, 2):
+            _sp.SP_PLACEMENT, _sp.SP_GROUPS = "uneven", groups
+            _sp._LAYOUTS.clear()
+            part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
+            err = max(err, float((part.float() - ref[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item()))
+            counts |= {k[-1] for k in _sp._LAYOUTS if isinstance(k[-1], tuple)}
+    _sp.SP_PLACEMENT, _sp.SP_GROUPS = "uneven", 1
+    ret[rank] = err if (2, 4) in counts else -1.0  # (-1: the skewed route did not give unequal head counts)
     dist.barrier()
     SP_STATE.cleanup()
 
@@ -389,27 +396,35 @@ def _sp_worker_fp8(rank, world, port, ret):
     score = torch.tensor(g["routing_score"]).to(dev())
     proc = WanAttnProcessorTripleEval(check_input=True)
     native = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
-    vorta_amd.set_attention_precision("fp8")
     from vorta_amd.attention import _sp
     res, full = {}, {}
     Sl = S // world
     shard = hidden[:, rank * Sl:(rank + 1) * Sl].contiguous()
+    score2 = torch.full_like(score, 0.1)  # a skewed route: the placement that follows it gives the ranks 2 and 4 heads
+    for h, e in enumerate([0, 1, 1, 1, 1, 1]):
+        score2[0, h, e] = 0.8
+    native2 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
+    vorta_amd.set_attention_precision("fp8")
+    full2 = {}
     for center in (False, True):
         routed.FP8_CENTER_K = center
         full[center] = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+        full2[center] = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
     SP_STATE.setup_sp_group(world)
     rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
     nat = native[:, rank * Sl:(rank + 1) * Sl].float()
+    nat2 = native2[:, rank * Sl:(rank + 1) * Sl].float()
     for groups, v_wire, placement in ((1, True, "even"), (1, False, "even"), (2, True, "even"), (3, False, "even"),
                                       (1, True, "uneven"), (2, False, "uneven")):
         _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = groups, v_wire, placement
         _sp._LAYOUTS.clear()
         for center in (False, True):
             routed.FP8_CENTER_K = center
-            part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
-            ref = full[center][:, rank * Sl:(rank + 1) * Sl].float()
-            res[(groups, v_wire, placement, center)] = (float((part.float() - ref).abs().max()), rel(ref, nat))
-    _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = 1, True, "even"
+            sc, fl, nt = (score2, full2, nat2) if placement == "uneven" else (score, full, nat)
+            part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
+            ref = fl[center][:, rank * Sl:(rank + 1) * Sl].float()
+            res[(groups, v_wire, placement, center)] = (float((part.float() - ref).abs().max()), rel(ref, nt))
+    _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = 1, True, "uneven"
     ret[rank] = res
     dist.barrier()
     SP_STATE.cleanup()

@@ -22,9 +22,11 @@ SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
 # fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
 # 16-bit exchange with the receive-side conversion (A/B; same bytes in the operand buffers either way)
 SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
-# head placement: "even" = H/P heads on every rank; "uneven" = the ranks' head counts follow the layer's routes
-# (ulysses/engine.py balanced_placement: whole heads are a coarse unit when H/P is small and the mix is skewed)
-SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "even")
+# head placement: "uneven" (default) = the ranks' head counts follow the layer's routes (ulysses/engine.py
+# balanced_placement: whole heads are a coarse unit when H/P is small and the mix is skewed -- 24 heads with 4 full-attention
+# ones on 8 ranks: heaviest rank 1.33 of the mean cost with 3 heads each, 1.02 with 1 + ... + 5; identical to "even" when
+# the routes are balanced); "even" = H/P heads on every rank (A/B)
+SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "uneven")
 
 
 class _SpBuffers:

@@ -591,10 +591,14 @@ class UlyssesRoutedAttention:
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
                  rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
                  sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False, fp8: bool = False,
-                 v_wire: bool = True, placement: str = "even"):
+                 v_wire: bool = True, placement: str = "even", heaviest_rank: bool = False):
+        """heaviest_rank (with loopback): every layer is run as the rank that carries the largest cost in THAT layer -- a
+        P-GPU step waits for its slowest rank layer by layer, so this (not a fixed rank) is the compute side of it."""
         from ..routed import HeadRouting
         if placement not in ("even", "uneven"):
             raise ValueError("placement is 'even' or 'uneven'")
+        if heaviest_rank and not loopback:
+            raise ValueError("heaviest_rank is an emulation mode (loopback)")
         self.fp8 = fp8
         H, T = cfg["heads"], cfg["text"]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
@@ -610,22 +614,24 @@ class UlyssesRoutedAttention:
                 order, counts = balanced_head_order(e, costs, P, groups), [H // P] * P
             else:
                 order, counts = balanced_placement(e, costs, P, groups)
-            key = tuple(counts)
+            starts = [sum(counts[:j]) for j in range(P + 1)]
+            loads = [sum(costs[int(e[h])] for h in order[starts[j]:starts[j + 1]]) for j in range(P)]
+            self.max_over_mean.append(max(loads) * P / sum(loads))
+            r = max(range(P), key=lambda j: (loads[j], -j)) if heaviest_rank else rank
+            key = (tuple(counts), r)
             if key not in layouts:
-                lay = UlyssesLayout(H, S, T, 128, P, rank, device, dtype, group, counts=counts)
+                lay = UlyssesLayout(H, S, T, 128, P, r, device, dtype, group, counts=counts)
                 lay.loopback = loopback
                 layouts[key] = lay
                 if lay.Hl not in self.states:
                     self.states[lay.Hl] = _RankState(lay, cfg, self.te, fp8, v_wire, loopback)
             lay = layouts[key]
             sg = slot_groups(lay.Hl, min(groups, min(counts)))
-            local = [int(e[h]) for h in order[lay.starts[rank]:lay.starts[rank + 1]]]
+            local = [int(e[h]) for h in order[lay.starts[r]:lay.starts[r + 1]]]
             self.orders.append(order)
             self.lays.append(lay)
             self.groups.append(sg)
             self.routes.append([HeadRouting.from_expert_ids(local[g0:g1], device) for g0, g1 in sg])
-            loads = [sum(costs[int(e[h])] for h in order[lay.starts[j]:lay.starts[j + 1]]) for j in range(P)]
-            self.max_over_mean.append(max(loads) * P / sum(loads))
         self.Sl = S // P
         self.sets = []
         for i in range(n_sets):
