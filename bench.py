@@ -302,9 +302,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="hunyuan-129f", choices=sorted(CONFIGS))
     ap.add_argument("--mix", default="uniform", choices=sorted(MIXES))
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp8"],
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp8", "fp8pv"],
                     help="fp8: bf16 inputs, converted to e4m3 inside the timed step (vorta_fp8_quantize_qkv), both "
-                         "contractions on the fp8 MFMA, bf16 output")
+                         "contractions on the fp8 MFMA, bf16 output; fp8pv: scores in bf16, P V in e4m3 (only v is converted, "
+                         "inside the step)")
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
     ap.add_argument("--sp-groups", type=int, default=int(os.environ.get("VORTA_SP_GROUPS", "1")),
                     help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
@@ -376,8 +377,10 @@ def main():
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
 
     dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16
-    fp8 = cfg["dtype"] == "fp8"
-    peak = PEAK_MFMA_FP8_TFLOPS if fp8 else PEAK_MFMA_TFLOPS
+    fp8 = True if cfg["dtype"] == "fp8" else ("fp8pv" if cfg["dtype"] == "fp8pv" else False)
+    # mixed precision: half of a layer's FLOPs run at the 16-bit rate, half at the e4m3 rate: harmonic mean of the peaks
+    peak = PEAK_MFMA_FP8_TFLOPS if fp8 is True else (2.0 / (1.0 / PEAK_MFMA_TFLOPS + 1.0 / PEAK_MFMA_FP8_TFLOPS)
+                                                     if fp8 == "fp8pv" else PEAK_MFMA_TFLOPS)
     H, L, T, te = cfg["heads"], cfg["layers"], cfg["text"], cfg["text_valid"]
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
@@ -410,7 +413,8 @@ def main():
             sets.append(tuple(torch.randn((1, H, S + T, 128), generator=gen, device=dev, dtype=dt) for _ in range(3)))
         out = torch.empty_like(sets[0][0])
         # e4m3 operand buffers reused by every layer (the conversion itself runs per layer, inside the step)
-        f8buf = ops.fp8_quantize_qkv(*(x[0] for x in sets[0])) if fp8 else None
+        f8buf = (ops.fp8_quantize_qkv(*(x[0] for x in sets[0])) if fp8 is True else
+                 ops.fp8_quantize_v(sets[0][2][0]) if fp8 == "fp8pv" else None)
         if te:
             geom.sta_tables(te)  # built once per prompt, outside the step (pipeline_hunyuan.py:378-392)
 
@@ -543,7 +547,10 @@ def main():
                                "concurrent": "experts on side streams"}[args.experts],
                    **({"fp8": "e4m3 q,k,v and probabilities on the fp8 MFMA; conversion (per-head scales, key centring "
                               + ("on" if __import__("vorta_amd.routed", fromlist=["x"]).FP8_CENTER_K else "off")
-                              + ") inside the timed step; bf16 in / out"} if fp8 else {}),
+                              + ") inside the timed step; bf16 in / out"} if fp8 is True else
+                      {"fp8pv": "scores on the bf16 MFMA, probabilities and v in e4m3 on the fp8 MFMA; v converted inside the "
+                                "timed step; bf16 in / out; roofline.peak = harmonic mean of the two MFMA peaks (3 333)"}
+                      if fp8 == "fp8pv" else {}),
                    **({"call_path": proc_info, "ms_per_layer": round(ms_per_step / (L * cfg["fwd_per_step"]), 3)}
                       if proc_info is not None else {}),
                    "step_algorithmic_pflop": round(step_flops / 1e15, 3),

@@ -72,6 +72,28 @@ def test_bench_plain_command_launches_its_ranks_and_fp8_exchange_variants_agree(
     assert "uneven head placement" in lines["uneven"]["config"]["parallelism"]
 
 
+def test_bench_three_rank_rehearsal_heads_not_divisible():
+    """3 ranks sharing the GPU (gloo, host-staged): 8 heads do not divide by 3 -- the reference's reshard and the equal-count
+    placement both refuse that -- but head counts that follow the routes place them (3 + 3 + 2 and the like).  One collective
+    per tensor with per-rank split sizes and grouped send / recv give the same layer, 16-bit and e4m3."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "bench.py", "--gpus", "3", "--config", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    for dtype in ("bf16", "fp8"):
+        fps = {}
+        for transport in ("a2a", "p2p"):
+            r = subprocess.run(base + ["--dtype", dtype], cwd=ROOT, env=dict(env, VORTA_SP_TRANSPORT=transport),
+                               capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, (dtype, transport, r.stdout[-1500:], r.stderr[-3000:])
+            j = _line(r.stdout)
+            assert j["n_gpus"] == 3 and j["process_group"]["world_size"] == 3 and "uneven" in j["config"]["parallelism"]
+            assert j["switches"]["env"].get("VORTA_SP_TRANSPORT") == transport
+            fps[transport] = j["output_fingerprint"]
+        assert fps["a2a"] == fps["p2p"] != 0, (dtype, fps)
+    r = subprocess.run(base + ["--placement", "even"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0  # H % P != 0: the equal-count placement has no answer
+
+
 def test_bench_emulated_rank_and_fp8_lines():
     """--emulate-rank P: one rank's share of a P-way Ulysses step on one GPU (loopback layout, no transfers);
     --dtype fp8: the e4m3 path (quantiser inside the step)."""

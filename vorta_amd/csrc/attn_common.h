@@ -73,8 +73,12 @@ struct MultiParams {
   int n;
 };
 
-// attn_fwd.hip: argument validation + launch geometry (in_esize = bytes per q/k/v element)
-int fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize);
+// attn_fwd.hip: argument validation + launch geometry (in_esize = bytes per q/k element, v_esize per v element: 0 = the
+// same; args->dtype names the 2-byte type, or e4m3 when in_esize = 1)
+int fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize, int v_esize = 0);
+// attn_fwd_mx.hip: 16-bit scores, e4m3 P V (vorta_attn_fwd_fp8 / _batch_fp8 with ext->flags bit1)
+int mx_fwd(const vorta_attn_args* a, const vorta_attn_fp8_ext* ext, void* hip_stream);
+int mx_fwd_batch(const vorta_attn_args* args, const vorta_attn_fp8_ext* ext, int32_t n, void* hip_stream);
 
 template <typename T> struct MF;
 template <> struct MF<__bf16> {

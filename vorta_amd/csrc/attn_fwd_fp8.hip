@@ -678,6 +678,7 @@ int launch8(const Params8& pp, int block_rows, hipStream_t st) {
 }  // namespace
 
 extern "C" int vorta_attn_fwd_fp8(const vorta_attn_args* a, const vorta_attn_fp8_ext* ext, void* hip_stream) {
+  if (ext && ext->struct_size == sizeof(vorta_attn_fp8_ext) && (ext->flags & 2)) return mx_fwd(a, ext, hip_stream);
   Params8 pp{};
   int block_rows = 0;
   int rc = fill8(a, ext, pp, block_rows);
@@ -690,6 +691,7 @@ extern "C" int vorta_attn_fwd_fp8(const vorta_attn_args* a, const vorta_attn_fp8
 extern "C" int vorta_attn_fwd_batch_fp8(const vorta_attn_args* args, const vorta_attn_fp8_ext* ext, int32_t n,
                                         void* hip_stream) {
   if (!args || !ext || n < 0 || n > MAX_SEGMENTS) return VORTA_EINVAL;
+  if (ext->struct_size == sizeof(vorta_attn_fp8_ext) && (ext->flags & 2)) return mx_fwd_batch(args, ext, n, hip_stream);
   MultiParams8 mp{};
   int64_t total = 0;
   int m = 0;

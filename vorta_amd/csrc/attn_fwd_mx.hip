@@ -1,0 +1,650 @@
+// Gather flash-attention forward, MIXED precision: scores in 16 bits, P V in e4m3 (include/vorta_hip.h:
+// vorta_attn_fwd_fp8 with ext->flags bit1).
+//
+// Why: the all-e4m3 kernel (attn_fwd_fp8.hip) is off by 3.7 % of the root sum of squares of a score's 128 products, an
+// ABSOLUTE logit error that grows with the logits -- 40 dB against the 16-bit kernels where the softmax is flat, 36-38 dB on
+// peaked logits, 21-32 dB when a few outlier channels carry them (tools/dbg/qk_format_study.py).  The
+// scores are where the mantissa is needed; P (in [0, 1] after the row max) and V (scaled per channel) tolerate e4m3:
+// 16-bit q k^T with e4m3 P, V holds 42-69 dB on every input family.
+//
+// Structure: the pipelined 16-bit kernel (attn_fwd.hip: attn_pipe_dma_body) up to the probabilities -- K tile in 16 bits,
+// XOR-swizzled, LDS-DMA staged, scores one key block ahead, softmax folded into the score MFMA's seed -- and the e4m3
+// kernel (attn_fwd_fp8.hip) from there: the accumulator starts from p_bias - m_run, P' = exp2(acc) = P 2^p_bias is packed
+// to e4m3 straight from the accumulator registers (a lane owns one query and 32 of the block's 64 keys = the B operand of
+// ONE K = 64 MFMA), O^T += V8^T P'^T on v_mfma_f32_32x32x64_f8f6f4 with the V tile (rows of 128 bytes) read through
+// ds_read_b64_tr_b8, row sums from one more MFMA against a tile of ones, v_descale in the epilogue.  Per wave and 64-key
+// block: 16 MFMAs of 32 cycles + 5 of 64 = 832 pipe cycles (1 024 in 16 bits, 576 in e4m3), 33 v_add_f32 fewer than the
+// 16-bit loop, a V tile of half the bytes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vorta_hip.h"
+#include "common.h"
+
+#include "attn_common.h"
+
+namespace {
+using namespace vorta_attn;
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+constexpr int ROWB8 = D;             // bytes per e4m3 row
+constexpr int TILE8 = KVB * ROWB8;   // 8 KiB
+constexpr int NSMX = 2;              // ring depth of the K (16 KiB) and V (8 KiB) tiles
+constexpr int SMEM_MX = NSMX * (TILE_BYTES + TILE8);  // 48 KiB
+
+struct ParamsMx {
+  Params p;
+  const float* v_descale; int64_t v_descale_sh;
+  float p_bias;  // log2 bias of the packed probabilities
+  float thr;     // p_bias + defer: offset scores above this move the reference point
+};
+struct MultiParamsMx {
+  ParamsMx seg[MAX_SEGMENTS];
+  int start[MAX_SEGMENTS + 1];
+  int n;
+};
+
+__device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // cbsz = blgp = 0: e4m3 x e4m3, no block scale
+}
+
+template <typename T, int NW, bool KVTAB, int NS>
+__device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restrict__ smem, const int wg) {
+  // NS = depth of the K ring (16 KiB tiles, 16-bit rows) and of the V ring (8 KiB tiles, e4m3 rows): K(j+NS) / V(j+NS-1)
+  // are requested at the top of step j, NS-1 steps before the step that reads them
+  static_assert(NS == 2, "ring depth");
+  const Params& p = pp.p;
+  constexpr int VBASE = NS * TILE_BYTES;  // the V ring sits behind the K ring
+  using V8 = typename MF<T>::v8;
+  using V4 = typename MF<T>::v4;
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
+  constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
+#ifndef VORTA_KPRE
+#define VORTA_KPRE 2
+#endif
+  // k-steps of K fragments read ahead of the softmax head; the 128-row body with a key table keeps two row ids per lane
+  // on top of that and spilled 5 VGPRs at depth 2 (24 B of scratch): one step there
+  constexpr int KPRE = (NW == 4 && KVTAB && VORTA_KPRE > 1) ? 1 : VORTA_KPRE;
+  const int sp = wg % p.n_splits;
+  const int rest = wg / p.n_splits;
+  const int n_qb = p.n_groups * p.blocks_per_group;
+  const int qb = rest % n_qb;
+  const int y = rest / n_qb;
+  if (p.n_heads_dev && y >= *p.n_heads_dev) return;
+  const int head = p.head_list ? p.head_list[y] : y;
+  int grp, p0, pend;
+  q_block_of(p, qb, QB, grp, p0, pend);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r32 = lane & 31;
+  const int hh = lane >> 5;
+
+  // ---- key block range of this split (n_kv / q_valid may live on the device: no host sync) ----
+  const int n_kv = p.n_kv_dev ? max(1, min(*p.n_kv_dev, p.n_kv)) : p.n_kv;
+  const int q_valid = p.q_valid_dev ? min(*p.q_valid_dev, p.q_valid) : p.q_valid;
+  const int nblk_total = (n_kv + KVB - 1) / KVB;
+  const int blk0 = sp * p.blocks_per_split;
+  const int blk1 = min(blk0 + p.blocks_per_split, nblk_total);
+
+  // ---- query rows ----
+  const int wrow0 = p0 + wave * 32;
+  const bool wave_active = wrow0 < pend;  // wave-uniform
+  const int my_p = wrow0 + r32;
+  const bool row_ok = my_p < pend;
+  const int ld_p = min(my_p, pend - 1);
+  const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
+  const int64_t my_row = q_rows ? (int64_t)q_rows[ld_p] : (int64_t)(p.q_row_offset + ld_p);
+
+  // Q is pre-multiplied by scale*log2(e) once (re-rounded to T): the MFMA then delivers scores in the exp2
+  // domain, and with the running max folded into the accumulator's initial value (below) the softmax needs no
+  // per-element multiply/subtract at all.
+  V8 qf[8];
+  {
+    const char* qp = p.q + (int64_t)head * p.q_sh + my_row * p.q_ss + hh * 16;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const V8 raw = *(const V8*)(qp + ks * 32);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) qf[ks][i] = (T)((float)raw[i] * p.scale_log2);
+    }
+  }
+
+  // ---- loader setup ----
+  const int32_t* kv_rows =
+      p.kv_rows ? p.kv_rows + (int64_t)y * p.kv_rows_sh + (int64_t)grp * p.kv_rows_sg : nullptr;
+  const char* kbase = p.k + (int64_t)head * p.k_sh + (tid & 15) * 16;
+  const char* vbase = p.v + (int64_t)head * p.v_sh + (tid & 15) * 16;
+  const int lrow0 = tid >> 4;
+  const int lcc = tid & 15;
+  // K / V tiles go global -> LDS directly (buffer_load ... lds): no staging registers, no ds_write.  One wave
+  // instruction fills 1 KiB = 4 tile rows (16 lanes x 16 B per row); the destination is lane-linear, so the
+  // bank swizzles of the tile images are applied on the SOURCE side: the lane that lands in chunk c' of row r
+  // fetches chunk c' ^ swz(r) of that row (same involution the fragment reads apply).
+  // K(b) is staged one block ahead of V(b); rings: K tiles at [0, NS*16K), V tiles behind them.
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.k + (int64_t)head * p.k_sh), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.v + (int64_t)head * p.v_sh), 0, 0x7fffffff, 0x00020000);
+  const int k_ss32 = (int)p.k_ss, v_ss32 = (int)p.v_ss;
+  // V tile: rows of 128 bytes, one wave instruction = 1 KiB = 8 tile rows (8 lanes x 16 B per row): 8 pieces per tile
+  constexpr int CHV = 8 / NW;
+  int k_col[CH], v_col[CHV];  // source byte offset inside the row for this lane's chunk
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int row = 4 * (CH * wave + i) + (lane >> 4);
+    k_col[i] = ((lane & 15) ^ (row & 15)) << 4;
+  }
+#pragma unroll
+  for (int i = 0; i < CHV; ++i) {
+    const int row = 8 * (CHV * wave + i) + (lane >> 3);
+    v_col[i] = ((lane & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4;
+  }
+  int rowK[CH], rowV[CHV];  // rows of the next K block / next V block to fetch (each in its own piece-to-row map)
+#define ROWS_OF(dst_, blk_)                                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
+    const int pos_ = min((blk_) * KVB + 4 * (CH * wave + i_) + (lane >> 4), n_kv - 1); \
+    if constexpr (KVTAB) dst_[i_] = kv_rows[pos_];                                \
+    else dst_[i_] = p.kv_row_offset + pos_;                                       \
+  }
+#define ROWS_OF_V(dst_, blk_)                                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < CHV; ++i_) {                            \
+    const int pos_ = min((blk_) * KVB + 8 * (CHV * wave + i_) + (lane >> 3), n_kv - 1); \
+    if constexpr (KVTAB) dst_[i_] = kv_rows[pos_];                                \
+    else dst_[i_] = p.kv_row_offset + pos_;                                       \
+  }
+#define DMA_K(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
+      k_rsrc, (LDS_AS void*)(smem + (par_) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                            \
+      (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + k_col[i_], 0, 0, 0);
+#define DMA_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CHV; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(  \
+      v_rsrc, (LDS_AS void*)(smem + VBASE + (par_) * TILE8 + (CHV * wave + i_) * 1024), 16,                        \
+      (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
+
+  // ---- LDS read addresses ----
+  int k_rd[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) k_rd[ks] = r32 * ROWB + (((2 * ks + hh) ^ (r32 & 15)) << 4);
+  // V^T fragment (A operand of the e4m3 MFMA, rows = channels): 16-lane group = (half hh, channel half dsub); lane pq of
+  // the group addresses 8 bytes of key row 16 n + 4 hh + (tt & 3) + 8 (tt >> 2), tt = pq >> 1, at channel 32 dt + 16 dsub
+  // + 8 (pq & 1), and receives channel 32 dt + 16 dsub + pq of the group's 8 key rows (attn_fwd_fp8.hip)
+  int v_rd[4];
+  {
+    const int dsub = (lane >> 4) & 1, pq = lane & 15, tt = pq >> 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      v_rd[dt] = VBASE + (4 * hh + (tt & 3) + 8 * (tt >> 2)) * ROWB8 + ((dt ^ ((tt >> 1) & 3)) << 5) + 16 * dsub + 8 * (pq & 1);
+  }
+
+  f32x16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  // row sums: one more MFMA per block against a tile of ones (fp4 e2m1 1.0 = 0b0010: 4 registers read) puts sum_k P'[k][q]
+  // into every register of lacc -- the same rounded P' that multiplies V
+  f32x16 lacc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+  i32x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = 0x22222222;
+  asm volatile("" : "+v"(ones));
+  i32x8 pb_;  // packed probabilities of the current block (B operand of the PV MFMAs)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pb_[i] = 0;
+  // Online softmax in the exp2 domain.  m_run = reference point of this row (a lower bound of its running max, at most
+  // thr - p_bias below it); the score MFMAs start from minit = p_bias - m_run in every accumulator register, so they
+  // produce z - m_run + p_bias directly and P' = P * 2^p_bias = exp2 of that (P' <= 2^thr <= 256 < 448, the e4m3 maximum).
+  // minit only changes in the (rare) rescale branch.
+  float m_run = -1e30f;
+  const float pbias = pp.p_bias, thr = pp.thr;
+  f32x16 sA0, sA1, sB0, sB1;  // scores (minus m_run) of the current / next key block (roles swap every block)
+  f32x16 minit;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) minit[i] = 0.f;
+  float mx_cur = -1e30f;       // row max of the current block's (offset) scores
+
+  // scores of a block from the K ring slot `par_` into (d0_, d1_); the tail mask is applied by the consumer
+#define QK(d0_, d1_, par_)                                                        \
+  {                                                                               \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
+      const V8 k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);        \
+      const V8 k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
+      d0_ = MF<T>::mfma(k0_, qf[ks_], ks_ == 0 ? minit : d0_);                    \
+      d1_ = MF<T>::mfma(k1_, qf[ks_], ks_ == 0 ? minit : d1_);                    \
+    }                                                                             \
+  }
+#define ROW_MAX(dst_, a_, b_)                                                      \
+  {                                                                               \
+    float mx_ = a_[0];                                                            \
+    _Pragma("unroll") for (int i_ = 1; i_ < 16; ++i_) mx_ = fmaxf(mx_, a_[i_]);   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, b_[i_]);   \
+    dst_ = half_max(mx_);                                                         \
+  }
+  // The loop only asks two things of the NEXT block's row max: "is it above `thr` (> 0)?" and, if so, its value.  Both
+  // are answered by a signed-integer max over the float bit patterns (order-preserving for non-negative floats, any
+  // negative result reads as "not above"; -inf of masked keys is a negative integer, there are no NaNs): v_max3_i32
+  // needs no canonicalising v_max x,x of the MFMA outputs, and two chains halve the dependent latency.
+#define ROW_MAX_POS(dst_, a_, b_)                                                  \
+  {                                                                               \
+    int m0_ = max(max(__float_as_int(a_[0]), __float_as_int(a_[1])), __float_as_int(a_[2])); \
+    int m1_ = max(max(__float_as_int(b_[0]), __float_as_int(b_[1])), __float_as_int(b_[2])); \
+    _Pragma("unroll") for (int i_ = 3; i_ < 15; i_ += 2) {                        \
+      m0_ = max(max(m0_, __float_as_int(a_[i_])), __float_as_int(a_[i_ + 1]));    \
+      m1_ = max(max(m1_, __float_as_int(b_[i_])), __float_as_int(b_[i_ + 1]));    \
+    }                                                                             \
+    m0_ = max(max(m0_, __float_as_int(a_[15])), __float_as_int(b_[15]));          \
+    m0_ = max(m0_, m1_);                                                          \
+    auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m0_, false, false); \
+    dst_ = __int_as_float(max((int)r_[0], (int)r_[1]));                           \
+  }
+  // the same with the fragments of the first KPRE k-steps already in registers (read at the top of the step,
+  // their LDS latency hides under the row-max phase)
+#define QK_PRE(d0_, d1_, par_)                                                    \
+  {                                                                               \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
+      V8 k0_, k1_;                                                                \
+      if (ks_ < KPRE) { k0_ = kpre_[ks_][0]; k1_ = kpre_[ks_][1]; }               \
+      else {                                                                      \
+        k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);               \
+        k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB);   \
+      }                                                                           \
+      d0_ = MF<T>::mfma(k0_, qf[ks_], ks_ == 0 ? minit : d0_);                    \
+      d1_ = MF<T>::mfma(k1_, qf[ks_], ks_ == 0 ? minit : d1_);                    \
+    }                                                                             \
+  }
+  // move the reference point of the row up by g_ (>= 0): everything accumulated so far and the current block's
+  // offset scores are brought to the new reference, and the accumulator seed follows.  The empty asm keeps the
+  // seed an opaque 16-register value (otherwise the compiler re-materialises the splat before every use).
+#define RAISE_REF(g_, c0_, c1_)                                                   \
+  {                                                                               \
+    const float alpha_ = __builtin_amdgcn_exp2f(-(g_));                           \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                           \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) lacc[i_] *= alpha_;         \
+    m_run += (g_);                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= (g_); c1_[i_] -= (g_); minit[i_] = pbias - m_run; } \
+    asm volatile("" : "+v"(minit));                                               \
+  }
+  // top of step j: K(j+NS) -> the slot K(j) left, V(j+NS-1) -> the slot V(j-1) left.  They are read in step
+  // j+NS-1, so the barrier that ends step j only waits for the requests of step j-NS+2 and older: with NS = 3
+  // the 2*CH requests of the current step stay in flight across it (two steps of latency cover, one with NS = 2)
+#define STAGE_DMA(kfree_, vfree_, j_)                                             \
+  DMA_K(kfree_)                                                                   \
+  DMA_V(vfree_)                                                                   \
+  ROWS_OF_V(rowV, (j_) + NS)                                                      \
+  ROWS_OF(rowK, (j_) + NS + 1)                                                    \
+  __builtin_amdgcn_sched_barrier(0);
+  // end of a step: own DMA requests older than the current step have landed, then the workgroup barrier (which
+  // also orders every wave's LDS reads of this step before the next step's overwrites)
+#define STEP_SYNC()                                                               \
+  {                                                                               \
+    if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    else if constexpr (CH == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+  }
+
+  // Issue-order recipe for the step's basic block (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x400 transcendental,
+  // 0x002 VALU).  Score phase: per MFMA one K-fragment read, two exp, two plain VALU (the converts and half of the row
+  // sum); PV phase: per MFMA the two transposed V reads and four VALU (the rest of the row sum, the next block's row
+  // max).  The score phase is the issue-bound one (exp costs two slots), so everything that can wait moves under the PV
+  // MFMAs.  With the post-RA scheduler off (build.py) the recipe is what the hardware sees: +3.5 % on the dense launch
+  // and +4 % on the fused layer kernel against no recipe; a dozen other groupings measured between -3 % and +2 %.
+  // -DVORTA_SCHED=0 disables it.
+#ifndef VORTA_SCHED
+#define VORTA_SCHED 1
+#endif
+#if VORTA_SCHED == 1
+#define SCHED_RECIPE()                                                            \
+  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                            \
+  }                                                                               \
+  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                            \
+  }                                                                               \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#else
+#define SCHED_RECIPE()
+#endif
+  // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
+  // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
+  // all visible to the scheduler together.
+#define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, vfree_, j_)                       \
+  { /* kcur_ = j % NS: slot of K(j) (free) and of V(j); knext_ = (j+1) % NS; vfree_ = (j-1) % NS */ \
+    STAGE_DMA(kcur_, vfree_, j_)                                                  \
+    if (wave_active) {                                                            \
+      V8 kpre_[KPRE > 0 ? KPRE : 1][2];                                                          \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < KPRE; ++ks_) {                    \
+        kpre_[ks_][0] = *(const V8*)(smem + (knext_) * TILE_BYTES + k_rd[ks_]);   \
+        kpre_[ks_][1] = *(const V8*)(smem + (knext_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
+      }                                                                           \
+      /* mx_cur (row max of this block's scores) was computed under the previous step's PV MFMAs; only the */ \
+      /* last, partial key block has to mask its tail and redo it here                                      */ \
+      if ((j_) * KVB + KVB > n_kv) {                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
+          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
+          if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
+          if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
+        }                                                                         \
+        ROW_MAX(mx_cur, c0_, c1_)                                                 \
+      }                                                                           \
+      /* deferred rescale: the reference point moves only when some row of the wave outgrew it by more than */ \
+      /* `thr - p_bias` (so P' <= 2^thr: inside e4m3's range); rows that did not grow                          */ \
+      /* keep theirs (g = 0)                                                                                  */ \
+      if (!__all(mx_cur <= thr)) {                                                \
+        const float g_ = fmaxf(mx_cur - pbias, 0.f);                              \
+        RAISE_REF(g_, c0_, c1_)                                                   \
+      }                                                                           \
+      QK_PRE(n0_, n1_, knext_) /* block j+1 (harmless garbage past the end) */    \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
+        c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                \
+        c1_[i_] = __builtin_amdgcn_exp2f(c1_[i_]);                                \
+      }                                                                           \
+      /* P' -> e4m3 straight from the accumulator registers: a lane owns one query and 32 of the block's 64 keys = the B */ \
+      /* operand of ONE K = 64 MFMA (v_cvt_pk_fp8_f32 keeps the other half of its destination: fed the stale word)      */ \
+      _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                          \
+        pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_], c0_[4 * w_ + 1], pb_[w_], false); \
+        pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_ + 2], c0_[4 * w_ + 3], pb_[w_], true); \
+        pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_], c1_[4 * w_ + 1], pb_[4 + w_], false); \
+        pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_ + 2], c1_[4 * w_ + 3], pb_[4 + w_], true); \
+      }                                                                           \
+      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
+        i32x8 vf_;                                                                \
+        _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                        \
+          const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                \
+              (LDS_AS i32x2*)(smem + (kcur_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8)); \
+          vf_[2 * n_] = t_[0]; vf_[2 * n_ + 1] = t_[1];                           \
+        }                                                                         \
+        o[dt_] = mfma8(vf_, pb_, o[dt_]);                                         \
+      }                                                                           \
+      lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pb_, lacc, 4, 0, 0, 0, 0, 0); \
+      ROW_MAX_POS(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */ \
+      SCHED_RECIPE()                                                              \
+    }                                                                             \
+    STEP_SYNC()                                                                   \
+  }
+
+  if (blk0 < blk1) {
+    // prologue: K(0..NS-1) and V(0..NS-2) -> their ring slots; then rowK = rows(NS), rowV = rows(NS-1)
+    ROWS_OF(rowK, blk0)
+    ROWS_OF_V(rowV, blk0)
+    DMA_K(0)
+    DMA_V(0)
+    ROWS_OF(rowK, blk0 + 1)
+    DMA_K(1)
+    ROWS_OF_V(rowV, blk0 + NS - 1)
+    ROWS_OF(rowK, blk0 + NS)
+    __syncthreads();
+    if (wave_active) {
+      QK(sA0, sA1, 0)  // seed 0: plain scores of the first block
+      if (blk0 * KVB + KVB > n_kv) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (blk0 * KVB + row >= n_kv) sA0[i] = -INFINITY;
+          if (blk0 * KVB + 32 + row >= n_kv) sA1[i] = -INFINITY;
+        }
+      }
+      ROW_MAX(mx_cur, sA0, sA1)
+      // the first block fixes the reference point at its true row max (block blk0 always has a valid key);
+      // O and l are still zero, so nothing is rescaled (exp2(-max) could overflow for very negative scores)
+      m_run = mx_cur;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sA0[i] += pbias - m_run; sA1[i] += pbias - m_run; minit[i] = pbias - m_run; }
+      asm volatile("" : "+v"(minit));
+      mx_cur = pbias;
+    }
+    __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
+  }
+  if constexpr (NS == 2) {
+    for (int blk = blk0; blk < blk1; blk += 2) {
+      STEP(sA0, sA1, sB0, sB1, 0, 1, 1, blk)
+      if (blk + 1 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 1, 0, 0, blk + 1)
+    }
+  } else {  // ring slots cycle with period 3, score roles with period 2: unrolled by 6
+    for (int blk = blk0; blk < blk1; blk += 6) {
+      STEP(sA0, sA1, sB0, sB1, 0, 1, 2, blk)
+      if (blk + 1 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 1, 2, 0, blk + 1)
+      if (blk + 2 >= blk1) break;
+      STEP(sA0, sA1, sB0, sB1, 2, 0, 1, blk + 2)
+      if (blk + 3 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 0, 1, 2, blk + 3)
+      if (blk + 4 >= blk1) break;
+      STEP(sA0, sA1, sB0, sB1, 1, 2, 0, blk + 4)
+      if (blk + 5 >= blk1) break;
+      STEP(sB0, sB1, sA0, sA1, 2, 0, 1, blk + 5)
+    }
+  }
+#undef QK
+#undef QK_PRE
+#undef ROW_MAX
+#undef ROW_MAX_POS
+#undef RAISE_REF
+#undef STEP
+#undef STAGE_DMA
+#undef STEP_SYNC
+#undef ROWS_OF
+#undef ROWS_OF_V
+#undef DMA_K
+#undef DMA_V
+
+  if (!wave_active) return;
+  // ---------------- epilogue ----------------
+  const float l_tot = lacc[0];  // every register holds the row's sum
+  if (p.n_splits > 1) {
+    // unnormalised partials: ws_o[y][sp][pos][d], ws_ml[y][sp][pos][2]
+    if (row_ok) {
+      const int64_t slot = ((int64_t)y * p.n_splits + sp) * p.n_q + my_p;
+      float* wo = p.ws_o + slot * D;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          f32x4 v = {o[dt][4 * rg], o[dt][4 * rg + 1], o[dt][4 * rg + 2], o[dt][4 * rg + 3]};
+          *(f32x4*)(wo + 32 * dt + 8 * rg + 4 * hh) = v;
+        }
+      if (hh == 0) {
+        p.ws_ml[slot * 2] = m_run;  // already in the exp2 domain
+        p.ws_ml[slot * 2 + 1] = l_tot;
+      }
+    }
+    return;
+  }
+  if (!row_ok) return;
+  const float inv = (my_p < q_valid && l_tot > 0.f) ? 1.f / l_tot : 0.f;
+  const float* vd = pp.v_descale + (int64_t)head * pp.v_descale_sh + 4 * hh;
+  uint2 packed[16];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const f32x4 s = *(const f32x4*)(vd + 32 * dt + 8 * rg);
+      V4 t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = (T)(o[dt][4 * rg + j] * (inv * s[j]));
+      packed[dt * 4 + rg] = *(uint2*)&t;
+    }
+  char* obase = p.o + (int64_t)head * p.o_sh + hh * 8;
+  auto store_row = [&](int64_t row) {
+    char* op = obase + row * p.o_ss;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) *(uint2*)(op + (32 * dt + 8 * rg) * 2) = packed[dt * 4 + rg];
+  };
+  store_row(my_row);
+  if (p.dup_rows && my_p < p.n_dup_pos) {
+    const int32_t* dr = p.dup_rows + (int64_t)y * p.dup_rows_sh + (int64_t)my_p * p.n_dup;
+    for (int i = 0; i < p.n_dup; ++i) store_row((int64_t)dr[i]);
+  }
+}
+
+template <typename T, int NW, bool KVTAB>
+__global__ __launch_bounds__(NW * 64, 2) void attn_mx_kernel(const ParamsMx pp) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_MX];
+  const int wg = live_order(pp.p, blockIdx.x, gridDim.x, pp.p.xcd_remap);  // XCD-aware order over the live workgroups
+  attn_mx_body<T, NW, KVTAB, NSMX>(pp, smem, wg);
+#endif
+}
+
+// Several launches fused into ONE grid (the experts of a routed layer), as attn_fwd_multi_kernel
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn_mx_multi_kernel(const MultiParamsMx mp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_MX];
+  const int b = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_SEGMENTS; ++i) s += (i < mp.n && b >= mp.start[i]) ? 1 : 0;
+  const ParamsMx& pp = mp.seg[s];
+  const int wg = live_order(pp.p, b - mp.start[s], mp.start[s + 1] - mp.start[s], true);
+  if (pp.p.kv_rows) attn_mx_body<T, 8, true, NSMX>(pp, smem, wg);
+  else attn_mx_body<T, 8, false, NSMX>(pp, smem, wg);
+#endif
+}
+
+// Merge the split-key partials: one wave per (head slot, query position); both partial sums carry the 2^p_bias factor
+template <typename T>
+__global__ __launch_bounds__(256) void attn_mx_combine_kernel(const ParamsMx pp) {
+  const Params& p = pp.p;
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= (int64_t)p.n_heads * p.n_q) return;
+  const int y = (int)(item / p.n_q);
+  const int pos = (int)(item - (int64_t)y * p.n_q);
+  if (p.n_heads_dev && y >= *p.n_heads_dev) return;
+  const int head = p.head_list ? p.head_list[y] : y;
+  float m = -1e30f;
+  for (int s = 0; s < p.n_splits; ++s) m = fmaxf(m, p.ws_ml[(((int64_t)y * p.n_splits + s) * p.n_q + pos) * 2]);
+  float acc0 = 0.f, acc1 = 0.f, l = 0.f;
+  for (int s = 0; s < p.n_splits; ++s) {
+    const int64_t slot = ((int64_t)y * p.n_splits + s) * p.n_q + pos;
+    const float w = __builtin_amdgcn_exp2f(p.ws_ml[slot * 2] - m);
+    l += w * p.ws_ml[slot * 2 + 1];
+    const float2 v = *(const float2*)(p.ws_o + slot * D + lane * 2);
+    acc0 += w * v.x;
+    acc1 += w * v.y;
+  }
+  const int q_valid = p.q_valid_dev ? min(*p.q_valid_dev, p.q_valid) : p.q_valid;
+  const float inv = (pos < q_valid && l > 0.f) ? 1.f / l : 0.f;
+  const float2 sd = *(const float2*)(pp.v_descale + (int64_t)head * pp.v_descale_sh + lane * 2);
+  const int32_t* q_rows = p.q_rows ? p.q_rows + (int64_t)y * p.q_rows_sh : nullptr;
+  const int64_t row = q_rows ? (int64_t)q_rows[pos] : (int64_t)(p.q_row_offset + pos);
+  T pair[2] = {(T)(acc0 * inv * sd.x), (T)(acc1 * inv * sd.y)};
+  char* ob = p.o + (int64_t)head * p.o_sh + lane * 4;
+  *(uint32_t*)(ob + row * p.o_ss) = *(uint32_t*)pair;
+  if (p.dup_rows && pos < p.n_dup_pos) {
+    const int32_t* dr = p.dup_rows + (int64_t)y * p.dup_rows_sh + (int64_t)pos * p.n_dup;
+    for (int i = 0; i < p.n_dup; ++i) *(uint32_t*)(ob + (int64_t)dr[i] * p.o_ss) = *(uint32_t*)pair;
+  }
+}
+
+int fill_mx(const vorta_attn_args* a, const vorta_attn_fp8_ext* ext, ParamsMx& pp, int& block_rows) {
+  if (!ext || ext->struct_size != sizeof(vorta_attn_fp8_ext)) return VORTA_EINVAL;
+  if (!a || (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) || ext->out_dtype != a->dtype) return VORTA_EUNSUPPORTED;
+  int rc = fill_params(a, pp.p, block_rows, 2, 1);  // q, k, o in 16 bits (strides in elements); v in e4m3 (bytes)
+  if (rc != VORTA_OK) return rc;
+  if (pp.p.n_heads == 0 || pp.p.n_groups == 0) return VORTA_OK;
+  if (a->variant == 1) return VORTA_EUNSUPPORTED;  // only the pipelined LDS-DMA body exists
+  if (!ext->v_descale || ext->v_descale_stride_h < D) return VORTA_EINVAL;
+  const float pb = ext->p_bias != 0.f ? ext->p_bias : 5.f;
+  const float df = ext->defer != 0.f ? ext->defer : 3.f;
+  if (!(pb >= 0.f) || !(df > 0.f) || pb + df > 8.f) return VORTA_EINVAL;  // P' <= 2^(p_bias+defer) must stay below 448
+  if (ext->flags & 1) return VORTA_EUNSUPPORTED;  // (the VALU row sum is an experiment of the all-e4m3 kernel)
+  pp.v_descale = ext->v_descale;
+  pp.v_descale_sh = ext->v_descale_stride_h;
+  pp.p_bias = pb;
+  pp.thr = pb + df;
+  return VORTA_OK;
+}
+
+template <typename T>
+int launch_mx(const ParamsMx& pp, int block_rows, hipStream_t st) {
+  const Params& p = pp.p;
+  const int64_t total = (int64_t)p.n_groups * p.blocks_per_group * p.n_heads * p.n_splits;
+  if (total <= 0) return VORTA_OK;
+  if (total > 0x7fffffff) return VORTA_EINVAL;
+  const dim3 g((unsigned)total);
+#define LMX(NW_, TAB_) hipLaunchKernelGGL((attn_mx_kernel<T, NW_, TAB_>), g, dim3(NW_ * 64), 0, st, pp)
+  if (block_rows == 256) { if (p.kv_rows) LMX(8, true); else LMX(8, false); }
+  else { if (p.kv_rows) LMX(4, true); else LMX(4, false); }
+#undef LMX
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vorta_set_hip_error(e);
+  if (p.n_splits > 1) {
+    const int64_t items = (int64_t)p.n_heads * p.n_q;
+    hipLaunchKernelGGL((attn_mx_combine_kernel<T>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, pp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return vorta_set_hip_error(e);
+  }
+  return VORTA_OK;
+}
+
+}  // namespace
+
+int vorta_attn::mx_fwd(const vorta_attn_args* a, const vorta_attn_fp8_ext* ext, void* hip_stream) {
+  ParamsMx pp{};
+  int block_rows = 0;
+  int rc = fill_mx(a, ext, pp, block_rows);
+  if (rc != VORTA_OK) return rc;
+  if (pp.p.n_heads == 0 || pp.p.n_groups == 0) return VORTA_OK;
+  hipStream_t st = (hipStream_t)hip_stream;
+  return a->dtype == VORTA_BF16 ? launch_mx<__bf16>(pp, block_rows, st) : launch_mx<_Float16>(pp, block_rows, st);
+}
+
+int vorta_attn::mx_fwd_batch(const vorta_attn_args* args, const vorta_attn_fp8_ext* ext, int32_t n, void* hip_stream) {
+  if (!args || !ext || n < 0 || n > MAX_SEGMENTS) return VORTA_EINVAL;
+  MultiParamsMx mp{};
+  int64_t total = 0;
+  int m = 0;
+  int dtype = -1;
+  for (int i = 0; i < n; ++i) {
+    ParamsMx pp{};
+    int block_rows = 0;
+    int rc = fill_mx(&args[i], ext, pp, block_rows);
+    if (rc != VORTA_OK) return rc;
+    if (pp.p.n_heads == 0 || pp.p.n_groups == 0) continue;
+    if (block_rows != 256) return VORTA_EUNSUPPORTED;  // only 256-row launches share a grid
+    if (dtype >= 0 && dtype != args[i].dtype) return VORTA_EINVAL;
+    dtype = args[i].dtype;
+    pp.p.xcd_remap = 0;
+    mp.seg[m] = pp;
+    mp.start[m] = (int)total;
+    total += (int64_t)pp.p.n_groups * pp.p.blocks_per_group * pp.p.n_heads * pp.p.n_splits;
+    if (total > 0x7fffffff) return VORTA_EINVAL;
+    ++m;
+  }
+  if (m == 0) return VORTA_OK;
+  for (int i = m; i <= MAX_SEGMENTS; ++i) mp.start[i] = (int)total;
+  mp.n = m;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const bool bf = dtype == VORTA_BF16;
+  if (bf) hipLaunchKernelGGL((attn_mx_multi_kernel<__bf16>), dim3((unsigned)total), dim3(512), 0, st, mp);
+  else hipLaunchKernelGGL((attn_mx_multi_kernel<_Float16>), dim3((unsigned)total), dim3(512), 0, st, mp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return vorta_set_hip_error(e);
+  for (int i = 0; i < m; ++i) {
+    const ParamsMx& pp = mp.seg[i];
+    if (pp.p.n_splits > 1) {
+      const int64_t items = (int64_t)pp.p.n_heads * pp.p.n_q;
+      if (bf) hipLaunchKernelGGL((attn_mx_combine_kernel<__bf16>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, pp);
+      else hipLaunchKernelGGL((attn_mx_combine_kernel<_Float16>), dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, pp);
+      e = hipGetLastError();
+      if (e != hipSuccess) return vorta_set_hip_error(e);
+    }
+  }
+  return VORTA_OK;
+}

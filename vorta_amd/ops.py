@@ -100,25 +100,33 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     the args carry `_ext`, the vorta_attn_fp8_ext of the fp8 entry points."""
     _require_gpu(q, k, v, out)
     fp8 = q.dtype == FP8_STORAGE
+    mixed = (not fp8) and v.dtype == FP8_STORAGE  # 16-bit scores, e4m3 P V (csrc/attn_fwd_mx.hip)
     if fp8:
         if not (k.dtype == v.dtype == FP8_STORAGE) or out.dtype not in _DT:
             raise ValueError("fp8 attention takes e4m3 (uint8) q,k,v and a bf16 / fp16 output")
-        if v_descale is None or v_descale.dtype != torch.float32 or v_descale.dim() != 2 or v_descale.shape[1] != q.shape[-1] \
-                or not v_descale.is_contiguous():
-            raise ValueError("fp8 attention needs v_descale: contiguous float32 (heads, D) from fp8_quantize_qkv")
+    elif mixed:
+        if q.dtype not in _DT or not (q.dtype == k.dtype == out.dtype):
+            raise ValueError("mixed-precision attention takes 16-bit q, k, out of one dtype and an e4m3 (uint8) v")
     elif q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype == out.dtype):
         raise ValueError("q,k,v,out must share dtype bf16 or fp16")
+    if fp8 or mixed:
+        if v_descale is None or v_descale.dtype != torch.float32 or v_descale.dim() != 2 or v_descale.shape[1] != q.shape[-1] \
+                or not v_descale.is_contiguous():
+            raise ValueError("fp8 attention needs v_descale: contiguous float32 (heads, D) from fp8_quantize_qkv / fp8_quantize_v")
     a = _C.AttnArgs()
     a.struct_size = C.sizeof(_C.AttnArgs)
     a.dtype = _C.VORTA_FP8E4M3 if fp8 else _DT[q.dtype]
     a._ext = None
-    if fp8:
+    a._mixed = mixed
+    if fp8 or mixed:
         ext = _C.AttnFp8Ext()
         ext.struct_size = C.sizeof(_C.AttnFp8Ext)
         ext.out_dtype = _DT[out.dtype]
         ext.v_descale, ext.v_descale_stride_h = v_descale.data_ptr(), v_descale.stride(0)
         o = fp8_opts or FP8_OPTS
         ext.p_bias, ext.defer, ext.flags = float(o.get("p_bias", 0.0)), float(o.get("defer", 0.0)), int(o.get("flags", 0))
+        if mixed:
+            ext.flags |= 2
         a._ext = ext
     a.head_dim = q.shape[-1]
     a.q, a.k, a.v, a.o = _tensor(q), _tensor(k), _tensor(v), _tensor(out)
@@ -174,14 +182,14 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     a.block_rows = block_rows
     a.n_splits = n_splits
     a.n_kv_dev, a.q_valid_dev = _ptr(n_kv_dev), _ptr(q_valid_dev)
-    a.variant = 0 if fp8 else (variant or DEFAULT_VARIANT)
+    a.variant = 0 if (fp8 or mixed) else (variant or DEFAULT_VARIANT)
     if a.variant != 1:
         # the pipelined kernel's 32-bit K/V offsets (vorta_hip.h): beyond a 2 GiB window per head, or 2^24 rows, use
         # the plain HIP kernel (64-bit addressing) instead
-        esz = 1 if fp8 else 2
         for t in (k, v):
+            esz = t.element_size()
             if t.shape[1] >= (1 << 24) or t.shape[1] * t.stride(1) * esz > 0x7fffffff or t.stride(1) * esz >= (1 << 24):
-                if fp8:
+                if fp8 or mixed:
                     raise ValueError("fp8 attention addresses K/V rows with 32-bit offsets: a head must fit a 2 GiB window")
                 a.variant = 1
     a.reserved = NO_XCD_REMAP
@@ -211,6 +219,8 @@ def _plan(a) -> Tuple[int, int, str]:
     nw, kk = kid.value // 16, kid.value % 16
     if a._ext is not None:
         tname = "_Float16" if a._ext.out_dtype == _C.VORTA_FP16 else "__bf16"
+        if a._ext.flags & 2:
+            return br.value, nwg.value, f"attn_mx_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>"
         return br.value, nwg.value, (f"attn8_kernel<{tname},{nw},{'true' if kk & 2 else 'false'},"
                                      f"{'false' if a._ext.flags & 1 else 'true'}>")
     sym = (f"attn_fwd_pipe_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>" if kk & 1
@@ -300,8 +310,9 @@ def attn_fwd_batch_built(built, fuse: bool = True) -> None:
         return
     arr = (_C.AttnArgs * len(built))(*[a for a, _, _, _ in built])
     ext = built[0][0]._ext  # one operand set per layer: every fused launch shares v_descale and the options
-    if any((a._ext is None) != (ext is None) for a, _, _, _ in built):
-        raise ValueError("a fused grid is either all fp8 or all 16-bit")
+    if any((a._ext is None) != (ext is None) or (ext is not None and (a._ext.flags & 2) != (ext.flags & 2))
+           for a, _, _, _ in built):
+        raise ValueError("a fused grid is all 16-bit, all e4m3 or all mixed-precision")
 
     def go():
         if ext is not None:
@@ -311,7 +322,8 @@ def attn_fwd_batch_built(built, fuse: bool = True) -> None:
 
     if _timeline is not None:
         if ext is not None:
-            sym = f"attn8_multi_kernel<{'_Float16' if ext.out_dtype == _C.VORTA_FP16 else '__bf16'}>"
+            sym = ("attn_mx_multi_kernel" if ext.flags & 2 else "attn8_multi_kernel") + \
+                f"<{'_Float16' if ext.out_dtype == _C.VORTA_FP16 else '__bf16'}>"
         else:
             sym = f"attn_fwd_multi_kernel<{'_Float16' if built[0][0].dtype == _C.VORTA_FP16 else '__bf16'}>"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -398,6 +410,22 @@ def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor]
             raise ValueError(f"fp8_quantize_qkv: slots {slots} need the segmented layout and 0 <= first < end <= {H}")
         a.slot_first, a.slot_count = slots[0], slots[1] - slots[0]
     _C.check(_C.lib().vorta_fp8_quantize_qkv(C.byref(a), _stream()), "vorta_fp8_quantize_qkv")
+    return out
+
+
+def fp8_quantize_v(v: torch.Tensor, out: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+    """(H,S,D) bf16 / fp16 view -> (v8 (H,S,D) uint8, v_descale (H,D) float32, amax workspace): the e4m3 copy of v for the
+    mixed-precision attention (16-bit scores, e4m3 P V): vorta_fp8_v_absmax + vorta_fp8_v_convert, exact per-(head,
+    channel) abs-max.  `out` = a previous result to overwrite."""
+    H, S, D = v.shape
+    if out is None:
+        out = (torch.empty((H, S, D), dtype=FP8_STORAGE, device=v.device),
+               torch.empty((H, D), dtype=torch.float32, device=v.device),
+               torch.empty((H, D), dtype=torch.float32, device=v.device))
+    v8, vd, amax = out
+    amax.zero_()
+    fp8_v_absmax(v, amax)
+    fp8_v_convert(v, amax, v8, v_descale=vd)
     return out
 
 

@@ -147,7 +147,9 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
 STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
 # process-wide default of `routed_attention(fp8=None)`: the processors of vorta.attention call it that way, so the
 # unchanged inference scripts pick the e4m3 path up from the environment or from `set_attention_precision("fp8")`
-DEFAULT_FP8 = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower() == "fp8"
+# False (native), True (all e4m3) or "fp8pv" (16-bit scores, e4m3 P V)
+_PREC_ENV = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower()
+DEFAULT_FP8 = True if _PREC_ENV == "fp8" else ("fp8pv" if _PREC_ENV == "fp8pv" else False)
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
 # the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
 FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
@@ -164,11 +166,13 @@ FUSED_TEXT_FIRST = FUSED_TEXT_SPLITS > 0
 
 
 def set_attention_precision(precision: str) -> None:
-    """"native" (the dtype of q,k,v: the reference's behaviour) or "fp8" (e4m3 contractions, 16-bit output)"""
+    """"native" (the dtype of q,k,v: the reference's behaviour), "fp8" (both contractions in e4m3: fastest, 40 dB against
+    native only where the softmax is flat) or "fp8pv" (scores in 16 bits, P V in e4m3: >= 42 dB on every input family
+    tried); 16-bit output in every case"""
     global DEFAULT_FP8
-    if precision not in ("native", "fp8"):
-        raise ValueError("precision is 'native' or 'fp8'")
-    DEFAULT_FP8 = precision == "fp8"
+    if precision not in ("native", "fp8", "fp8pv"):
+        raise ValueError("precision is 'native', 'fp8' or 'fp8pv'")
+    DEFAULT_FP8 = True if precision == "fp8" else ("fp8pv" if precision == "fp8pv" else False)
 _SIDE_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
 
 
@@ -232,6 +236,9 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         fp8 = DEFAULT_FP8
     if fp8_views is not None:
         base = dict(q=fp8_views[0], k=fp8_views[1], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
+    elif fp8 == "fp8pv":  # scores in 16 bits, P V in e4m3: only v is converted (exact per-channel abs-max, one pass + one)
+        v8, vd, _ = ops.fp8_quantize_v(v3, out=fp8_operands if isinstance(fp8_operands, tuple) else None)
+        base = dict(q=q3, k=k3, v=v8, scale=scale, v_descale=vd)
     elif fp8:
         f8 = ops.fp8_quantize_qkv(q3, k3, v3, scale, out=fp8_operands, center_k=FP8_CENTER_K)
         base = dict(q=f8.q, k=f8.k, v=f8.v, scale=scale, v_descale=f8.v_descale)
