@@ -72,6 +72,26 @@ def test_bench_plain_command_launches_its_ranks_and_fp8_exchange_variants_agree(
     assert "uneven head placement" in lines["uneven"]["config"]["parallelism"]
 
 
+def test_bench_fp8pv_lines():
+    """--dtype fp8pv (scores in bf16, P V in e4m3): one GPU, and 2 ranks (v converted on the send side, exchanged as
+    bytes) with one and two slot groups giving one fingerprint"""
+    r = subprocess.run([sys.executable, "bench.py", "--config", "tiny", "--steps", "1", "--warmup", "1", "--dtype", "fp8pv",
+                        "--no-gemm-ceiling", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _line(r.stdout)
+    assert j["dtype"] == "fp8pv" and j["roofline"]["kernel"].startswith("attn_mx_") and 3300 < j["roofline"]["peak"] < 3400
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    fps = []
+    for extra in ([], ["--sp-groups", "2"]):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--config", "tiny", "--dtype", "fp8pv", "--steps", "1",
+                            "--warmup", "1", "--no-cpu-baseline"] + extra, cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, (extra, r.stdout[-1500:], r.stderr[-3000:])
+        fps.append(_line(r.stdout)["output_fingerprint"])
+    assert fps[0] == fps[1] != 0, fps
+
+
 def test_bench_three_rank_rehearsal_heads_not_divisible():
     """3 ranks sharing the GPU (gloo, host-staged): 8 heads do not divide by 3 -- the reference's reshard and the equal-count
     placement both refuse that -- but head counts that follow the routes place them (3 + 3 + 2 and the like).  One collective

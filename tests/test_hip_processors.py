@@ -410,6 +410,10 @@ def _sp_worker_fp8(rank, world, port, ret):
         routed.FP8_CENTER_K = center
         full[center] = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
         full2[center] = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
+    vorta_amd.set_attention_precision("fp8pv")  # scores in 16 bits, P V in e4m3
+    fullpv = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    fullpv2 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
+    vorta_amd.set_attention_precision("fp8")
     SP_STATE.setup_sp_group(world)
     rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
     nat = native[:, rank * Sl:(rank + 1) * Sl].float()
@@ -424,6 +428,15 @@ def _sp_worker_fp8(rank, world, port, ret):
             part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
             ref = fl[center][:, rank * Sl:(rank + 1) * Sl].float()
             res[(groups, v_wire, placement, center)] = (float((part.float() - ref).abs().max()), rel(ref, nt))
+    vorta_amd.set_attention_precision("fp8pv")
+    for groups, placement in ((1, "even"), (2, "even"), (2, "uneven")):
+        _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = groups, True, placement
+        _sp._LAYOUTS.clear()
+        sc, fl, nt = (score2, fullpv2, nat2) if placement == "uneven" else (score, fullpv, nat)
+        part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
+        ref = fl[:, rank * Sl:(rank + 1) * Sl].float()
+        res[("fp8pv", groups, placement)] = (float((part.float() - ref).abs().max()), rel(ref, nt))
+    vorta_amd.set_attention_precision("native")
     _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = 1, True, "uneven"
     ret[rank] = res
     dist.barrier()
@@ -443,7 +456,7 @@ def test_processor_under_sequence_parallel_rehearsal_fp8():
     ret = mp.Manager().dict()
     mp.spawn(_sp_worker_fp8, args=(2, port, ret), nprocs=2, join=True)
     for r in (0, 1):
-        assert len(ret[r]) == 12
+        assert len(ret[r]) == 15
         for key, (d, one) in ret[r].items():
             assert d == 0.0 and 0.0 < one < 0.1, (key, dict(ret[r]))
 

@@ -38,11 +38,17 @@ class _SpBuffers:
         self.f8 = None
         self.vwire = None
 
-    def fp8(self):
+    def fp8(self, mode=True):
+        """(operands, v wire) of the e4m3 path; mode "fp8pv" (16-bit scores): only the e4m3 receive buffer of v"""
+        if mode == "fp8pv":
+            if self.vwire is None or self.f8 is not None:
+                self.f8 = None
+                self.vwire = VWire(self.lay, torch.zeros((self.lay.rows_total, self.lay.D), dtype=torch.uint8,
+                                                         device=self.lay.device))
+            return None, self.vwire
         if self.f8 is None:
             self.f8 = self.lay.fp8_operands()
-            if SP_V_WIRE:
-                self.vwire = VWire(self.lay, self.f8.v[0])
+            self.vwire = VWire(self.lay, self.f8.v[0]) if SP_V_WIRE else None
         return self.f8, self.vwire
 
 
@@ -129,14 +135,16 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     # the precision switch (set_attention_precision / VORTA_ATTENTION_PRECISION) is about the ROUTED operator; dense
     # attention -- --native_attention, the PSNR reference -- stays in the dtype of q,k,v on one GPU and under SP alike
     from .. import routed as _routed
-    fp8 = _routed.DEFAULT_FP8 and not dense_only
-    f8, vwire = sb.fp8() if fp8 else (None, None)
+    fp8 = _routed.DEFAULT_FP8 if not dense_only else False  # False, True (all e4m3) or "fp8pv" (16-bit scores)
+    f8, vwire = sb.fp8(fp8) if fp8 else (None, None)
     if vwire is not None:
         vwire.lay = lay  # the layouts of one slot count share the buffers; the head offsets are this layer's
 
     def attend(g0, g1, gi):
         views = None
-        if fp8:  # the slot group that has landed is converted while the next one is in flight
+        if fp8 == "fp8pv":  # q, k as they landed; v arrived as e4m3 (converted on the send side)
+            views = (qv[g0:g1], kv[g0:g1], lay.head_view(vwire.buf)[g0:g1], vwire.descale(g0, g1))
+        elif fp8:  # the slot group that has landed is converted while the next one is in flight
             q8, k8, v8, vd, _ = lay.fp8_views(bufs, out=f8, slots=(g0, g1), vwire=vwire)
             views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
         if dense_only:

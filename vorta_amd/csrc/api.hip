@@ -65,6 +65,12 @@ static const char kBuildInfo[] = "libvorta_hip gfx950 (CDNA4) hipcc " __VERSION_
 #ifdef VORTA_SCHED
     " -DVORTA_SCHED=" VORTA_STR_(VORTA_SCHED)
 #endif
+#ifdef VORTA_MX_KPRE
+    " -DVORTA_MX_KPRE=" VORTA_STR_(VORTA_MX_KPRE)
+#endif
+#ifdef VORTA_MX_SCHED
+    " -DVORTA_MX_SCHED=" VORTA_STR_(VORTA_MX_SCHED)
+#endif
 #ifdef VORTA_SCHED8
     " -DVORTA_SCHED8=" VORTA_STR_(VORTA_SCHED8)
 #endif

@@ -63,12 +63,13 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
   constexpr int QB = NW * 32;
   constexpr int CH = (KVB * 16) / NT;  // 16-byte chunks of one tile per thread (2 or 4)
   constexpr int ROWSTEP = NT / 16;     // rows between a thread's consecutive chunks
-#ifndef VORTA_KPRE
-#define VORTA_KPRE 2
+#ifndef VORTA_MX_KPRE
+#define VORTA_MX_KPRE 1
 #endif
-  // k-steps of K fragments read ahead of the softmax head; the 128-row body with a key table keeps two row ids per lane
-  // on top of that and spilled 5 VGPRs at depth 2 (24 B of scratch): one step there
-  constexpr int KPRE = (NW == 4 && KVTAB && VORTA_KPRE > 1) ? 1 : VORTA_KPRE;
+  // k-steps of K fragments read ahead of the softmax head: one (two, the 16-bit kernel's depth, spill 8 VGPRs in the fused
+  // kernel here -- the e4m3 row-sum accumulator and ones tile take 24 registers the 16-bit loop does not have); the
+  // 128-row body with a key table keeps two row ids per lane on top of that: none there
+  constexpr int KPRE = (NW == 4 && KVTAB) ? 0 : VORTA_MX_KPRE;
   const int sp = wg % p.n_splits;
   const int rest = wg / p.n_splits;
   const int n_qb = p.n_groups * p.blocks_per_group;
@@ -295,11 +296,11 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
   // max).  The score phase is the issue-bound one (exp costs two slots), so everything that can wait moves under the PV
   // MFMAs.  With the post-RA scheduler off (build.py) the recipe is what the hardware sees: +3.5 % on the dense launch
   // and +4 % on the fused layer kernel against no recipe; a dozen other groupings measured between -3 % and +2 %.
-  // -DVORTA_SCHED=0 disables it.
-#ifndef VORTA_SCHED
-#define VORTA_SCHED 1
+  // -DVORTA_MX_SCHED=0 disables it.
+#ifndef VORTA_MX_SCHED
+#define VORTA_MX_SCHED 1
 #endif
-#if VORTA_SCHED == 1
+#if VORTA_MX_SCHED == 1
 #define SCHED_RECIPE()                                                            \
   _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \

@@ -570,7 +570,14 @@ class _RankState:
             for b in self.bufs[:3]:
                 b.normal_()
         self.f8 = self.vwire = None
-        if fp8:
+        if fp8 == "fp8pv":  # scores in 16 bits: only v is e4m3, converted on the send side (it always travels as bytes)
+            if not v_wire:
+                raise ValueError("precision 'fp8pv' under sequence parallelism converts v on the send side (v_wire)")
+            buf8 = torch.zeros((lay.rows_total, lay.D), dtype=torch.uint8, device=lay.device)
+            if loopback:
+                buf8.random_(0, 120)
+            self.vwire = VWire(lay, buf8)
+        elif fp8:
             self.f8 = lay.fp8_operands()
             if v_wire:  # v travels as e4m3 straight into the operand buffer
                 self.vwire = VWire(lay, self.f8.v[0])
@@ -654,7 +661,9 @@ class UlyssesRoutedAttention:
 
         def attend(g0, g1, gi):
             views = None
-            if self.fp8:  # the slot group that has landed is converted while the next one is in flight
+            if self.fp8 == "fp8pv":  # 16-bit q, k as they landed; v arrived as e4m3
+                views = (q[g0:g1], k[g0:g1], lay.head_view(st.vwire.buf)[g0:g1], st.vwire.descale(g0, g1))
+            elif self.fp8:  # the slot group that has landed is converted while the next one is in flight
                 q8, k8, v8, vd, st.f8 = lay.fp8_views(st.bufs, out=st.f8, slots=(g0, g1), vwire=st.vwire)
                 views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
             routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], st.geom, model=self.cfg["model"],
