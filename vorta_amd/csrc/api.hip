@@ -71,6 +71,12 @@ static const char kBuildInfo[] = "libvorta_hip gfx950 (CDNA4) hipcc " __VERSION_
 #ifdef VORTA_MX_SCHED
     " -DVORTA_MX_SCHED=" VORTA_STR_(VORTA_MX_SCHED)
 #endif
+#ifdef VORTA_MX_SC_VALU
+    " -DVORTA_MX_SC_VALU=" VORTA_STR_(VORTA_MX_SC_VALU)
+#endif
+#ifdef VORTA_MX_PV_VALU
+    " -DVORTA_MX_PV_VALU=" VORTA_STR_(VORTA_MX_PV_VALU)
+#endif
 #ifdef VORTA_SCHED8
     " -DVORTA_SCHED8=" VORTA_STR_(VORTA_SCHED8)
 #endif

@@ -300,18 +300,24 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
 #ifndef VORTA_MX_SCHED
 #define VORTA_MX_SCHED 1
 #endif
+#ifndef VORTA_MX_SC_VALU
+#define VORTA_MX_SC_VALU 2
+#endif
+#ifndef VORTA_MX_PV_VALU
+#define VORTA_MX_PV_VALU 5
+#endif
 #if VORTA_MX_SCHED == 1
 #define SCHED_RECIPE()                                                            \
   _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, VORTA_MX_SC_VALU, 0);             \
   }                                                                               \
   _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                              \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x002, VORTA_MX_PV_VALU, 0);             \
   }                                                                               \
   __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
 #else
