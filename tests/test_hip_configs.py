@@ -278,3 +278,67 @@ def test_hunyuan_129f_fp8_with_text_and_biased_keys_at_full_size():
     print("fp8 vs fp16, Hunyuan-129f geometry, keys with a 3-sigma common component (PSNR over data range, dB):",
           {n: round(p, 2) for n, p in table.items()})
     assert min(table.values()) >= 40.0, table
+
+
+def test_hunyuan_129f_fp8pv_one_rank_of_eight_at_full_size():
+    """Precision "fp8pv" (16-bit scores, e4m3 P V) on the headline geometry through the Ulysses receive layout of a rank of
+    8: v is converted the way the exchange does it -- per-(head, channel) abs-max taken shard by shard (P calls that only
+    raise the maximum) and one conversion with the whole-sequence scales into the e4m3 receive buffer -- q and k are read as
+    they landed.  Keys with a 3-sigma common component and a peaked softmax (q, k x 1.5): >= 45 dB over max|x| per expert
+    against the fp16 kernels, valid text rows included; padded text rows exactly zero."""
+    import math
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    from vorta_amd.ulysses import UlyssesLayout
+    dtype = torch.float16
+    H, P, rank = 24, 8, 2
+    latent, tile, group = (33, 45, 80), (11, 9, 8), (3, 3, 2)
+    S, T, te = 33 * 45 * 80, 256, 96
+    lay = UlyssesLayout(H, S, T, 128, P, rank, dev(), dtype)
+    Hl, Sl = lay.Hl, lay.Sl
+    bufs = []
+    for i in range(3):
+        b = lay.new_buffer()
+        x = _rand((lay.rows_total, 128), 800 + i, dtype)
+        if i < 2:
+            x = (x.float() * 1.5).to(dtype)
+        if i == 1:
+            seg = (torch.arange(lay.rows_total, device=dev()) // Sl) % Hl
+            x = (x.float() + (3.0 * _rand((Hl, 128), 810, torch.float32))[seg]).to(dtype)
+        b[:lay.rows_video] = x[:lay.rows_video]
+        for s_ in range(Hl):
+            b[lay.rows_video + s_ * Sl: lay.rows_video + s_ * Sl + T] = x[lay.rows_video + s_ * Sl: lay.rows_video + s_ * Sl + T]
+        bufs.append(b)
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev(), row_map=lay.row_map)
+    route = HeadRouting.from_expert_ids([0, 1, 2], dev())
+    views = [lay.head_view(b) for b in bufs]
+    ref, out = lay.new_buffer(), lay.new_buffer()
+    routed_attention(*views, route, geom, model="hunyuan", text_len=T, text_valid=te, out=lay.head_view(ref), fp8=False)
+    # v: abs-max chunk by chunk (what the P senders contribute through the MAX all-reduce), then one conversion per chunk
+    vb = bufs[2]
+    amax = torch.zeros((Hl, 128), dtype=torch.float32, device=dev())
+    chunks = [vb[j * Hl * Sl:(j + 1) * Hl * Sl].view(Hl, Sl, 128) for j in range(P)]
+    texts = vb[lay.rows_video:].as_strided((Hl, T, 128), (Sl * 128, 128, 1))
+    for c in chunks + [texts]:
+        ops.fp8_v_absmax(c, amax)
+    v8 = torch.zeros((lay.rows_total, 128), dtype=torch.uint8, device=dev())
+    vd = torch.empty((Hl, 128), dtype=torch.float32, device=dev())
+    for j, c in enumerate(chunks):
+        ops.fp8_v_convert(c, amax, v8[j * Hl * Sl:(j + 1) * Hl * Sl].view(Hl, Sl, 128), v_descale=vd)
+    ops.fp8_v_convert(texts, amax, v8[lay.rows_video:].as_strided((Hl, T, 128), (Sl * 128, 128, 1)))
+    routed_attention(*views, route, geom, model="hunyuan", text_len=T, text_valid=te, out=lay.head_view(out), fp8=False,
+                     fp8_views=(views[0], views[1], lay.head_view(v8), vd))
+    torch.cuda.synchronize()
+    rm = lay.row_map.long()
+    a, b = lay.head_view(out)[:, rm].float(), lay.head_view(ref)[:, rm].float()
+    assert not torch.isnan(a).any()
+    assert (a[:, S + te:] == 0).all() and (b[:, S + te:] == 0).all()
+    table = {}
+    for i, name in enumerate(("full", "coreset", "sliding-tile")):
+        for part, sl in (("video", slice(0, S)), ("text", slice(S, S + te))):
+            mse = ((a[i, sl] - b[i, sl]) ** 2).mean().item()
+            table[f"{name}/{part}"] = 10 * math.log10(b[i, sl].abs().max().item() ** 2 / mse)
+    print("fp8pv vs fp16, Hunyuan-129f geometry, rank of 8, peaked softmax + key bias (PSNR over max|x|, dB):",
+          {n: round(p, 2) for n, p in table.items()})
+    # (the 96 valid text queries attend every key: a flat softmax over 118 896 keys, the e4m3 noise of P and V averages least)
+    assert all(v >= (55.0 if n.endswith("video") else 42.0) for n, v in table.items()), table
