@@ -570,12 +570,18 @@ def main():
             n = 16384
             a = torch.randn((n, n), device=dev).to(dt)
             b = torch.randn((n, n), device=dev).to(dt)
+            mm = lambda: a @ b
+            if fp8 is True:  # both contractions in e4m3: the library's e4m3 GEMM (torch._scaled_mm, unit scales)
+                a, b = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn).t().contiguous().t()
+                one = torch.ones((), device=dev)
+                mm = lambda: torch._scaled_mm(a, b, scale_a=one, scale_b=one, out_dtype=torch.bfloat16)
+                roofline["library_gemm_dtype"] = "e4m3"
             for _ in range(2):
-                a @ b
+                mm()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                a @ b
+                mm()
             e1.record()
             torch.cuda.synchronize()
             gemm = 2.0 * n ** 3 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e12

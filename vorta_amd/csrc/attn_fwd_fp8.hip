@@ -311,12 +311,17 @@ __device__ __forceinline__ void attn8_body(const Params8& pp, char* __restrict__
 #ifndef VORTA_SCHED8
 #define VORTA_SCHED8 1
 #endif
-  // Issue-order recipe (sched_group_barrier: 0x008 MFMA, 0x100 DS read) of the PV half of the matrix part: 5 MFMAs
-  // with the fragment reads of the later ones (V channel tiles 2,3; k-step 0 of the next K block) under the earlier
-  // ones; the score half follows (its k-step-1 fragments are requested first).
+  // Issue-order recipe (sched_group_barrier: 0x008 MFMA, 0x100 DS read) of the PV half of the matrix part: the reads of
+  // V channel tiles 0,1 first (claimed by a group of their own: without it the scheduler counts them as the groups behind
+  // the first MFMAs, allocates ONE register set to tiles 0, 1, 2 in turn, and every PV MFMA waits a full LDS round trip
+  // for reads issued just before it), then 5 MFMAs with the fragment reads of the later ones (V channel tiles 2,3;
+  // k-step 0 of the next K block) under the earlier ones; the score half follows (its k-step-1 fragments are requested
+  // first).  Each PV MFMA then waits with two fragments still in flight (lgkmcnt(4)): +1.5-2 % on the dense launch, +1 %
+  // on the Wan-14B step, Hunyuan-129f unchanged (profiles/r03_fp8_loop_experiments.txt).
 #if VORTA_SCHED8 == 1
 #define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
 #define SCHED_M()                                                                 \
+  SG_(0x100, 8)                                                                   \
   SG_(0x008, 1) SG_(0x100, 4)                                                     \
   SG_(0x008, 1) SG_(0x100, 4)                                                     \
   SG_(0x008, 1) SG_(0x100, 2)                                                     \
