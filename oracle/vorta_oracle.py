@@ -544,13 +544,16 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
                     kv_row_offset: int = 0, dup_rows: Optional[np.ndarray] = None, n_dup_pos: int = 0, n_splits: int = 1,
                     p_bias: float = 5.0, defer: float = 3.0, round_p: bool = True,
                     ambiguous: Optional[np.ndarray] = None,
-                    q_group_bounds: Optional[Sequence[Tuple[int, int]]] = None) -> None:
+                    q_group_bounds: Optional[Sequence[Tuple[int, int]]] = None,
+                    wave_filter=None) -> None:
     """include/vorta_hip.h vorta_attn_fwd_fp8 for ONE head: q,k,v (rows,D) decoded e4m3 values, `out` (rows,D) is
     written in place (rows named by q_rows / dup_rows only).  kv_rows: (n_kv,) or (n_groups, n_kv).
     `ambiguous` (rows,) float, optional: per output row, the total normalised probability of the keys whose e4m3
     rounding is within fp32 noise of a midpoint (see `_fp8_flash_rows`; 0 for most rows, inf where a reference point
     is in doubt).  Each of those may move by one e4m3 step (<= 2^-3 relative), so a correct kernel differs from this
-    restatement by at most 2^-3 * that * (|v| + |o|) on top of its accumulation error."""
+    restatement by at most 2^-3 * that * (|v| + |o|) on top of its accumulation error.
+    `wave_filter(group, first_position_in_group) -> bool`, optional: restate only the waves it accepts (sampled checks at
+    sizes where every wave would take hours); rows of the other waves are left untouched."""
     q_valid = n_q if q_valid is None else q_valid
     glen = q_group_len if q_group_len > 0 else n_q
     if q_group_bounds is None:  # equal groups; else [start, end) of every group (vorta_attn_args.q_block_table)
@@ -564,8 +567,12 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
             kr = kv_row_offset + np.arange(n_kv)
         else:
             kr = (kv_rows[g] if kv_rows.ndim == 2 else kv_rows)[:n_kv]
+        if wave_filter is not None and not any(wave_filter(g, w0) for w0 in range(0, len(pos), 32)):
+            continue
         Kg, Vg = k[kr], v[kr]
         for w0 in range(0, len(pos), 32):  # one wave = 32 consecutive positions of the group
+            if wave_filter is not None and not wave_filter(g, w0):
+                continue
             sl = slice(w0, min(w0 + 32, len(pos)))
             Qw = q[rows[sl]]
             parts, ambs = [], []

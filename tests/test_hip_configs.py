@@ -284,8 +284,8 @@ def test_hunyuan_129f_fp8pv_one_rank_of_eight_at_full_size():
     """Precision "fp8pv" (16-bit scores, e4m3 P V) on the headline geometry through the Ulysses receive layout of a rank of
     8: v is converted the way the exchange does it -- per-(head, channel) abs-max taken shard by shard (P calls that only
     raise the maximum) and one conversion with the whole-sequence scales into the e4m3 receive buffer -- q and k are read as
-    they landed.  Keys with a 3-sigma common component and a peaked softmax (q, k x 1.5): >= 45 dB over max|x| per expert
-    against the fp16 kernels, valid text rows included; padded text rows exactly zero."""
+    they landed.  Keys with a 3-sigma common component and a peaked softmax (q, k x 1.5): >= 55 dB over max|x| per expert on
+    the video rows, >= 42 dB on the valid text rows, against the fp16 kernels; padded text rows exactly zero."""
     import math
     from vorta_amd import ops
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
@@ -342,3 +342,85 @@ def test_hunyuan_129f_fp8pv_one_rank_of_eight_at_full_size():
           {n: round(p, 2) for n, p in table.items()})
     # (the 96 valid text queries attend every key: a flat softmax over 118 896 keys, the e4m3 noise of P and V averages least)
     assert all(v >= (55.0 if n.endswith("video") else 42.0) for n, v in table.items()), table
+
+
+@pytest.mark.parametrize("precision", ["fp8", "fp8pv"])
+@pytest.mark.parametrize("config", ["wan14b-81f", "hunyuan-129f"])
+def test_fp8_headline_sizes_sampled_waves_vs_oracle_emulator(config, precision):
+    """The e4m3 kernels at the sizes that matter against the ORACLE (not against the 16-bit kernels): one head per expert
+    over the whole sequence of BASELINE configs[4] (Wan-2.1 14B 81x720x1280, S = 75 600) and of the headline geometry
+    (HunyuanVideo 129f, S = 118 800 + 256 text rows, 96 valid), the routed op as the processors call it (fused grid),
+    then sampled waves -- 32 consecutive query positions, the unit that shares reference-point decisions -- of every
+    launch restated by oracle.fp8_attn_launch on the kernel's own e4m3 operands, rounding point for rounding point
+    (same tolerance rule as tests/test_hip_fp8.py at small sizes).  precision "fp8pv": the mixed kernel (16-bit scores,
+    e4m3 P V) the same way, on the operands tests/test_hip_mx.py gives the emulator."""
+    import test_hip_fp8 as F
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    if config == "wan14b-81f":
+        model, latent, tile, group, T, te, dtype = "wan", (21, 45, 80), (7, 9, 8), (3, 3, 2), 0, 0, torch.bfloat16
+    else:
+        model, latent, tile, group, T, te, dtype = "hunyuan", (33, 45, 80), (11, 9, 8), (3, 3, 2), 256, 96, torch.float16
+    S = latent[0] * latent[1] * latent[2]
+    experts = [0, 1, 2]
+    q, k, v = (_rand((1, 3, S + T, 128), 900 + i, dtype) for i in range(3))
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
+    if precision == "fp8":
+        f8 = ops.fp8_quantize_qkv(q[0], k[0], v[0], center_k=True)
+        out = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, model=model, text_len=T,
+                               text_valid=te, fp8=True, fp8_operands=f8)
+        torch.cuda.synchronize()
+        q8, k8, v8, vd = F._decoded(f8)
+    else:
+        import test_hip_mx as M
+        out = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, model=model, text_len=T,
+                               text_valid=te, fp8="fp8pv")
+        torch.cuda.synchronize()
+        v8_, vd_, _ = ops.fp8_quantize_v(v[0])
+        q8, k8, v8, vd = M._operands(q[0], k[0], v8_, vd_, dtype)
+    N = S + T
+    ref, amb = np.zeros((3, N, 128)), np.full((3, N), np.nan)
+    gen = np.random.default_rng(7)
+
+    def some(n_groups_lens, n):
+        """n random (group, first position) pairs of a launch whose groups have the given lengths"""
+        picks = set()
+        while len(picks) < n:
+            g = int(gen.integers(len(n_groups_lens)))
+            picks.add((g, 32 * int(gen.integers(-(-n_groups_lens[g] // 32)))))
+        return lambda g, w0: (g, w0) in picks
+
+    # full expert: one group of S + T positions (the last waves hold the text rows)
+    nq = S + T
+    picks = some([nq], 5)
+    last = ((S + te - 1) // 32) * 32  # the wave with the last valid text row / last video rows
+    O.fp8_attn_launch(q8[0], k8[0], v8[0], ref[0], vd[0], n_q=nq, n_kv=S + te, q_valid=S + te, ambiguous=amb[0],
+                      wave_filter=lambda g, w0: picks(g, w0) or w0 == last)
+    # coreset expert
+    hl = torch.tensor([1], dtype=torch.int32, device=dev())
+    keep_q, drop_q = ops.coreset_select(q[0], geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T, head_list=hl)
+    keep_k = keep_q if model == "wan" else ops.coreset_select(k[0], geom.latent, geom.group, geom.n_keep, tail_first=S,
+                                                              n_tail=te, head_list=hl, want_drop=False)[0]
+    nql = geom.S_low + T
+    picks = some([nql], 5)
+    O.fp8_attn_launch(q8[1], k8[1], v8[1], ref[1], vd[1], n_q=nql, n_kv=geom.S_low + te, q_valid=geom.S_low + te,
+                      q_rows=keep_q[0].cpu().numpy(), kv_rows=keep_k[0].cpu().numpy(), dup_rows=drop_q[0].cpu().numpy(),
+                      n_dup_pos=geom.G, ambiguous=amb[1], wave_filter=lambda g, w0: picks(g, w0) or w0 == 0)
+    # sliding-tile expert (query tiles of equal key lists merged, as vorta_amd/routed.py launches them)
+    q_rows, kv_rows, n_kv, table, n_lists = geom.sta_launch_tables(te, 256)
+    qr, kr, tb = q_rows.cpu().numpy(), kv_rows.cpu().numpy(), table.cpu().numpy()
+    bounds = [(int(tb[tb[:, 0] == g, 1].min()), int(tb[tb[:, 0] == g, 2].max())) for g in range(n_lists)]
+    O.fp8_attn_launch(q8[2], k8[2], v8[2], ref[2], vd[2], n_q=S, n_kv=n_kv, q_rows=qr, kv_rows=kr, q_group_bounds=bounds,
+                      ambiguous=amb[2], wave_filter=some([b[1] - b[0] for b in bounds], 12))
+    if T:
+        # inside the fused grid the text launch of the sliding expert is unsplit (vorta_amd/routed.py FUSED_TEXT_SPLITS)
+        O.fp8_attn_launch(q8[2], k8[2], v8[2], ref[2], vd[2], n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te,
+                          n_splits=1, ambiguous=amb[2], wave_filter=lambda g, w0: w0 in (0, 64))
+    o = out[0].float().cpu().numpy()
+    vmax = F._vmax(v8, vd)
+    for h in range(3):
+        sel = ~np.isnan(amb[h])
+        assert sel.sum() >= 32 * 5, (h, sel.sum())
+        F._check(torch.from_numpy(o[h][sel]), ref[h][sel], dtype, amb[h][sel], vmax)
+    if T:
+        assert torch.all(out[0, :, S + te:] == 0)
