@@ -35,52 +35,66 @@ __device__ __forceinline__ float q16_sum(float v) {
   return v;
 }
 
-template <typename T>
-__device__ __forceinline__ void rope8(float (&y)[8], const NParams& p, int token, int d0) {
-  const float* c = p.cs + (int64_t)token * 128 + d0;
-  const float* s = p.sn + (int64_t)token * 128 + d0;
-  const f32x4 c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
-  const f32x4 s0 = *(const f32x4*)s, s1 = *(const f32x4*)(s + 4);
-  const float cc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-  const float ss[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-  float o[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    o[2 * i] = y[2 * i] * cc[2 * i] - y[2 * i + 1] * ss[2 * i];
-    o[2 * i + 1] = y[2 * i + 1] * cc[2 * i + 1] + y[2 * i] * ss[2 * i + 1];
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) y[i] = o[i];
-}
-
-// per-head normalisation (HunyuanVideo): one quarter wave per (token, head) row, heads fastest
+// per-head normalisation (HunyuanVideo): a 16-lane quarter wave owns one token and every fourth head of it.  The token's
+// cos / sin (2 x 512 B of fp32, the same for all its heads) are read ONCE into registers -- read per (token, head) row
+// they were 4 x the bytes of the row itself through the vector cache -- and the head rows are loaded UNR at a time before
+// the first is touched.  Same box, Hunyuan-129f q (1.46 GB read + write): 4.3 -> 5.0-5.25 TB/s (tools/bench_norm_rope.py,
+// profiles/r03_norm_rope_quantizer_bandwidth.txt).
 template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_rope_head_kernel(const NParams p) {
   typedef __attribute__((ext_vector_type(8))) T V8;
-  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  constexpr int UNR = 6;  // 24 heads: every quarter wave's six rows in flight at once (3: 4.9, 6: 5.0-5.25 TB/s)
   const int sub = threadIdx.x & 15;
-  if (row >= (int64_t)p.n_tokens * p.heads) return;
-  const int token = (int)(row / p.heads), head = (int)(row - (int64_t)token * p.heads);
-  char* xp = p.x + (int64_t)head * p.x_sh + (int64_t)(p.token_offset + token) * p.x_ss + sub * 16;
-  const V8 xv = *(const V8*)xp;
-  float y[8], ss = 0.f;
+  const int qw = threadIdx.x >> 4;
+  const int token = blockIdx.x * 4 + (qw >> 2);
+  const int hq = qw & 3;
+  if (token >= p.n_tokens) return;
+  const bool rot = p.cs && token < p.rope_tokens;
+  float cc[8], sn[8];
+  if (rot) {
+    const float* c = p.cs + (int64_t)token * 128 + sub * 8;
+    const float* s = p.sn + (int64_t)token * 128 + sub * 8;
+    const f32x4 c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
+    const f32x4 s0 = *(const f32x4*)s, s1 = *(const f32x4*)(s + 4);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { y[i] = (float)xv[i]; ss += y[i] * y[i]; }
-  ss = q16_sum(ss);
-  const float r = rsqrtf(ss * (1.f / 128.f) + p.eps);
+    for (int i = 0; i < 4; ++i) { cc[i] = c0[i]; cc[4 + i] = c1[i]; sn[i] = s0[i]; sn[4 + i] = s1[i]; }
+  }
+  float wf[8];
   if (p.w) {
     const V8 wv = *(const V8*)((const char*)p.w + sub * 16);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = y[i] * r * (float)wv[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] *= r;
+    for (int i = 0; i < 8; ++i) wf[i] = (float)wv[i];
   }
-  if (p.cs && token < p.rope_tokens) rope8<T>(y, p, token, sub * 8);
-  V8 ov;
+  char* base = p.x + (int64_t)(p.token_offset + token) * p.x_ss + sub * 16;
+  for (int h0 = hq; h0 < p.heads; h0 += 4 * UNR) {
+    V8 xv[UNR];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ov[i] = (T)y[i];
-  *(V8*)xp = ov;
+    for (int j = 0; j < UNR; ++j)
+      if (h0 + 4 * j < p.heads) xv[j] = *(const V8*)(base + (int64_t)(h0 + 4 * j) * p.x_sh);
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      if (h0 + 4 * j >= p.heads) break;
+      float y[8], ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { y[i] = (float)xv[j][i]; ss += y[i] * y[i]; }
+      ss = q16_sum(ss);
+      const float r = rsqrtf(ss * (1.f / 128.f) + p.eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = p.w ? y[i] * r * wf[i] : y[i] * r;
+      V8 ov;
+      if (rot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ov[2 * i] = (T)(y[2 * i] * cc[2 * i] - y[2 * i + 1] * sn[2 * i]);
+          ov[2 * i + 1] = (T)(y[2 * i + 1] * cc[2 * i + 1] + y[2 * i] * sn[2 * i + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = (T)y[i];
+      }
+      *(V8*)(base + (int64_t)(h0 + 4 * j) * p.x_sh) = ov;
+    }
+  }
 }
 
 // normalisation across all heads of a token (Wan): one wave per token, values kept in registers
@@ -91,16 +105,28 @@ __global__ __launch_bounds__(256) void qk_norm_rope_token_kernel(const NParams p
   const int token = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (token >= p.n_tokens) return;
   const int chunks = p.heads * 16;  // 16-byte chunks per token
-  float y[MAXIT][8];
+  // chunk c = it * 64 + lane of the token is channels 8 (lane & 15) .. +8 of head c >> 4: a lane meets the same channels in
+  // every one of its chunks, so its cos / sin are read once
+  const bool rot = p.cs && token < p.rope_tokens;
+  float cc[8], sn[8];
+  if (rot) {
+    const float* c = p.cs + (int64_t)token * 128 + (lane & 15) * 8;
+    const float* s = p.sn + (int64_t)token * 128 + (lane & 15) * 8;
+    const f32x4 c0 = *(const f32x4*)c, c1 = *(const f32x4*)(c + 4);
+    const f32x4 s0 = *(const f32x4*)s, s1 = *(const f32x4*)(s + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { cc[i] = c0[i]; cc[4 + i] = c1[i]; sn[i] = s0[i]; sn[4 + i] = s1[i]; }
+  }
+  V8 xv[MAXIT];  // the token stays in registers in its 16-bit form (half the registers of fp32 copies: more waves per SIMD)
   float ss = 0.f;
 #pragma unroll
   for (int it = 0; it < MAXIT; ++it) {
     const int c = it * 64 + lane;
     if (c < chunks) {
       const int head = c >> 4, sub = c & 15;
-      const V8 xv = *(const V8*)(p.x + (int64_t)head * p.x_sh + (int64_t)(p.token_offset + token) * p.x_ss + sub * 16);
+      xv[it] = *(const V8*)(p.x + (int64_t)head * p.x_sh + (int64_t)(p.token_offset + token) * p.x_ss + sub * 16);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { y[it][i] = (float)xv[i]; ss += y[it][i] * y[it][i]; }
+      for (int i = 0; i < 8; ++i) { const float f = (float)xv[it][i]; ss += f * f; }
     }
   }
 #pragma unroll
@@ -111,18 +137,26 @@ __global__ __launch_bounds__(256) void qk_norm_rope_token_kernel(const NParams p
     const int c = it * 64 + lane;
     if (c < chunks) {
       const int head = c >> 4, sub = c & 15;
+      float y[8];
       if (p.w) {
         const V8 wv = *(const V8*)((const char*)p.w + (int64_t)c * 16);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) y[it][i] = y[it][i] * r * (float)wv[i];
+        for (int i = 0; i < 8; ++i) y[i] = (float)xv[it][i] * r * (float)wv[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) y[it][i] *= r;
+        for (int i = 0; i < 8; ++i) y[i] = (float)xv[it][i] * r;
       }
-      if (p.cs && token < p.rope_tokens) rope8<T>(y[it], p, token, sub * 8);
       V8 ov;
+      if (rot) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) ov[i] = (T)y[it][i];
+        for (int i = 0; i < 4; ++i) {
+          ov[2 * i] = (T)(y[2 * i] * cc[2 * i] - y[2 * i + 1] * sn[2 * i]);
+          ov[2 * i + 1] = (T)(y[2 * i + 1] * cc[2 * i + 1] + y[2 * i] * sn[2 * i + 1]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = (T)y[i];
+      }
       *(V8*)(p.x + (int64_t)head * p.x_sh + (int64_t)(p.token_offset + token) * p.x_ss + sub * 16) = ov;
     }
   }
@@ -131,8 +165,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_token_kernel(const NParams p
 template <typename T>
 int launch(const NParams& p, hipStream_t st) {
   if (!p.across_heads) {
-    const int64_t rows = (int64_t)p.n_tokens * p.heads;
-    hipLaunchKernelGGL(qk_norm_rope_head_kernel<T>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(qk_norm_rope_head_kernel<T>, dim3((unsigned)((p.n_tokens + 3) / 4)), dim3(256), 0, st, p);
   } else {
     const unsigned blocks = (unsigned)((p.n_tokens + 3) / 4);
     const int its = (p.heads * 16 + 63) / 64;
