@@ -303,22 +303,36 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
   }
   const char* src = p.x[which] + (int64_t)hphys * p.x_sh[which] + cc * 32;
   char* dst = p.y[which] + (int64_t)hphys * p.y_sh[which] + cc * 16;
-  for (int r = r0 + rl; r < r1; r += 32) {
-    const T8 a = *(const T8*)(src + (int64_t)r * p.x_ss[which]);
-    const T8 b = *(const T8*)(src + (int64_t)r * p.x_ss[which] + 16);
-    float f[16];
+  // UNR row passes in flight per thread (one pass in flight: 4.9 TB/s over q, k, v of Hunyuan-129f)
+  constexpr int UNR = 4;
+  for (int rb = r0 + rl; rb < r1; rb += 32 * UNR) {
+    T8 a[UNR], b[UNR];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      f[i] = clamp448((to_f(a[i]) - sub[i]) * mul[i]);
-      f[8 + i] = clamp448((to_f(b[i]) - sub[8 + i]) * mul[8 + i]);
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rb + 32 * u;
+      if (r < r1) {
+        a[u] = *(const T8*)(src + (int64_t)r * p.x_ss[which]);
+        b[u] = *(const T8*)(src + (int64_t)r * p.x_ss[which] + 16);
+      }
     }
-    u32x4 o;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
-      o[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], lo, true);
+    for (int u = 0; u < UNR; ++u) {
+      const int r = rb + 32 * u;
+      if (r >= r1) break;
+      float f[16];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f[i] = clamp448((to_f(a[u][i]) - sub[i]) * mul[i]);
+        f[8 + i] = clamp448((to_f(b[u][i]) - sub[8 + i]) * mul[8 + i]);
+      }
+      u32x4 o;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w], f[4 * w + 1], 0, false);
+        o[w] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(f[4 * w + 2], f[4 * w + 3], lo, true);
+      }
+      *(u32x4*)(dst + (int64_t)r * p.y_ss[which]) = o;
     }
-    *(u32x4*)(dst + (int64_t)r * p.y_ss[which]) = o;
   }
 }
 
