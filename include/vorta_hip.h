@@ -31,9 +31,11 @@ extern "C" {
 #define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
 #define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
 
-#define VORTA_ABI_VERSION 4 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
+#define VORTA_ABI_VERSION 5 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
                                 4: vorta_fp8_quant_args gains slot_first / slot_count and flags bit2, adds vorta_fp8_v_absmax /
-                                vorta_fp8_v_convert; every earlier call means what it meant */
+                                vorta_fp8_v_convert; every earlier call means what it meant
+                                5: vorta_fp8_quant_args gains video_tokens / token_offset / total_tokens / src_map and flags
+                                bit3 / bit4 (sequence shards), adds vorta_fp8_quant_ws_partials */
 
 typedef enum vorta_dtype {
   VORTA_BF16 = 0,
@@ -188,8 +190,26 @@ typedef struct vorta_fp8_quant_args {
   int32_t slot_count;       /* slot group whose exchange has landed while the next one is in flight (0, 0 = every slot).
                                Scales and centres are per head, so converting slot group by slot group gives the bytes
                                one call over all slots gives */
+  int32_t video_tokens;     /* seg_len == 0: tokens [0, video_tokens) of a head's sequence are its video tokens, the rest its
+                               tail (text) tokens; 0 = all of them.  The sample of flags bit1 and of the q/k abs-max is summed
+                               in 8 equal ranges of the video tokens + the tail, so pass the same value wherever the same
+                               heads are converted (the segmented layout derives it from tail_first) */
+  int32_t token_offset;     /* seg_len == 0, sequence shards (flags bit3 / bit4): the views hold tokens [token_offset, */
+  int32_t total_tokens;     /* token_offset + n_tokens) of heads whose whole sequence has total_tokens tokens (0: the views
+                               are the whole sequence) */
+  const int32_t* src_map;   /* seg_len == 0, optional: q8 / k8 / v8 head h <- head src_map[h] of q / k / v, with that head's
+                               scales and centre (the heads in destination order for the exchange) */
 } vorta_fp8_quant_args;
-/* flags bit2: q and k only -- v, v8 and v_descale are not touched (v arrived as e4m3: vorta_fp8_v_convert on the sender) */
+/* flags bit2: q and k only -- v, v8 and v_descale are not touched (v arrived as e4m3: vorta_fp8_v_convert on the sender)
+ * flags bit3: statistics only -- the sample partials of the tokens this call holds go to their slots of `ws`, nothing is
+ *             converted.  Zero the partial region first (vorta_fp8_quant_ws_partials), call once per piece of the sequence
+ *             (a shard must hold whole eighths of the video tokens: token_offset and n_tokens multiples of video_tokens / 8;
+ *             the tail tokens in a call of their own), ADD the regions of all ranks (disjoint slots: exact);
+ * flags bit4: no statistics -- multipliers and centres from the partials already in `ws`, then the conversion of the tokens
+ *             this call holds.  bit3 calls + all-reduce + bit4 calls write the bytes ONE plain call over the assembled
+ *             sequence writes: the send side of the Ulysses exchange moves q and k as e4m3 (vorta/ulysses/utils.py:61-91
+ *             moves them in 16 bits). */
+int vorta_fp8_quant_ws_partials(int32_t heads, int32_t head_dim, int64_t* first_float, int64_t* n_floats);
 
 int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim);
 int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* args, void* hip_stream);

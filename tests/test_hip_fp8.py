@@ -112,7 +112,8 @@ def test_quantizer_key_centring_and_segmented_rows(dtype):
     qd, kd, vd = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
     kr = rounded(k, dtype)
     # (H,S,D) layout, centred: the centre is the mean of the oracle's sample rows; everything else bit for bit
-    f8 = ops.fp8_quantize_qkv(qd, kd, vd, center_k=True)
+    # (`video_tokens`: the sample is summed in eighths of the video tokens + the text tokens, in either layout)
+    f8 = ops.fp8_quantize_qkv(qd, kd, vd, center_k=True, video_tokens=S)
     c = f8.k_center().cpu().numpy()
     rows = O.fp8_center_rows(S + T, Hl)
     want = np.stack([kr[h, rows[h]].mean(0) for h in range(Hl)])
@@ -496,3 +497,47 @@ def test_fp8_operator_psnr_on_structured_inputs(geometry):
             for h in (0, 2):  # (the coreset ranking itself changes under the rescaling: not comparable)
                 gain = psnr(out2[0, h, :S + te], ref2[0, h, :S + te])[1] - table[experts[h]][1]
                 assert abs(gain) < 2.5, (geometry, experts[h], gain)
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+@pytest.mark.parametrize("T", [0, 96])
+def test_quantizer_sequence_shards_write_the_bytes_of_one_call(P, T):
+    """The send side of the exchange converts q and k shard by shard (include/vorta_hip.h flags bit3 / bit4): every rank
+    adds the sample partials of its tokens to a table (here: P calls into one zeroed table = the SUM all-reduce of P
+    tables with disjoint slots), then converts its shard with the scales of the whole sequence, heads in destination
+    order.  The bytes are those of ONE plain call over the assembled (H, S + T, D) sequence, bit for bit."""
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    H, S = 5, 8 * 520  # shards of S / P tokens hold whole eighths of the video tokens
+    gen = torch.Generator(device=dev()).manual_seed(11 + P + T)
+    q, k, v = (torch.randn((H, S + T, 128), generator=gen, device=dev()).to(dtype) for _ in range(3))
+    k = (k.float() + 2.0 * torch.randn((H, 1, 128), generator=gen, device=dev())).to(dtype)  # a centre worth subtracting
+    whole = ops.fp8_quantize_qkv(q, k, v, center_k=True, video_tokens=S)
+    order = torch.tensor([3, 0, 4, 1, 2], dtype=torch.int32, device=dev())
+    Sl = S // P
+    nws = whole.ws.numel()
+    ws = torch.full((nws,), 7.0, dtype=torch.float32, device=dev())  # stale contents everywhere but the zeroed partials
+    part = ops.fp8_ws_partials(ws, H)
+    part.zero_()
+    dummy = torch.empty((H, 1, 128), dtype=torch.uint8, device=dev())
+    shards = [(q[:, r * Sl:(r + 1) * Sl], k[:, r * Sl:(r + 1) * Sl]) for r in range(P)]
+    for r, (qs, ks) in enumerate(shards):
+        ops.fp8_quantize_qkv(qs, ks, None, out=ops.Fp8Operands(dummy, dummy, dummy, whole.v_descale, ws), center_k=True,
+                             phase="stats", token_offset=r * Sl, total_tokens=S + T, video_tokens=S)
+    if T:
+        ops.fp8_quantize_qkv(q[:, S:], k[:, S:], None, out=ops.Fp8Operands(dummy, dummy, dummy, whole.v_descale, ws),
+                             center_k=True, phase="stats", token_offset=S, total_tokens=S + T, video_tokens=S)
+    assert torch.equal(part, ops.fp8_ws_partials(whole.ws, H))  # the partial tables agree slot for slot
+    q8 = torch.zeros((H, S + T, 128), dtype=torch.uint8, device=dev())
+    k8 = torch.zeros_like(q8)
+    pieces = [(qs, ks, r * Sl, slice(r * Sl, (r + 1) * Sl)) for r, (qs, ks) in enumerate(shards)]
+    if T:
+        pieces.append((q[:, S:], k[:, S:], S, slice(S, S + T)))
+    for qs, ks, off, sl in pieces:
+        ops.fp8_quantize_qkv(qs, ks, None, out=ops.Fp8Operands(q8[:, sl], k8[:, sl], dummy, whole.v_descale, ws),
+                             center_k=True, phase="convert", token_offset=off, total_tokens=S + T, video_tokens=S,
+                             src_map=order)
+    torch.cuda.synchronize()
+    o = order.long()
+    assert torch.equal(q8, whole.q[o]) and torch.equal(k8, whole.k[o])
+    # and the receive layout's conversion (what the 16-bit wire does today) still writes the same bytes for Wan (T = 0)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvo
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
 VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3 = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _i32, _i64, _u32, _f32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
 
@@ -101,6 +101,7 @@ class Fp8QuantArgs(C.Structure):
         ("q", Tensor), ("k", Tensor), ("v", Tensor), ("q8", Tensor), ("k8", Tensor), ("v8", Tensor),
         ("v_descale", _vp), ("ws", _vp), ("flags", _i32), ("seg_len", _i32), ("tail_first", _i32), ("tail_len", _i32),
         ("slot_first", _i32), ("slot_count", _i32),
+        ("video_tokens", _i32), ("token_offset", _i32), ("total_tokens", _i32), ("src_map", _vp),
     ]
 
 
@@ -125,6 +126,7 @@ SYMBOLS = {
     "vorta_attn_plan": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i32)]),
     "vorta_attn_workspace_bytes": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vorta_fp8_quant_ws_floats": (C.c_int, [_i32, _i32]),
+    "vorta_fp8_quant_ws_partials": (C.c_int, [_i32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
     "vorta_fp8_quantize_qkv": (C.c_int, [C.POINTER(Fp8QuantArgs), _vp]),
     "vorta_fp8_v_absmax": (C.c_int, [C.POINTER(Fp8VArgs), _vp]),
     "vorta_fp8_v_convert": (C.c_int, [C.POINTER(Fp8VArgs), _vp]),

@@ -8,6 +8,11 @@
 // (tools/dbg/fp8_kbias.py: a mean of 3 / 8 standard deviations costs 6 / 12 dB of output PSNR; centring gives all of it
 // back).  ANY vector c works, so c[h][d] is the mean of <= ~1024 evenly spaced key TOKENS of the head (the same tokens in
 // either row layout below): one small launch, fixed summation order (deterministic), no extra pass over K.
+// The sample is summed in SAMPLE_CHUNKS equal ranges of the head's video tokens plus one slot for its tail (text) tokens,
+// one workgroup each, combined in slot order: a sequence shard that holds whole chunks computes exactly the partials the
+// whole sequence would, so P ranks (P | SAMPLE_CHUNKS) that each hold Sv/P tokens of every head -- the send side of the
+// Ulysses exchange -- add their partial tables (flags bit3, disjoint slots: the sum is exact) and convert their shards
+// (flags bit4) to the bytes one call over the assembled sequence writes: q and k cross the links as e4m3.
 //
 // Row layouts: (heads, n_tokens, D) views (seg_len = 0), or ONE row array of n_tokens rows in which row r belongs to head
 // (r / seg_len) % heads (seg_len > 0: the Ulysses receive buffer, ulysses/engine.py -- each rank head keeps its own
@@ -36,7 +41,8 @@ constexpr int D = 128;
 constexpr float V_TARGET = 240.f;  // amax of a v channel maps here (e4m3 max 448; relative precision is range-independent)
 constexpr float E4M3_MAX = 448.f;
 constexpr int MEAN_SAMPLES = 1024;  // key rows per head that define the centre (approximately: see fp8_kmean_kernel)
-constexpr int MEAN_BLOCKS = 8;      // workgroups per head that sum them (partial sums, combined in a fixed order)
+constexpr int SAMPLE_CHUNKS = 8;    // equal ranges of a head's video tokens whose samples are summed apart
+constexpr int MEAN_BLOCKS = SAMPLE_CHUNKS + 1;  // + the tail (text) tokens: workgroups per head, partials combined in slot order
 
 struct QParams {
   const char* x[3]; int64_t x_sh[3], x_ss[3];  // inputs (bytes)
@@ -45,7 +51,10 @@ struct QParams {
   int seg_len, chunks_per_seg;                 // segmented row layout (seg_len > 0)
   int tail_first, tail_len;                    // segments from row tail_first on hold tail_len rows of data each
   int mean_stride, mean_cand;                  // tokens of the centre: s = i * mean_stride, i < mean_cand (per head)
-  int64_t video_tokens;                        // segmented layout: tokens of a head that live in the non-tail segments
+  int64_t video_tokens;                        // tokens of a head before its tail (text) tokens: what the sample's chunks cut
+  int64_t total_tokens;                        // tokens of a head's whole sequence (sample stride)
+  int64_t token_offset;                        // seg_len == 0: the views hold tokens [token_offset, token_offset + n_tokens)
+  const int32_t* src_map;                      // seg_len == 0, convert: output head h <- input head src_map[h]
   float c0;  // qk_scale * log2(e)
   float* ws; float* v_descale;
   int v_per_head, center_k;
@@ -93,11 +102,13 @@ __device__ __forceinline__ void block_rows(const QParams& p, int& r0, int& r1, i
 }
 
 // grid (heads, MEAN_BLOCKS), 1024 threads: the head's SAMPLE -- its tokens s = i * mean_stride (i < mean_cand), the same
-// tokens whether the head is a (S,D) view or scattered over the segments of the Ulysses receive layout (so a head gets the
-// same centre and multipliers, hence the same e4m3 bytes, on one GPU and on a rank of P).  Per block: partial sums of the
-// sampled key rows (the centre), per-channel max / min of them (abs-max of k minus ANY centre follows exactly), abs-max of
-// the sampled q rows.  64 row lanes x 16 channel groups, four rows in flight per lane; fixed reduction order here and in
-// `kcenter` (deterministic).
+// tokens whether the head is a (S,D) view, a sequence shard of one, or scattered over the segments of the Ulysses receive
+// layout (so a head gets the same centre and multipliers, hence the same e4m3 bytes, on one GPU and on a rank of P).
+// Workgroup (h, b) owns the sampled tokens of chunk b (b < SAMPLE_CHUNKS: video tokens [b Sv / C, (b+1) Sv / C); b = C: the
+// tail tokens) and writes their partials -- sums of the key rows (the centre), per-channel max / min of them (abs-max of k
+// minus ANY centre follows exactly), abs-max of the q rows -- unless the call's views do not hold that chunk (a shard:
+// another call, or another rank, owns it).  64 row lanes x 16 channel groups, four rows in flight per lane, lanes by
+// position INSIDE the chunk; fixed reduction order here and in `kcenter` (deterministic).
 template <typename T>
 __global__ __launch_bounds__(1024) void fp8_sample_kernel(const QParams p) {
   typedef __attribute__((ext_vector_type(8))) T T8;
@@ -111,20 +122,27 @@ __global__ __launch_bounds__(1024) void fp8_sample_kernel(const QParams p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; kmx[i] = -3.0e38f; kmn[i] = 3.0e38f; }
   int cnt = 0;
-  const int n_cand = p.mean_cand;
-  // physical row of token s of head h
+  // sample indices of this chunk: tokens [t0, t1)
+  const int b = blockIdx.y;
+  const int64_t t0 = b < SAMPLE_CHUNKS ? (int64_t)b * p.video_tokens / SAMPLE_CHUNKS : p.video_tokens;
+  const int64_t t1 = b < SAMPLE_CHUNKS ? (int64_t)(b + 1) * p.video_tokens / SAMPLE_CHUNKS : p.total_tokens;
+  // a chunk that is not wholly inside this call's views belongs to another call (its slot is left alone)
+  if (p.seg_len <= 0 && (t0 < p.token_offset || t1 > p.token_offset + p.n_tokens)) return;
+  const int i_lo = (int)((t0 + p.mean_stride - 1) / p.mean_stride);
+  const int i_hi = (int)min((int64_t)p.mean_cand, (t1 + p.mean_stride - 1) / p.mean_stride);
+  // physical row of sample i of head h
   auto row_of = [&](int i) -> int64_t {
     const int64_t tok = (int64_t)i * p.mean_stride;
-    if (p.seg_len <= 0) return tok;
+    if (p.seg_len <= 0) return tok - p.token_offset;
     if (tok < p.video_tokens) return ((tok / p.seg_len) * p.heads + h) * p.seg_len + tok % p.seg_len;
     return (int64_t)p.tail_first + (int64_t)h * p.seg_len + (tok - p.video_tokens);
   };
-  for (int i0 = blockIdx.y * 4 * RL + rl; i0 < n_cand; i0 += MEAN_BLOCKS * 4 * RL) {
+  for (int i0 = i_lo + rl; i0 < i_hi; i0 += 4 * RL) {
     T8 v[4], w[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      ok[u] = i0 + u * RL < n_cand;
+      ok[u] = i0 + u * RL < i_hi;
       if (ok[u]) {
         const int64_t r = row_of(i0 + u * RL);
         v[u] = *(const T8*)(base + r * p.x_ss[1]);
@@ -176,7 +194,7 @@ __global__ __launch_bounds__(1024) void fp8_sample_kernel(const QParams p) {
   if (t < D) {
     float a = -3.0e38f;
     for (int j = 0; j < RL; ++j) a = fmaxf(a, red[j][t]);
-    kmaxp_of(p)[part * D + t] = a;
+    kmaxp_of(p)[part * D + t] = i_hi > i_lo ? a : 0.f;  // an empty chunk writes zeros: partial tables of several ranks ADD
   }
   __syncthreads();
 #pragma unroll
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(1024) void fp8_sample_kernel(const QParams p) {
   if (t < D) {
     float a = 3.0e38f;
     for (int j = 0; j < RL; ++j) a = fminf(a, red[j][t]);
-    kminp_of(p)[part * D + t] = a;
+    kminp_of(p)[part * D + t] = i_hi > i_lo ? a : 0.f;
   }
 }
 
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(128) void fp8_scales_kernel(const QParams p) {
   float kmx = -3.0e38f, kmn = 3.0e38f;
 #pragma unroll
   for (int b = 0; b < MEAN_BLOCKS; ++b) {
+    if (kcnt_of(p)[h * MEAN_BLOCKS + b] <= 0.f) continue;  // no sampled token in this chunk
     kmx = fmaxf(kmx, kmaxp_of(p)[((int64_t)h * MEAN_BLOCKS + b) * D + d]);
     kmn = fminf(kmn, kminp_of(p)[((int64_t)h * MEAN_BLOCKS + b) * D + d]);
   }
@@ -283,6 +302,8 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
   block_rows(p, r0, r1, h, hphys);
   if (r0 >= r1) return;
   const int t = threadIdx.x, cc = t & 7, rl = t >> 3;
+  const int hout = hphys;  // output head; with a source map the input head (and its scales) is src_map[hout]
+  if (p.src_map && p.seg_len <= 0) h = hphys = p.src_map[hout];
   const float* qmul = p.ws + 2 * H + H * D;
   float mul[16], sub[16];
 #pragma unroll
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
     }
   }
   const char* src = p.x[which] + (int64_t)hphys * p.x_sh[which] + cc * 32;
-  char* dst = p.y[which] + (int64_t)hphys * p.y_sh[which] + cc * 16;
+  char* dst = p.y[which] + (int64_t)hout * p.y_sh[which] + cc * 16;
   // UNR row passes in flight per thread (one pass in flight: 4.9 TB/s over q, k, v of Hunyuan-129f)
   constexpr int UNR = 4;
   for (int rb = r0 + rl; rb < r1; rb += 32 * UNR) {
@@ -344,6 +365,13 @@ extern "C" int vorta_fp8_quant_ws_floats(int32_t heads, int32_t head_dim) {
          2 * heads * MEAN_BLOCKS * head_dim + heads * MEAN_BLOCKS;
 }
 
+extern "C" int vorta_fp8_quant_ws_partials(int32_t heads, int32_t head_dim, int64_t* first_float, int64_t* n_floats) {
+  if (heads <= 0 || head_dim != D || !first_float || !n_floats) return VORTA_EINVAL;
+  *first_float = 2 * (2 * (int64_t)heads + (int64_t)heads * D) + (int64_t)heads * D;  // behind kmean
+  *n_floats = (int64_t)heads * MEAN_BLOCKS * (D + 1) + 2 * (int64_t)heads * MEAN_BLOCKS * D + (int64_t)heads * MEAN_BLOCKS;
+  return VORTA_OK;
+}
+
 extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_stream) {
   if (!a || a->struct_size != sizeof(vorta_fp8_quant_args)) return VORTA_EINVAL;
   if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
@@ -354,18 +382,31 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   if (a->slot_first < 0 || a->slot_count < 0 || (int64_t)a->slot_first + a->slot_count > a->heads) return VORTA_EINVAL;
   if ((a->slot_first || a->slot_count) && a->seg_len <= 0) return VORTA_EINVAL;  // a slot range needs the segmented layout
   if (a->heads == 0 || a->n_tokens == 0) return VORTA_OK;
+  const bool stats_only = a->flags & 8, no_stats = a->flags & 16;
+  if (stats_only && no_stats) return VORTA_EINVAL;
+  if (a->video_tokens < 0 || a->token_offset < 0 || a->total_tokens < 0) return VORTA_EINVAL;
+  if (a->seg_len > 0 && (a->video_tokens || a->token_offset || a->total_tokens || a->src_map || stats_only || no_stats))
+    return VORTA_EINVAL;  // shards, source maps and an explicit video length belong to the (heads, tokens, D) views
+  if ((a->token_offset || a->total_tokens) && !(stats_only || no_stats)) return VORTA_EINVAL;  // a shard alone has no scales
+  if (a->total_tokens && (int64_t)a->token_offset + a->n_tokens > a->total_tokens) return VORTA_EINVAL;
+  // the sample and v's abs-max of a plain call are taken per INPUT head: a source map needs the two-phase form or q, k only
+  if (a->src_map && !no_stats) return VORTA_EINVAL;
   const int n_which = (a->flags & 4) ? 2 : 3;
+  if ((stats_only || no_stats) && n_which == 3) return VORTA_EUNSUPPORTED;  // v has its own pair (vorta_fp8_v_absmax / _convert)
   if (!a->ws || (n_which == 3 && !a->v_descale) || !(a->qk_scale > 0.f)) return VORTA_EINVAL;
   const vorta_tensor* in[3] = {&a->q, &a->k, &a->v};
   const vorta_tensor* out[3] = {&a->q8, &a->k8, &a->v8};
   QParams p{};
   for (int i = 0; i < n_which; ++i) {
-    if (!in[i]->ptr || !out[i]->ptr) return VORTA_EINVAL;
+    if (!in[i]->ptr || (!stats_only && !out[i]->ptr)) return VORTA_EINVAL;
     if (((uintptr_t)in[i]->ptr & 15) || (in[i]->stride_s % 8) || (in[i]->stride_h % 8) || in[i]->stride_s < D) return VORTA_EINVAL;
-    if (((uintptr_t)out[i]->ptr & 15) || (out[i]->stride_s % 16) || (out[i]->stride_h % 16) || out[i]->stride_s < D) return VORTA_EINVAL;
     p.x[i] = (const char*)in[i]->ptr; p.x_sh[i] = in[i]->stride_h * 2; p.x_ss[i] = in[i]->stride_s * 2;
+    if (stats_only) continue;
+    if (((uintptr_t)out[i]->ptr & 15) || (out[i]->stride_s % 16) || (out[i]->stride_h % 16) || out[i]->stride_s < D) return VORTA_EINVAL;
     p.y[i] = (char*)out[i]->ptr; p.y_sh[i] = out[i]->stride_h; p.y_ss[i] = out[i]->stride_s;
   }
+  p.src_map = a->src_map;
+  p.token_offset = a->token_offset;
   p.heads = a->heads; p.n_tokens = a->n_tokens;
   p.c0 = a->qk_scale * 1.4426950408889634f;
   p.ws = a->ws; p.v_descale = a->v_descale;
@@ -400,21 +441,27 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
   }
   // centre: ~MEAN_SAMPLES evenly spaced tokens of the head (an odd stride: one that divides the segment length would
   // sample the same offsets of every segment)
-  int64_t head_tokens = a->n_tokens;
+  int64_t head_tokens = a->total_tokens ? a->total_tokens : a->n_tokens;
+  p.video_tokens = a->video_tokens ? a->video_tokens : head_tokens;
+  if (p.video_tokens > head_tokens) return VORTA_EINVAL;
   if (p.seg_len > 0) {
     const int64_t data_rows = has_tail ? (int64_t)a->tail_first : (int64_t)a->n_tokens;
     p.video_tokens = (data_rows / p.seg_len / H) * p.seg_len;
     head_tokens = p.video_tokens + p.tail_len;
   }
+  p.total_tokens = head_tokens;
   p.mean_stride = (int)(head_tokens / MEAN_SAMPLES);
   if (p.mean_stride < 1) p.mean_stride = 1;
   p.mean_stride |= 1;
   p.mean_cand = (int)((head_tokens + p.mean_stride - 1) / p.mean_stride);
   const bool bf = a->dtype == VORTA_BF16;
-  if (bf) hipLaunchKernelGGL((fp8_sample_kernel<__bf16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
-  else hipLaunchKernelGGL((fp8_sample_kernel<_Float16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
-  e = hipGetLastError();
-  if (e != hipSuccess) return vorta_set_hip_error(e);
+  if (!no_stats) {
+    if (bf) hipLaunchKernelGGL((fp8_sample_kernel<__bf16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((fp8_sample_kernel<_Float16>), dim3((unsigned)hn, MEAN_BLOCKS), dim3(1024), 0, st, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return vorta_set_hip_error(e);
+  }
+  if (stats_only) return VORTA_OK;
   if (n_which == 3) {
     if (bf) hipLaunchKernelGGL((fp8_absmax_kernel<__bf16>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((fp8_absmax_kernel<_Float16>), grid, dim3(256), 0, st, p);

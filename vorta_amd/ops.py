@@ -359,16 +359,30 @@ class Fp8Operands:
         return self.ws[base:base + H * D].view(H, D)
 
 
+def fp8_ws_partials(ws: torch.Tensor, heads: int, head_dim: int = 128) -> torch.Tensor:
+    """the sample-partials region of a quantiser workspace (vorta_fp8_quant_ws_partials): what the ranks zero, fill with
+    `fp8_quantize_qkv(phase="stats")` and all-reduce with SUM"""
+    first, count = C.c_int64(), C.c_int64()
+    _C.check(_C.lib().vorta_fp8_quant_ws_partials(heads, head_dim, C.byref(first), C.byref(count)), "vorta_fp8_quant_ws_partials")
+    return ws[first.value:first.value + count.value]
+
+
 def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor], scale: Optional[float] = None, *,
                      out: Optional[Fp8Operands] = None, v_per_head: bool = False, center_k: bool = False,
                      heads: Optional[int] = None, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0,
-                     slots: Optional[Tuple[int, int]] = None) -> Fp8Operands:
+                     slots: Optional[Tuple[int, int]] = None, video_tokens: int = 0, phase: Optional[str] = None,
+                     token_offset: int = 0, total_tokens: int = 0, src_map: Optional[torch.Tensor] = None) -> Fp8Operands:
     """vorta_fp8_quantize_qkv: (H,S,D) bf16/fp16 views -> e4m3 copies (contiguous (H,S,D) uint8) with the softmax scale
     and log2(e) folded into q/k.  `out` = a previous result to overwrite (same shapes).  `center_k`: subtract a per-head
     centre from the keys first (softmax-invariant; see include/vorta_hip.h).  `seg_len > 0`: q,k,v are (1,rows,D) row
     arrays in which row r belongs to head (r // seg_len) % heads (the Ulysses receive layout); from row `tail_first` on
     only the first `tail_len` rows of a segment hold data; `slots` = (first, end): only those head slots of it.
-    `v=None`: q and k only (flags bit2) -- `out.v` / `out.v_descale` are left to `fp8_v_convert`."""
+    `v=None`: q and k only (flags bit2) -- `out.v` / `out.v_descale` are left to `fp8_v_convert`.
+    `video_tokens`: tokens of a head before its tail (text) tokens (0: all) -- the sample is summed in 8 ranges of them + the
+    tail, pass the same value wherever the same heads are converted.  Sequence shards (q, k only): `phase="stats"` adds the
+    sample partials of tokens [token_offset, token_offset + S) of `total_tokens` to `out.ws` (zero `fp8_ws_partials(out)`
+    first, all-reduce it with SUM afterwards), `phase="convert"` converts them with the scales of the whole sequence,
+    output head h <- head src_map[h]: the two phases write the bytes one plain call over the assembled sequence writes."""
     skip_v = v is None
     if skip_v:
         if out is None:
@@ -403,8 +417,18 @@ def fp8_quantize_qkv(q: torch.Tensor, k: torch.Tensor, v: Optional[torch.Tensor]
     a.q, a.k, a.v = _tensor(q), _tensor(k), _tensor(v)
     a.q8, a.k8, a.v8 = _tensor(out.q), _tensor(out.k), _tensor(out.v)
     a.v_descale, a.ws = out.v_descale.data_ptr(), out.ws.data_ptr()
-    a.flags = (1 if v_per_head else 0) | (2 if center_k else 0) | (4 if skip_v else 0)
+    if phase not in (None, "stats", "convert"):
+        raise ValueError(f"fp8_quantize_qkv: unknown phase {phase!r}")
+    if phase is not None and not skip_v:
+        raise ValueError("fp8_quantize_qkv: the shard phases convert q and k only (v: fp8_v_absmax / fp8_v_convert)")
+    a.flags = (1 if v_per_head else 0) | (2 if center_k else 0) | (4 if skip_v else 0) | \
+        (8 if phase == "stats" else 0) | (16 if phase == "convert" else 0)
     a.seg_len, a.tail_first, a.tail_len = seg_len, tail_first, tail_len
+    a.video_tokens, a.token_offset, a.total_tokens = video_tokens, token_offset, total_tokens
+    if src_map is not None:
+        if src_map.dtype != torch.int32 or not src_map.is_cuda or src_map.numel() < H:
+            raise ValueError("fp8_quantize_qkv: src_map must be an int32 device tensor with one entry per output head")
+        a.src_map = src_map.data_ptr()
     if slots is not None:
         if seg_len <= 0 or not (0 <= slots[0] < slots[1] <= H):
             raise ValueError(f"fp8_quantize_qkv: slots {slots} need the segmented layout and 0 <= first < end <= {H}")

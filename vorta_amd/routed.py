@@ -240,7 +240,9 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         v8, vd, _ = ops.fp8_quantize_v(v3, out=fp8_operands if isinstance(fp8_operands, tuple) else None)
         base = dict(q=q3, k=k3, v=v8, scale=scale, v_descale=vd)
     elif fp8:
-        f8 = ops.fp8_quantize_qkv(q3, k3, v3, scale, out=fp8_operands, center_k=FP8_CENTER_K)
+        # (video_tokens: the sample is summed in eighths of the video tokens + the text, as the sequence-parallel send side sums it)
+        f8 = ops.fp8_quantize_qkv(q3, k3, v3, scale, out=fp8_operands, center_k=FP8_CENTER_K,
+                                  video_tokens=S if rm is None and T > 0 else 0)
         base = dict(q=f8.q, k=f8.k, v=f8.v, scale=scale, v_descale=f8.v_descale)
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
