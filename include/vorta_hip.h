@@ -198,7 +198,8 @@ typedef struct vorta_fp8_quant_args {
   int32_t total_tokens;     /* token_offset + n_tokens) of heads whose whole sequence has total_tokens tokens (0: the views
                                are the whole sequence) */
   const int32_t* src_map;   /* seg_len == 0, optional: q8 / k8 / v8 head h <- head src_map[h] of q / k / v, with that head's
-                               scales and centre (the heads in destination order for the exchange) */
+                               scales and centre (the heads in destination order for the exchange); `heads` entries, a
+                               negative one = that output head is not written */
 } vorta_fp8_quant_args;
 /* flags bit2: q and k only -- v, v8 and v_descale are not touched (v arrived as e4m3: vorta_fp8_v_convert on the sender)
  * flags bit3: statistics only -- the sample partials of the tokens this call holds go to their slots of `ws`, nothing is

@@ -540,4 +540,11 @@ def test_quantizer_sequence_shards_write_the_bytes_of_one_call(P, T):
     torch.cuda.synchronize()
     o = order.long()
     assert torch.equal(q8, whole.q[o]) and torch.equal(k8, whole.k[o])
-    # and the receive layout's conversion (what the 16-bit wire does today) still writes the same bytes for Wan (T = 0)
+    # a negative map entry leaves that output head alone (a rank writes the text rows of ITS heads only)
+    part_map = torch.tensor([3, -1, 4, -1, -1], dtype=torch.int32, device=dev())
+    q8b = torch.full((H, Sl, 128), 77, dtype=torch.uint8, device=dev())
+    k8b = torch.full_like(q8b, 77)
+    ops.fp8_quantize_qkv(shards[0][0], shards[0][1], None, out=ops.Fp8Operands(q8b, k8b, dummy, whole.v_descale, ws),
+                         center_k=True, phase="convert", token_offset=0, total_tokens=S + T, video_tokens=S, src_map=part_map)
+    assert torch.equal(q8b[0], whole.q[3, :Sl]) and torch.equal(k8b[2], whole.k[4, :Sl])
+    assert (q8b[[1, 3, 4]] == 77).all() and (k8b[[1, 3, 4]] == 77).all()

@@ -303,7 +303,11 @@ __global__ __launch_bounds__(256) void fp8_convert_kernel(const QParams p) {
   if (r0 >= r1) return;
   const int t = threadIdx.x, cc = t & 7, rl = t >> 3;
   const int hout = hphys;  // output head; with a source map the input head (and its scales) is src_map[hout]
-  if (p.src_map && p.seg_len <= 0) h = hphys = p.src_map[hout];
+  if (p.src_map && p.seg_len <= 0) {
+    const int hs = p.src_map[hout];
+    if (hs < 0) return;  // output head not written by this call
+    h = hphys = hs;
+  }
   const float* qmul = p.ws + 2 * H + H * D;
   float mul[16], sub[16];
 #pragma unroll
