@@ -23,7 +23,8 @@ def one(i):
     dev = torch.device("cuda:0")
     q, k, v = (torch.randn((H, S, 128), device=dev, dtype=torch.bfloat16) for _ in range(3))
     o = torch.empty_like(q)
-    # TRACE_SCALE_MUL=8 for libraries built with -DVORTA_P_DIRECT=1 (their q8 . k8 carries 8 x the score)
+    # TRACE_SCALE_MUL: multiplier on the softmax scale (8 for the byte-direct pack experiment of
+    # profiles/r03_fp8_loop_experiments.txt, whose q8 . k8 carried 8 x the score; that build is not in the tree)
     f8 = ops.fp8_quantize_qkv(q, k, v, scale=float(os.environ.get("TRACE_SCALE_MUL", 1)) / 128 ** 0.5)
     br, nw = 256, 8
     n_wg = H * ((S + br - 1) // br)
