@@ -184,7 +184,7 @@ def processor_level(cfg, mix, dev, dt, fp8):
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
     width = H * 128
-    vorta_amd.set_attention_precision("fp8" if fp8 else "native")
+    vorta_amd.set_attention_precision("fp8pv" if fp8 == "fp8pv" else "fp8" if fp8 else "native")
     gen = torch.Generator(device=dev).manual_seed(1234)
 
     def lin(i, o):
@@ -316,9 +316,17 @@ def main():
                          "over the whole sequence through the zero-copy receive layout, the send-side staging passes and the "
                          "un-permute of the output included, the transfers themselves left out.  `value` is an upper bound of "
                          "the P-GPU throughput; not a BASELINE line")
-    ap.add_argument("--placement", default=os.environ.get("VORTA_SP_PLACEMENT", "uneven"), choices=["even", "uneven"],
+    ap.add_argument("--placement", default=os.environ.get("VORTA_SP_PLACEMENT", "auto"), choices=["auto", "even", "uneven"],
                     help="N>1: heads per rank -- even: H/N on every rank (whole-head LPT under that constraint); uneven: the "
-                         "ranks' head counts follow the layer's routes (LPT on the expert costs alone)")
+                         "ranks' head counts follow the layer's routes (LPT on the expert costs alone); auto (default): even "
+                         "when N divides the heads (one receive layout for every layer; identical to uneven on the uniform "
+                         "mix), uneven otherwise")
+    ap.add_argument("--conservative", action="store_true",
+                    help="N>1 fallback: --placement even --sp-groups 1, one all_to_all_single per tensor "
+                         "(VORTA_SP_TRANSPORT=a2a), v exchanged in 16 bits -- the oldest, most exercised form of the exchange")
+    ap.add_argument("--no-selfcheck", action="store_true",
+                    help="N>1: skip the exchange self-check that runs before the warm-up (integer-tagged q,k,v through layer "
+                         "0's exchange with identity attention, compared exactly on every rank)")
     ap.add_argument("--no-v-wire", action="store_true",
                     help="N>1 with --dtype fp8: exchange v in 16 bits and convert it on the receive side (A/B; default: v "
                          "is converted on the send side and crosses the links as e4m3)")
@@ -342,6 +350,11 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.dtype:
         cfg["dtype"] = args.dtype
+    if args.conservative:  # before vorta_amd.ulysses.engine reads the transport switch, and inherited by the child ranks
+        args.placement, args.sp_groups, args.no_v_wire = "even", 1, True
+        os.environ["VORTA_SP_TRANSPORT"] = "a2a"
+    if args.placement == "auto":
+        args.placement = "even" if cfg["heads"] % max(args.emulate_rank or args.gpus, 1) == 0 else "uneven"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_rank:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (never exec: nothing in this
         # process has touched the GPU yet, and nothing will), relay its output and exit with its code
@@ -359,10 +372,14 @@ def main():
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
+        # a collective that never completes must not eat the caller's whole time limit and leave no line: the process group's
+        # watchdog aborts the ranks after this long (VORTA_BENCH_TIMEOUT_S), and `guarded` below turns that into one JSON line
+        from datetime import timedelta
+        pg_timeout = timedelta(seconds=float(os.environ.get("VORTA_BENCH_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     # what the process group saw: one entry per rank (proof that N ranks on N devices ran the step over RCCL)
     props = torch.cuda.get_device_properties(dev_index)
@@ -441,6 +458,19 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # N > 1: before anything is timed, prove that the exchange moves the right bytes on THIS transport (RCCL on the driver's
+    # node, gloo in the one-GPU rehearsals): vorta_amd/ulysses/engine.py exchange_selfcheck on layer 0's placement
+    selfcheck = None
+    if world > 1 and not args.no_selfcheck:
+        selfcheck = sp.selfcheck(0, break_order=os.environ.get("VORTA_SP_SELFCHECK_BREAK") == "1")
+        if not selfcheck["ok"]:
+            if rank == 0:
+                print(json.dumps({"error": "exchange self-check failed: the head exchange did not deliver the expected rows",
+                                  "exchange_selfcheck": selfcheck, "n_gpus": world, "backend": backend}), flush=True)
+            barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
 
     for _ in range(args.warmup):
         one_step()
@@ -531,6 +561,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "backend": (backend if world > 1 else None), "output_fingerprint": fingerprint,
+        **({"exchange_selfcheck": selfcheck} if selfcheck is not None else {}),
         "process_group": {"world_size": dist.get_world_size() if world > 1 else 1,
                           "backend": dist.get_backend() if world > 1 else None,
                           "distinct_devices": len({(r["host"], r["uuid"] or r["device"]) for r in ranks_seen}),
@@ -599,5 +630,23 @@ def main():
         dist.destroy_process_group()
 
 
+def guarded():
+    """main() with one promise: a failure leaves ONE JSON line naming it on rank 0's stdout and a non-zero exit code (a failed
+    GPU process exits; it never re-executes itself)."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as exc:  # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"error": f"{type(exc).__name__}: {exc}"[:600], "n_gpus": int(os.environ.get("WORLD_SIZE", "1")),
+                              "argv": sys.argv[1:]}), flush=True)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)  # not sys.exit: a rank stuck in a collective's destructor would hang the exit
+
+
 if __name__ == "__main__":
-    main()
+    guarded()

@@ -45,6 +45,37 @@ def test_bench_two_rank_rehearsal(dtype):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     j = _line(r.stdout)
     assert KEYS <= set(j) and j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0 and j["dtype"] == dtype
+    # the pre-flight of the N > 1 run: tagged q,k,v through layer 0's exchange (v as e4m3 in the fp8 run), exact on every rank
+    sc = j["exchange_selfcheck"]
+    assert sc["ok"] is True and sc["bytes"] > 0 and sc["ms"] > 0 and sc["failed_on_this_rank"] == []
+    assert ("v as e4m3" in sc["what"]) == (dtype == "fp8")
+
+
+def test_bench_selfcheck_catches_a_misordered_exchange_and_conservative_line():
+    """VORTA_SP_SELFCHECK_BREAK=1 (test-only): the last rank swaps two heads of its copy of the placement -> the run must stop
+    before the warm-up with ONE JSON error line and a non-zero exit code.  --conservative: even placement, one slot group,
+    one all_to_all_single per tensor, v in 16 bits -- same layer output as the default exchange."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "bench.py", "--gpus", "2", "--config", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(base, cwd=ROOT, env=dict(env, VORTA_SP_SELFCHECK_BREAK="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0
+    err = [l for l in r.stdout.splitlines() if l.startswith('{"error"')]
+    assert len(err) == 1 and not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')], r.stdout[-2000:]
+    e = json.loads(err[0])
+    assert e["exchange_selfcheck"]["ok"] is False and "self-check" in e["error"]
+    fps = {}
+    for name, extra in (("default", []), ("conservative", ["--conservative"])):
+        for dtype in ("bf16", "fp8"):
+            r = subprocess.run(base + ["--dtype", dtype] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, (name, dtype, r.stdout[-1500:], r.stderr[-3000:])
+            j = _line(r.stdout)
+            assert j["exchange_selfcheck"]["ok"] is True
+            fps[(name, dtype)] = j["output_fingerprint"]
+            if name == "conservative":
+                assert "even head placement" in j["config"]["parallelism"] and j["switches"]["env"]["VORTA_SP_TRANSPORT"] == "a2a"
+                assert "v as e4m3" not in j["exchange_selfcheck"]["what"]
+    assert fps[("default", "bf16")] == fps[("conservative", "bf16")] != 0 and fps[("default", "fp8")] == fps[("conservative", "fp8")] != 0
 
 
 def test_bench_plain_command_launches_its_ranks_and_fp8_exchange_variants_agree():
@@ -107,6 +138,7 @@ def test_bench_three_rank_rehearsal_heads_not_divisible():
             assert r.returncode == 0, (dtype, transport, r.stdout[-1500:], r.stderr[-3000:])
             j = _line(r.stdout)
             assert j["n_gpus"] == 3 and j["process_group"]["world_size"] == 3 and "uneven" in j["config"]["parallelism"]
+            assert j["exchange_selfcheck"]["ok"] is True and "head counts" in j["exchange_selfcheck"]["what"]
             assert j["switches"]["env"].get("VORTA_SP_TRANSPORT") == transport
             fps[transport] = j["output_fingerprint"]
         assert fps["a2a"] == fps["p2p"] != 0, (dtype, fps)

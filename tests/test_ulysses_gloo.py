@@ -201,6 +201,47 @@ def _uneven_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _selfcheck_worker(rank, world, port, ret):
+    """exchange_selfcheck (bench.py's N > 1 pre-flight): integer-tagged q,k,v through the layout's own exchange, exact on every
+    rank; a rank whose copy of the head order differs must fail it everywhere"""
+    _init(rank, world, port)
+    import vorta_amd.ulysses.engine as E
+    from vorta_amd.ulysses import (UlyssesLayout, balanced_head_order, balanced_placement, exchange_selfcheck, slot_groups)
+    P = world
+    S, T, D = 40 * world, 6, 8
+    res = {}
+    for H, uneven in ((2 * world, False), (3 * world + 1, True)):
+        experts = ([0, 2, 2, 1, 2, 2, 1] * H)[:H]
+        cost = [7.0, 2.0, 1.0]
+        for groups in (1, 2):
+            if uneven:
+                order, counts = balanced_placement(experts, cost, P, groups)
+            else:
+                order, counts = balanced_head_order(experts, cost, P, groups), None
+            lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.bfloat16, counts=counts)
+            sg = slot_groups(lay.Hl, min(groups, min(lay.counts)))
+            for transport in ("a2a", "p2p"):
+                E.TRANSPORT = transport
+                for brk in (False, True):
+                    bufs = [lay.new_buffer() for _ in range(4)]
+                    r = exchange_selfcheck(lay, order, sg, bufs, break_order=brk)
+                    res[(H, groups, transport, brk)] = (r["ok"], r["bytes"] > 0, r["ms"] >= 0)
+    E.TRANSPORT = "a2a"
+    ret[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_selfcheck_passes_and_catches_a_misordered_placement(world):
+    ret = mp.Manager().dict()
+    mp.spawn(_selfcheck_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        for key, (ok, nb, ms) in ret[r].items():
+            assert nb and ms, (r, key)
+            assert ok == (not key[3]), (r, key, ok)  # break_order -> the check fails on EVERY rank (MIN all-reduce)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_uneven_head_placement_round_trip(world):
     ret = mp.Manager().dict()

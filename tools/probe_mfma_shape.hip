@@ -1,0 +1,382 @@
+// Energy per FLOP of the 16-bit attention loop's ingredients, on RANDOM operands.
+//   part A  bare MFMA loops, operands in registers: v_mfma_f32_32x32x16 vs v_mfma_f32_16x16x32, f16 and bf16, the same
+//           64 x 32 output tile per wave and the same FLOPs per iteration; zeros as the control (cycles only);
+//   part B  the same with the A operand of every MFMA re-read from LDS by ds_read_b128 (1 KiB per 32 pipe cycles in both
+//           shapes: a 16x16x32 fragment feeds two MFMAs);
+//   part C  an attention-shaped step (scores one block ahead, exp2 / row sum / convert on the VALU, P V, one barrier per
+//           step, the product kernel's issue recipe) in three forms: 32x32x16 with 1 KiB of LDS fragment reads per MFMA
+//           (= the product loop, 32 query rows per wave), the same with every fragment feeding TWO MFMAs (0.5 KiB per
+//           MFMA = what 64 query rows per wave would read), and 16x16x32 (two 16-row query tiles per wave; a fragment
+//           feeds two MFMAs there by construction).  Not numerically meaningful -- the addresses, instruction mix and
+//           operand statistics are those of the product loop, the values are not checked.
+// Per variant: wall time (HIP events), TFLOP/s, shader clock inside the loop (s_memtime / s_memrealtime), shader cycles
+// per step.  2 waves per SIMD (512 threads, one workgroup per CU), every CU busy, ~2 s of back-to-back launches each.
+//   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -enable-post-misched=0 tools/probe_mfma_shape.hip -o /tmp/probe_shape
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+#define LDS_AS __attribute__((address_space(3)))
+
+template <typename T> struct M;
+template <> struct M<__bf16> {
+  using v8 = bf16x8; using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 m32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 m16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ v4 tr(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS_AS v4*)p); }
+  static const char* name() { return "bf16"; }
+};
+template <> struct M<_Float16> {
+  using v8 = f16x8; using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 m32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 m16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ v4 tr(const char* p) {
+    typedef __attribute__((ext_vector_type(4))) __fp16 h4;
+    h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS_AS h4*)p);
+    return *(v4*)&r;
+  }
+  static const char* name() { return "fp16"; }
+};
+
+__device__ __forceinline__ unsigned hash(unsigned x) { x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16; return x; }
+template <typename T> __device__ __forceinline__ T rnd(unsigned seed, float amp) { return (T)(((int)(hash(seed) & 0xffff) - 32768) * (amp / 32768.f)); }
+
+constexpr int ROWB = 256, TILE = 64 * ROWB;
+
+template <typename T, int RANDOM>
+__device__ __forceinline__ void fill_lds(char* smem) {
+  T* s = (T*)smem;
+  for (int i = threadIdx.x; i < 2 * TILE / 2; i += blockDim.x) s[i] = RANDOM ? rnd<T>(i * 7 + 1 + blockIdx.x * 65536, 1.f) : (T)0.f;
+  __syncthreads();
+}
+
+struct Stamp { long long cyc, real; };
+__device__ __forceinline__ Stamp stamp() { Stamp s; s.cyc = __builtin_amdgcn_s_memtime(); s.real = __builtin_amdgcn_s_memrealtime(); return s; }
+
+// ---------------------------------------------------------------- parts A, B ----------------------------------------
+// SHAPE 32: 2 accumulators of 32x32, 8 MFMAs of 32 cycles per iteration; SHAPE 16: 8 accumulators of 16x16, 16 MFMAs of 16
+// cycles: 256 pipe cycles and 262 144 FLOP per wave and iteration either way.  SRC 1: the A fragments come from LDS.
+template <typename T, int SHAPE, int SRC, int RANDOM>
+__global__ __launch_bounds__(512) void bare(long long* out, int iters) {
+  using V8 = typename M<T>::v8;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+  fill_lds<T, RANDOM>(smem);
+  const int lane = threadIdx.x & 63;
+  V8 ra[4], rb[4];
+  _Pragma("unroll") for (int s = 0; s < 4; ++s)
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+      ra[s][i] = RANDOM ? rnd<T>(threadIdx.x * 64 + s * 16 + i, 4.f) : (T)0.f;
+      rb[s][i] = RANDOM ? rnd<T>(threadIdx.x * 64 + s * 16 + i + 77777, 4.f) : (T)0.f;
+    }
+  // conflict-free ds_read_b128 addresses (the product K tile's swizzle): 8 fragments of 1 KiB
+  int rd[8];
+  {
+    const int r32 = lane & 31, hh = lane >> 5;
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) rd[ks] = r32 * ROWB + (((2 * ks + hh) ^ (r32 & 15)) << 4);
+  }
+  f32x16 c0, c1;
+  f32x4 c[8];
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) { c0[i] = 0.f; c1[i] = 0.f; }
+  _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int i = 0; i < 4; ++i) c[t][i] = 0.f;
+  const Stamp s0 = stamp();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      V8 a0, a1;
+      if (SRC) {
+        a0 = *(const V8*)(smem + rd[2 * u] + ((it & 1) ? 32 * ROWB : 0));
+        a1 = *(const V8*)(smem + rd[2 * u + 1] + ((it & 1) ? 0 : 32 * ROWB));
+      } else { a0 = ra[u]; a1 = ra[(u + 1) & 3]; }
+      if (SHAPE == 32) {
+        c0 = M<T>::m32(a0, rb[u], c0);
+        c1 = M<T>::m32(a1, rb[(u + 2) & 3], c1);
+      } else {
+        c[0 + 4 * (u & 1)] = M<T>::m16(a0, rb[u], c[0 + 4 * (u & 1)]);
+        c[1 + 4 * (u & 1)] = M<T>::m16(a0, rb[(u + 1) & 3], c[1 + 4 * (u & 1)]);
+        c[2 + 4 * (u & 1)] = M<T>::m16(a1, rb[u], c[2 + 4 * (u & 1)]);
+        c[3 + 4 * (u & 1)] = M<T>::m16(a1, rb[(u + 1) & 3], c[3 + 4 * (u & 1)]);
+      }
+    }
+    if (RANDOM && (it & 63) == 63) {  // keep the accumulators finite
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) { c0[i] *= 1e-3f; c1[i] *= 1e-3f; }
+      _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int i = 0; i < 4; ++i) c[t][i] *= 1e-3f;
+    }
+  }
+  const Stamp s1 = stamp();
+  float s = 0.f;
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) s += c0[i] + c1[i];
+  _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int i = 0; i < 4; ++i) s += c[t][i];
+  if (threadIdx.x == 0) { out[blockIdx.x * 4] = s1.cyc - s0.cyc; out[blockIdx.x * 4 + 1] = s1.real - s0.real; out[blockIdx.x * 4 + 2] = (long long)s; }
+}
+
+// ---------------------------------------------------------------- part C --------------------------------------------
+// One wave = 32 query rows against a 64-key block per step (MODE 0, 1) or two 16-row query tiles (MODE 2).  Scores of the next
+// block are computed while the current block's probabilities go through the VALU, as in the product loop.
+// MODE 0: 16 + 16 MFMAs (32x32x16), 16 K-fragment reads + 32 transposed V reads.
+// MODE 1: the same MFMAs, every fragment read feeding two of them (8 + 16 reads).
+// MODE 2: 32 + 32 MFMAs (16x16x32), 16 K-fragment reads + 32 transposed V reads (a fragment feeds both query tiles).
+template <typename T, int MODE, int VALU>
+__global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters) {
+  using V8 = typename M<T>::v8;
+  using V4 = typename M<T>::v4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+  fill_lds<T, 1>(smem);
+  const int lane = threadIdx.x & 63;
+  const int r32 = lane & 31, hh = lane >> 5;
+  V8 qf[8];
+  _Pragma("unroll") for (int s = 0; s < 8; ++s)
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) qf[s][i] = rnd<T>(threadIdx.x * 64 + s * 8 + i + 4242, 0.35f);  // scores ~ N(0, 1.3) in log2 units
+  int k_rd[8], v_rd[4];
+  _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) k_rd[ks] = r32 * ROWB + (((2 * ks + hh) ^ (r32 & 15)) << 4);
+  {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) v_rd[dt] = TILE + (4 * (g >> 1) + q4) * ROWB + ((dt ^ q4) << 6) + 32 * (g & 1) + 8 * pp;
+  }
+  // 16x16x32: fragment of key tile kt (16 keys), k-step ks (32 channels): row 16 kt + (lane & 15), chunk 4 ks + (lane >> 4)
+  int k16_rd[4];
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) k16_rd[ks] = (lane & 15) * ROWB + (((4 * ks + (lane >> 4)) ^ (lane & 15)) << 4);
+
+  float l_run = 0.f;
+  long long cyc = 0;
+  if constexpr (MODE < 2) {
+    f32x16 o[4], sA0, sA1, sB0, sB1, minit;
+    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) _Pragma("unroll") for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) { minit[i] = -6.f; sA0[i] = -6.f; sA1[i] = -7.f; sB0[i] = -6.f; sB1[i] = -7.f; }
+    asm volatile("" : "+v"(minit));
+#define STEP32(c0_, c1_, n0_, n1_, kslot_)                                                                       \
+  {                                                                                                              \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                                                        \
+      if (MODE == 0) {                                                                                           \
+        const V8 k0_ = *(const V8*)(smem + k_rd[ks_] + (kslot_) * 0);                                            \
+        const V8 k1_ = *(const V8*)(smem + k_rd[ks_] + 32 * ROWB);                                               \
+        n0_ = M<T>::m32(k0_, qf[ks_], ks_ == 0 ? minit : n0_);                                                   \
+        n1_ = M<T>::m32(k1_, qf[ks_], ks_ == 0 ? minit : n1_);                                                   \
+      } else { /* one fragment, two MFMAs (two query sets: the B operands and accumulators differ) */            \
+        const V8 k0_ = *(const V8*)(smem + k_rd[ks_] + ((kslot_) ? 32 * ROWB : 0));                              \
+        n0_ = M<T>::m32(k0_, qf[ks_], ks_ == 0 ? minit : n0_);                                                   \
+        n1_ = M<T>::m32(k0_, qf[ks_ ^ 1], ks_ == 0 ? minit : n1_);                                               \
+      }                                                                                                          \
+    }                                                                                                            \
+    V8 pb_[4];                                                                                                   \
+    if (VALU) {                                                                                                  \
+      float lsum_ = 0.f;                                                                                         \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                                        \
+        c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                                               \
+        c1_[i_] = __builtin_amdgcn_exp2f(c1_[i_]);                                                               \
+        lsum_ += c0_[i_] + c1_[i_];                                                                              \
+      }                                                                                                          \
+      l_run += lsum_;                                                                                            \
+    }                                                                                                            \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) {                                                           \
+      pb_[0][e_] = (T)c0_[e_]; pb_[1][e_] = (T)c0_[8 + e_]; pb_[2][e_] = (T)c1_[e_]; pb_[3][e_] = (T)c1_[8 + e_]; \
+    }                                                                                                            \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                                                        \
+      _Pragma("unroll") for (int kg_ = 0; kg_ < 4; ++kg_) {                                                      \
+        if (MODE == 0 || (kg_ & 1) == 0) {                                                                       \
+          const V4 lo_ = M<T>::tr(smem + v_rd[dt_] + (16 * kg_) * ROWB);                                         \
+          const V4 hi_ = M<T>::tr(smem + v_rd[dt_] + (16 * kg_ + 8) * ROWB);                                     \
+          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { vf_[e_] = lo_[e_]; vf_[4 + e_] = hi_[e_]; }         \
+        }                                                                                                        \
+        o[MODE == 0 ? dt_ : (dt_ ^ (kg_ & 1))] = M<T>::m32(vf_, pb_[kg_], o[MODE == 0 ? dt_ : (dt_ ^ (kg_ & 1))]); \
+      }                                                                                                          \
+    }                                                                                                            \
+    if (VALU) {                                                                                                  \
+      int m0_ = __float_as_int(n0_[0]), m1_ = __float_as_int(n1_[0]);                                            \
+      _Pragma("unroll") for (int i_ = 1; i_ < 15; i_ += 2) {                                                     \
+        m0_ = max(max(m0_, __float_as_int(n0_[i_])), __float_as_int(n0_[i_ + 1]));                              \
+        m1_ = max(max(m1_, __float_as_int(n1_[i_])), __float_as_int(n1_[i_ + 1]));                              \
+      }                                                                                                          \
+      mx_ = max(mx_, max(m0_, m1_));                                                                             \
+    }                                                                                                            \
+    if (MODE == 0) {                                                                                             \
+      _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
+      }                                                                                                          \
+      _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                       \
+      }                                                                                                          \
+    } else {                                                                                                     \
+      _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
+      }                                                                                                          \
+      _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    \
+      }                                                                                                          \
+    }                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              \
+  }
+    V8 vf_;
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) vf_[i] = (T)0.f;
+    int mx_ = 0;
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+      STEP32(sA0, sA1, sB0, sB1, 0)
+      STEP32(sB0, sB1, sA0, sA1, 1)
+    }
+    const Stamp s1 = stamp();
+#undef STEP32
+    float s = l_run + (float)mx_;
+    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) _Pragma("unroll") for (int i = 0; i < 16; ++i) s += o[dt][i];
+    if (threadIdx.x == 0) { out[blockIdx.x * 4] = s1.cyc - s0.cyc; out[blockIdx.x * 4 + 1] = s1.real - s0.real; out[blockIdx.x * 4 + 2] = (long long)s; }
+    (void)cyc;
+  } else {
+    // 16x16x32.  s[kt][qt]: key tile kt (16 keys) x query tile qt; o[dt][qt]: channel tile dt (16 channels) x query tile qt
+    f32x4 o[8][2], sA[4][2], sB[4][2], minit;
+    _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) _Pragma("unroll") for (int i = 0; i < 4; ++i) o[dt][qt][i] = 0.f;
+    _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) _Pragma("unroll") for (int i = 0; i < 4; ++i) { sA[kt][qt][i] = -6.f; sB[kt][qt][i] = -7.f; }
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) minit[i] = -6.f;
+    asm volatile("" : "+v"(minit));
+    // query fragments: qf[2 qt' + ...]: reuse the 8 registers-sets as [qt][ks]
+#define STEP16(c_, n_)                                                                                           \
+  {                                                                                                              \
+    _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_) {                                                        \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                      \
+        const V8 kf_ = *(const V8*)(smem + k16_rd[ks_] + 16 * kt_ * ROWB);                                       \
+        n_[kt_][0] = M<T>::m16(kf_, qf[ks_], ks_ == 0 ? minit : n_[kt_][0]);                                     \
+        n_[kt_][1] = M<T>::m16(kf_, qf[4 + ks_], ks_ == 0 ? minit : n_[kt_][1]);                                 \
+      }                                                                                                          \
+    }                                                                                                            \
+    V8 pb_[2][2]; /* [k-step of 32 keys][query tile]: two stacked score tiles */                                 \
+    if (VALU) {                                                                                                  \
+      float lsum_ = 0.f;                                                                                         \
+      _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_)                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                       \
+          c_[kt_][0][i_] = __builtin_amdgcn_exp2f(c_[kt_][0][i_]);                                               \
+          c_[kt_][1][i_] = __builtin_amdgcn_exp2f(c_[kt_][1][i_]);                                               \
+          lsum_ += c_[kt_][0][i_] + c_[kt_][1][i_];                                                              \
+        }                                                                                                        \
+      l_run += lsum_;                                                                                            \
+    }                                                                                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                             \
+      _Pragma("unroll") for (int qt_ = 0; qt_ < 2; ++qt_)                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                       \
+          pb_[s_][qt_][e_] = (T)c_[2 * s_][qt_][e_];                                                             \
+          pb_[s_][qt_][4 + e_] = (T)c_[2 * s_ + 1][qt_][e_];                                                     \
+        }                                                                                                        \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < 8; ++dt_) {                                                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                         \
+        const V4 lo_ = M<T>::tr(smem + v_rd[dt_ & 3] + (32 * s_ + 16 * (dt_ >> 2)) * ROWB);                     \
+        const V4 hi_ = M<T>::tr(smem + v_rd[dt_ & 3] + (32 * s_ + 16 * (dt_ >> 2) + 8) * ROWB);                 \
+        V8 vf_;                                                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { vf_[e_] = lo_[e_]; vf_[4 + e_] = hi_[e_]; }           \
+        o[dt_][0] = M<T>::m16(vf_, pb_[s_][0], o[dt_][0]);                                                       \
+        o[dt_][1] = M<T>::m16(vf_, pb_[s_][1], o[dt_][1]);                                                       \
+      }                                                                                                          \
+    }                                                                                                            \
+    if (VALU) {                                                                                                  \
+      int m0_ = __float_as_int(n_[0][0][0]), m1_ = __float_as_int(n_[0][1][0]);                                  \
+      _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_) {                                                      \
+        m0_ = max(max(m0_, __float_as_int(n_[kt_][0][1])), __float_as_int(n_[kt_][0][2]));                       \
+        m1_ = max(max(m1_, __float_as_int(n_[kt_][1][1])), __float_as_int(n_[kt_][1][2]));                       \
+        m0_ = max(max(m0_, __float_as_int(n_[kt_][0][3])), __float_as_int(n_[kt_][1][3]));                       \
+        m1_ = max(max(m1_, __float_as_int(n_[kt_][1][0])), __float_as_int(n_[kt_][0][0]));                       \
+      }                                                                                                          \
+      mx_ = max(mx_, max(m0_, m1_));                                                                             \
+    }                                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+      __builtin_amdgcn_sched_group_barrier(0x400, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);      \
+    }                                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      \
+    }                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              \
+  }
+    int mx_ = 0;
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+      STEP16(sA, sB)
+      STEP16(sB, sA)
+    }
+    const Stamp s1 = stamp();
+#undef STEP16
+    float s = l_run + (float)mx_;
+    _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) _Pragma("unroll") for (int qt = 0; qt < 2; ++qt) _Pragma("unroll") for (int i = 0; i < 4; ++i) s += o[dt][qt][i];
+    if (threadIdx.x == 0) { out[blockIdx.x * 4] = s1.cyc - s0.cyc; out[blockIdx.x * 4 + 1] = s1.real - s0.real; out[blockIdx.x * 4 + 2] = (long long)s; }
+  }
+}
+
+// ---------------------------------------------------------------- host ----------------------------------------------
+static int cmp_ll(const void* a, const void* b) { long long x = *(const long long*)a, y = *(const long long*)b; return x < y ? -1 : x > y; }
+static double now() { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
+template <typename F>
+void run(const char* label, long long* d, int grid, double flop_per_wave_iter, double steps_per_iter, int iters, F launch) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  launch(iters / 8 + 1);
+  hipDeviceSynchronize();
+  // calibrate: one launch ~ 25 ms, then ~2 s of back-to-back launches (the clock settles), the last ones timed
+  hipEventRecord(e0); launch(iters); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms1; hipEventElapsedTime(&ms1, e0, e1);
+  const int reps = (int)(2000.f / ms1) + 3, timed = reps / 2 > 0 ? reps / 2 : 1;
+  const double t_start = now();
+  for (int w = 0; w < reps - timed; ++w) launch(iters);
+  hipEventRecord(e0);
+  for (int w = 0; w < timed; ++w) launch(iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  const double t_end = now();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  ms /= timed;
+  static long long h[4 * 1024];
+  hipMemcpy(h, d, sizeof(long long) * 4 * grid, hipMemcpyDeviceToHost);
+  static long long cyc[1024], real[1024];
+  for (int b = 0; b < grid; ++b) { cyc[b] = h[4 * b]; real[b] = h[4 * b + 1]; }
+  qsort(cyc, grid, sizeof(long long), cmp_ll); qsort(real, grid, sizeof(long long), cmp_ll);
+  const double mcyc = (double)cyc[grid / 2], mreal = (double)real[grid / 2];
+  const double flops = (double)grid * 8 * iters * flop_per_wave_iter;
+  printf("%-58s %8.3f ms %7.0f TFLOP/s  clock %5.0f MHz  %7.1f cyc/step  [%.3f .. %.3f]\n", label, ms, flops / ms / 1e9,
+         mcyc / mreal * 100.0, mcyc / (iters * steps_per_iter), t_start, t_end);
+  fflush(stdout);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
+template <typename T>
+void all(long long* d, int parts) {
+  const int G = 256;
+  char lab[128];
+#define BARE(SHAPE, SRC, RANDOM)                                                                                           \
+  snprintf(lab, sizeof lab, "%s bare %s A from %s, %s", M<T>::name(), SHAPE == 32 ? "32x32x16" : "16x16x32", SRC ? "LDS " : "regs", \
+           RANDOM ? "random" : "zeros");                                                                                   \
+  run(lab, d, G, 262144.0, 1.0, 60000, [&](int it) { hipLaunchKernelGGL((bare<T, SHAPE, SRC, RANDOM>), dim3(G), dim3(512), 0, 0, d, it); });
+  if (parts & 1) { BARE(32, 0, 0) BARE(16, 0, 0) BARE(32, 0, 1) BARE(16, 0, 1) }
+  if (parts & 2) { BARE(32, 1, 0) BARE(16, 1, 0) BARE(32, 1, 1) BARE(16, 1, 1) }
+#define ATT(MODE, VALU)                                                                                                    \
+  snprintf(lab, sizeof lab, "%s step %s, %s", M<T>::name(),                                                                \
+           MODE == 0 ? "32x32x16 1 KiB LDS/MFMA" : MODE == 1 ? "32x32x16 0.5 KiB LDS/MFMA" : "16x16x32 (0.5 KiB per MFMA)", \
+           VALU ? "exp+sum+cvt+max" : "cvt only");                                                                         \
+  run(lab, d, G, 2.0 * 32 * 64 * 128 * 2 * 2, 2.0, 12000, [&](int it) { hipLaunchKernelGGL((attn_like<T, MODE, VALU>), dim3(G), dim3(512), 0, 0, d, it); });
+  if (parts & 4) { ATT(0, 1) ATT(1, 1) ATT(2, 1) ATT(0, 0) ATT(1, 0) ATT(2, 0) }
+}
+
+int main(int argc, char** argv) {
+  const int parts = argc > 1 ? atoi(argv[1]) : 7;
+  const int rounds = argc > 2 ? atoi(argv[2]) : 2;
+  long long* d;
+  hipMalloc(&d, sizeof(long long) * 4 * 1024);
+  for (int r = 0; r < rounds; ++r) {
+    printf("---- round %d ----\n", r);
+    all<_Float16>(d, parts);
+    all<__bf16>(d, parts);
+  }
+  return 0;
+}

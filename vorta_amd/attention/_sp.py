@@ -154,10 +154,20 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
             routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], _routing(tuple(local[g0:g1]), q.device), geom,
                              model=model, text_len=T, text_valid=te, out=ov[g0:g1], fp8=False, fp8_views=views)
 
+    sg = slot_groups(lay.Hl, groups)
+
+    def prepare():
+        # everything `attend` caches is built here, on the current stream, before the slot groups fork onto theirs
+        if not dense_only:
+            geom.prebuild(te if model == "hunyuan" else 0)
+            for g0, g1 in sg:
+                _routing(tuple(local[g0:g1]), q.device)
+
     # the received heads are written straight into the (1, N, H, D) result the output projection reads
     buf = torch.empty((1, N, H, D), dtype=q.dtype, device=q.device)
-    exchange_and_attend(lay, shards, bufs, order, texts, slot_groups(lay.Hl, groups), attend,
-                        buf[0, :Sl].transpose(0, 1), buf[0, Sl:].transpose(0, 1) if T else None, vwire=vwire)
+    exchange_and_attend(lay, shards, bufs, order, texts, sg, attend,
+                        buf[0, :Sl].transpose(0, 1), buf[0, Sl:].transpose(0, 1) if T else None, vwire=vwire,
+                        prepare=prepare)
     return buf
 
 

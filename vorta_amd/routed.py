@@ -95,6 +95,14 @@ class RoutedGeometry:
             self._sta[t_eff] = (q_rows, kv_rows, kv_rows.shape[1])
         return self._sta[t_eff]
 
+    def prebuild(self, t_eff: int, block_rows: int = 256) -> None:
+        """Build (on the CURRENT stream) every lazily cached device table a routed call with this text length may touch.
+        Callers that enqueue routed_attention on several streams call this before they fork: a table built inside one
+        stream's call is not ordered against another stream's first use of the cached object."""
+        self.sta_tables(t_eff)
+        if STA_MERGE and block_rows in (128, 256):
+            self.sta_launch_tables(t_eff, block_rows)
+
     def sta_launch_tables(self, t_eff: int, block_rows: int = 256):
         """The sliding-tile launch with query tiles of EQUAL key lists merged into one group.  The reference clamps the
         window centre (sliding_attn_flex.py:118-120), so the two outermost tiles of a dimension -- all tiles, when the

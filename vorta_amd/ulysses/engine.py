@@ -121,12 +121,17 @@ def slot_groups(Hl: int, groups: int) -> List[tuple]:
 
 
 def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, groups, attend, out_shard, out_text,
-                        vwire: Optional["VWire"] = None):
+                        vwire: Optional["VWire"] = None, prepare=None):
     """One layer under sequence parallelism.  `groups` = slot ranges of the local heads; `attend(g0, g1, index)`
     enqueues the attention over local head slots [g0, g1) of the layout buffers.  With one group this is
     scatter -> attention -> gather.  With several, the exchange of group g+1 and the return of group g-1 are in
     flight while group g computes (both run on the communicator's stream, the attention on the current one).
-    `vwire`: v travels as e4m3 (converted on this side with the scales of the whole sequence) into `vwire.buf`."""
+    `vwire`: v travels as e4m3 (converted on this side with the scales of the whole sequence) into `vwire.buf`.
+    `prepare()`: builds, on the current stream and BEFORE the group streams fork, every cached device object `attend` would
+    otherwise build lazily (geometry tables, routing lists): a table built inside group 0's stream is not ordered against
+    group 1's first read of the cached object on the other stream."""
+    if prepare is not None:
+        prepare()
     handles = lay.scatter_heads_start(shards, bufs[:3], head_order, texts, groups, vwire=vwire)
     state = lay.gather_heads_begin(out_shard, head_order)
     back = []
@@ -160,6 +165,111 @@ def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, g
     for h in back:
         lay._finish(h)
     lay.gather_heads_end(bufs[3], state, out_text)
+
+
+def tag_rows(t: int, heads: Sequence[int], tokens: torch.Tensor, kind: int, D: int, dtype, device) -> torch.Tensor:
+    """(len(heads), len(tokens), D) rows whose VALUES name where they belong: channel 0 = head + 1, channels 1-3 = the token
+    index in base 128, channel 4 = tensor id + 1 (q, k, v), channel 5 = `kind` (1 video row, 2 text row), the rest a hash
+    of (token, head, channel, tensor) in [-125, 125].  Small integers: exact in bf16 and fp16, so a row that travelled
+    through the exchange can be compared for EQUALITY with the row that should have arrived."""
+    h = torch.as_tensor(list(heads), dtype=torch.int64, device=device).view(-1, 1, 1)
+    s = tokens.to(device=device, dtype=torch.int64).view(1, -1, 1)
+    c = torch.arange(D, dtype=torch.int64, device=device).view(1, 1, -1)
+    x = (s * 31 + h * 17 + c * 7 + t * 5) % 251 - 125
+    x[..., 0] = (h + 1).expand(-1, s.shape[1], 1)[..., 0]
+    x[..., 1] = (s & 127).expand(h.shape[0], -1, 1)[..., 0]
+    x[..., 2] = ((s >> 7) & 127).expand(h.shape[0], -1, 1)[..., 0]
+    x[..., 3] = ((s >> 14) & 127).expand(h.shape[0], -1, 1)[..., 0]
+    x[..., 4] = t + 1
+    x[..., 5] = kind
+    return x.to(dtype)
+
+
+def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, bufs, vwire: Optional["VWire"] = None,
+                       break_order: bool = False) -> dict:
+    """Push integer-tagged q, k, v (`tag_rows`: value = f(tensor, head, token, channel)) through THIS layout's own exchange
+    -- the staging pass, the all_to_all_single (even or per-rank splits) or the grouped send / recv of every slot group,
+    the text rows, v as e4m3 when it travels that way, the return trip of the output and the all-gather of the text
+    outputs -- with identity in place of attention (o = q), and compare EXACTLY on every rank:
+      * every row of every local head slot of the q, k, v receive buffers, read through `row_map` as the kernels read
+        them, against the row that head and token should hold (v as e4m3: against the bytes and scales this rank computes
+        from the whole tagged sequence of its heads: abs-max over shards = abs-max over the sequence);
+      * the returned sequence shard of every head and the gathered text rows against the q rows sent.
+    Replaces nothing in the reference (vorta/ulysses/utils.py:42-56,68-89 has no check); it is what makes the first run
+    on a new transport trustworthy.  `break_order` (tests only): the last rank swaps two heads of ITS copy of the order,
+    which must fail the check.  Returns {"ok", "failed": [names], "bytes": sent + received by this rank, "ms"}."""
+    import time
+    dev, dt = lay.device, lay.dtype
+    H, S, T, D, P, Sl, me, Hl = lay.H, lay.S, lay.T, lay.D, lay.P, lay.Sl, lay.rank, lay.Hl
+    order = list(head_order)
+    if break_order and me == P - 1 and H > 1:
+        order[0], order[-1] = order[-1], order[0]
+    mine = order[lay.starts[me]:lay.starts[me + 1]]
+    tok_local = torch.arange(me * Sl, (me + 1) * Sl)
+    shards = [tag_rows(t, range(H), tok_local, 1, D, dt, dev) for t in range(3)]
+    texts = [tag_rows(t, range(H), torch.arange(T), 2, D, dt, dev) for t in range(3)] if T else None
+    out_shard = torch.zeros((H, Sl, D), dtype=dt, device=dev)
+    out_text = torch.zeros((H, T, D), dtype=dt, device=dev) if T else None
+    rv = lay.rows_video
+
+    def attend(g0, g1, gi):  # identity attention: the output rows of a head slot are its query rows
+        bufs[3][:rv].view(P, Hl, Sl, D)[:, g0:g1].copy_(bufs[0][:rv].view(P, Hl, Sl, D)[:, g0:g1])
+        if T:
+            bufs[3][rv:].view(Hl, Sl, D)[g0:g1, :T].copy_(bufs[0][rv:].view(Hl, Sl, D)[g0:g1, :T])
+
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    exchange_and_attend(lay, shards, bufs, order, texts, groups, attend, out_shard, out_text, vwire=vwire)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) * 1e3
+
+    failed = []
+    rm = lay.row_map.long()
+    all_tok = torch.arange(S)
+    n16 = 2 if vwire is not None else 3
+    for t in range(n16):
+        got = lay.head_view(bufs[t])
+        if not torch.equal(got[:, rm[:S]], tag_rows(t, mine, all_tok, 1, D, dt, dev)):
+            failed.append("qkv"[t] + " video rows")
+        if T and not torch.equal(got[:, rm[S:S + T]], tag_rows(t, mine, torch.arange(T), 2, D, dt, dev)):
+            failed.append("qkv"[t] + " text rows")
+    if vwire is not None:  # the bytes and scales of ONE conversion over the assembled sequence of this rank's heads
+        v_full = tag_rows(2, mine, all_tok, 1, D, dt, dev)
+        amax = torch.zeros((Hl, D), dtype=torch.float32, device=dev)
+        ops.fp8_v_absmax(v_full, amax)
+        if T:
+            v_txt = tag_rows(2, mine, torch.arange(T), 2, D, dt, dev)
+            ops.fp8_v_absmax(v_txt, amax)
+        exp8 = torch.empty((Hl, S, D), dtype=torch.uint8, device=dev)
+        vd = torch.empty((Hl, D), dtype=torch.float32, device=dev)
+        ops.fp8_v_convert(v_full, amax, exp8, v_descale=vd)
+        got8 = lay.head_view(vwire.buf)
+        if not torch.equal(got8[:, rm[:S]], exp8):
+            failed.append("v video rows (e4m3 on the wire)")
+        if T:
+            exp8t = torch.empty((Hl, T, D), dtype=torch.uint8, device=dev)
+            ops.fp8_v_convert(v_txt, amax, exp8t)
+            if not torch.equal(got8[:, rm[S:S + T]], exp8t):
+                failed.append("v text rows (e4m3)")
+        if not torch.equal(vwire.descale(0, Hl), vd):
+            failed.append("v_descale")
+    if not torch.equal(out_shard, shards[0]):
+        failed.append("returned sequence shard")
+    if T and not torch.equal(out_text, texts[0]):
+        failed.append("gathered text rows")
+    ok = torch.tensor([0 if failed else 1], dtype=torch.int32, device=dev)
+    if P > 1 and not lay.loopback:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=lay.group)
+    esz = torch.empty((), dtype=dt).element_size()
+    away = (H - Hl) * Sl * D  # elements of one tensor this rank sends to its peers
+    back = Hl * (S - Sl) * D  # ... and receives from them
+    nbytes = (n16 * esz + (1 if vwire is not None else 0)) * (away + back) + esz * (away + back)  # q, k, v in; o back
+    nbytes += esz * (P - 1) * max(lay.counts) * T * D * 2 if T else 0  # text all-gather (padded to the largest count)
+    return {"ok": bool(int(ok.item())), "failed_on_this_rank": failed, "bytes": int(nbytes), "ms": round(ms, 3),
+            "what": f"tagged q,k,v through layer 0's exchange ({'v as e4m3, ' if vwire is not None else ''}"
+                    f"{len(groups)} slot group(s), head counts {lay.counts}), identity attention, exact compare on every rank"}
 
 
 _GROUP_STREAMS = {}
@@ -585,8 +695,7 @@ class _RankState:
                     self.f8.v.random_(0, 120)  # finite e4m3 bytes in the chunks no peer fills
         self.geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], lay.device,
                                    row_map=lay.row_map)
-        if te or cfg["model"] == "wan":
-            self.geom.sta_tables(te)
+        self.geom.prebuild(te if cfg["model"] == "hunyuan" else 0)
 
 
 class UlyssesRoutedAttention:
@@ -650,6 +759,14 @@ class UlyssesRoutedAttention:
         self.out_shard = torch.empty((H, self.Sl, 128), dtype=dtype, device=device)
         self.out_text = torch.empty((H, T, 128), dtype=dtype, device=device) if T else None
 
+    def selfcheck(self, l: int = 0, break_order: bool = False) -> dict:
+        """`exchange_selfcheck` on layer l's placement, buffers and transport (before the warm-up of bench.py's N > 1 run)"""
+        lay = self.lays[l]
+        st = self.states[lay.Hl]
+        if st.vwire is not None:
+            st.vwire.lay = lay
+        return exchange_selfcheck(lay, self.orders[l], self.groups[l], st.bufs, vwire=st.vwire, break_order=break_order)
+
     def layer(self, l: int):
         from ..routed import routed_attention
         shards, texts = self.sets[l % len(self.sets)]
@@ -670,5 +787,7 @@ class UlyssesRoutedAttention:
                              text_len=self.cfg["text"], text_valid=self.te, out=o[g0:g1], concurrent=self.concurrent,
                              fused=self.fused, sliding_block_rows=self.sliding_block_rows, fp8=False, fp8_views=views)
 
+        # every cached table of this layer exists before the slot groups fork onto their streams (the routing lists were
+        # copied to the device in __init__)
         exchange_and_attend(lay, shards, st.bufs, self.orders[l], texts, self.groups[l], attend, self.out_shard,
-                            self.out_text, vwire=st.vwire)
+                            self.out_text, vwire=st.vwire, prepare=lambda: st.geom.prebuild(self.te if self.cfg["model"] == "hunyuan" else 0))
