@@ -204,8 +204,10 @@ typedef struct vorta_fp8_quant_args {
 /* flags bit2: q and k only -- v, v8 and v_descale are not touched (v arrived as e4m3: vorta_fp8_v_convert on the sender)
  * flags bit3: statistics only -- the sample partials of the tokens this call holds go to their slots of `ws`, nothing is
  *             converted.  Zero the partial region first (vorta_fp8_quant_ws_partials), call once per piece of the sequence
- *             (a shard must hold whole eighths of the video tokens: token_offset and n_tokens multiples of video_tokens / 8;
- *             the tail tokens in a call of their own), ADD the regions of all ranks (disjoint slots: exact);
+ *             (a shard must hold whole eighths of the video tokens: token_offset and token_offset + n_tokens each equal to
+ *             floor(b video_tokens / 8) for some b, or to total_tokens -- anything else is VORTA_EINVAL, a cut chunk would be
+ *             summed by nobody; the tail tokens in a call of their own or behind the last eighth), ADD the regions of all
+ *             ranks (disjoint slots: exact);
  * flags bit4: no statistics -- multipliers and centres from the partials already in `ws`, then the conversion of the tokens
  *             this call holds.  bit3 calls + all-reduce + bit4 calls write the bytes ONE plain call over the assembled
  *             sequence writes: the send side of the Ulysses exchange moves q and k as e4m3 (vorta/ulysses/utils.py:61-91

@@ -44,7 +44,7 @@ def test_config0_wan13b_49f_native_attention():
     assert (out2.float() - const.float()).abs().max().item() <= 2e-2
 
 
-def _verify_samples(model, geom, q, k, v, experts, rows_of, dtype, seed, text=(0, 0)):
+def _verify_samples(model, geom, q, k, v, experts, rows_of, dtype, seed, text=(0, 0), layout=None):
     """Per expert: sampled query rows against the oracle run on the key / query lists the kernels used (the tables are
     bit-exact vs the reference at small size), plus the structural properties.  q,k,v: (1,H,S+T,128) in TOKEN order;
     rows_of(h, token_ids) -> the kernel's output rows of head h for those tokens (whatever layout it wrote them in)."""
@@ -93,6 +93,77 @@ def _verify_samples(model, geom, q, k, v, experts, rows_of, dtype, seed, text=(0
             ref = O.dense_attention(f64(q[0, h, trow]), f64(k[0, h, keys]), f64(v[0, h, keys]))
             assert np.abs(got(h, trow) - ref).max() <= tol, h
             assert torch.all(rows_of(h, torch.arange(S + te, S + T, device=dev())) == 0)
+    _lists_vs_oracle(model, geom, q, k, h_low, seed, text, layout)
+
+
+def _lists_vs_oracle(model, geom, q, k, h_low, seed, text=(0, 0), layout=None):
+    """The lists the kernels READ THROUGH at full size against the oracle's own index code -- nothing here comes from the
+    library except the lists under test (`_verify_samples` feeds the oracle the kernel's lists).
+      * coreset (coreset_select.py:98-113): 512 random window groups -> O.coreset_similarity on those groups -> centre, kept
+        and dropped margins index for index wherever the similarity gaps exceed fp32 noise (Q matching; Hunyuan: K too);
+      * sliding tile (sliding_attn_flex.py:93-128, tile.py:7-41): q_rows == O.tile_major_order; 32 random query tiles: the key
+        rows of the tile == the tokens of the tiles O.sta_window_tiles lets it see (+ the valid text); the same for 32
+        workgroups of the merged launch table (query tiles of equal key lists share a group).
+    `layout` = (q_view, k_view, row_map): the lists of a sequence-parallel rank are rows of its receive buffers."""
+    from vorta_amd import ops
+    S, (T, te) = geom.S, text
+    rng = np.random.default_rng(seed)
+    rm = None if layout is None else layout[2].long().cpu().numpy()
+    to_rows = (lambda tok: tok) if rm is None else (lambda tok: rm[tok])
+    gi = O.group_info(geom.latent, geom.group, geom.rate)
+    G, nk = gi.n_groups, gi.n_keep_margin
+    assert G == geom.G and nk == geom.n_keep
+    idx = np.sort(rng.choice(G, size=min(512, G), replace=False))
+    sub = O.GroupInfo(center=gi.center[idx], margin=gi.margin[idx], n_keep_margin=nk)
+    for which, x, n_tail in (("q", q, T), ("k", k, te)) if model == "hunyuan" else (("q", q, T),):
+        if layout is None:
+            keep, drop = ops.coreset_select(x[0, h_low:h_low + 1], geom.latent, geom.group, nk, tail_first=S, n_tail=n_tail)
+        else:
+            xv = layout[0] if which == "q" else layout[1]
+            keep, drop = ops.coreset_select(xv[h_low:h_low + 1], geom.latent, geom.group, nk, tail_first=S, n_tail=n_tail,
+                                            row_map=layout[2])
+        keep, drop = keep[0].cpu().numpy(), drop[0].cpu().numpy()
+        xh = x[0, h_low, :S].double().cpu().numpy()[None, None]
+        sims = O.coreset_similarity(xh, sub)[0, 0]  # (n, g-1), float64 on the same rounded inputs
+        order = np.argsort(sims, axis=-1, kind="stable")
+        kept_ref = np.take_along_axis(sub.margin, order[:, :nk], axis=1)
+        drop_ref = np.take_along_axis(sub.margin, order[:, nk:], axis=1)
+        clear = np.diff(np.sort(sims, axis=-1), axis=-1).min(-1) > 1e-5
+        assert clear.mean() > 0.9, (which, clear.mean())
+        assert np.array_equal(keep[:G][idx], to_rows(sub.center[:, 0])), which
+        assert np.array_equal(keep[G:G + G * nk].reshape(G, nk)[idx][clear], to_rows(kept_ref)[clear]), which
+        assert np.array_equal(drop[idx][clear], to_rows(drop_ref)[clear]), which
+        assert np.array_equal(keep[G + G * nk:], to_rows(np.arange(S, S + n_tail))), which
+    # ---- sliding tile ----
+    q_rows, kv_rows, n_kv = geom.sta_tables(te)
+    q_rows, kv_rows = q_rows.cpu().numpy(), kv_rows.cpu().numpy()
+    perm = O.tile_major_order(geom.latent, geom.tile)
+    assert np.array_equal(q_rows, to_rows(perm))
+    sees = O.sta_window_tiles(geom.latent, geom.tile, geom.window)
+    tok, n_tiles = geom.tok, S // geom.tok
+    text_rows = to_rows(np.arange(S, S + te))
+
+    def keys_of(ti):
+        return np.concatenate([to_rows(perm[j * tok:(j + 1) * tok]) for j in np.nonzero(sees[ti])[0]] + [text_rows])
+
+    for ti in rng.choice(n_tiles, size=min(32, n_tiles), replace=False):
+        want = keys_of(ti)
+        assert n_kv == want.size and np.array_equal(np.sort(kv_rows[ti]), np.sort(want)), ti
+    # the launch the routed op submits: merged groups of query tiles with equal key lists
+    q_m, lists, n_kv_m, table, n_lists = geom.sta_launch_tables(te, 256)
+    q_m, lists, table = q_m.cpu().numpy(), lists.cpu().numpy(), table.cpu().numpy()
+    assert n_kv_m == n_kv and np.array_equal(np.sort(q_m), np.sort(q_rows)) and lists.shape[0] == n_lists
+    covered = np.zeros(S, dtype=np.int32)
+    for g, p0, p1 in table:
+        covered[p0:p1] += 1
+    assert (covered == 1).all()  # every query position in exactly one workgroup
+    inv = np.empty(S + T if rm is None else int(rm.max()) + 1, dtype=np.int64)
+    inv[q_rows] = np.arange(S) // tok  # row -> its tile (tile-major position / tokens per tile)
+    for b in rng.choice(table.shape[0], size=min(32, table.shape[0]), replace=False):
+        g, p0, p1 = table[b]
+        tiles = np.unique(inv[q_m[p0:p1]])
+        for ti in tiles:
+            assert np.array_equal(np.sort(lists[g]), np.sort(keys_of(ti))), (b, ti)
 
 
 def _sampled_expert_checks(model, latent, tile, group, H, experts, dtype, seed, text=(0, 0), fp8=False):
@@ -189,7 +260,9 @@ def test_config3_one_rank_of_eight_at_full_size():
     routed_attention(*(lay.head_view(b) for b in bufs), HeadRouting.from_expert_ids(experts, dev()), geom,
                      model="hunyuan", text_len=T, text_valid=te, out=lay.head_view(obuf))
     ov, rm = lay.head_view(obuf), lay.row_map.long()
-    _verify_samples("hunyuan", geom, q, k, v, experts, lambda h, ids: ov[h][rm[ids]], dtype, 501, (T, te))
+    views = [lay.head_view(b) for b in bufs]
+    _verify_samples("hunyuan", geom, q, k, v, experts, lambda h, ids: ov[h][rm[ids]], dtype, 501, (T, te),
+                    layout=(views[0], views[1], lay.row_map))
 
 
 def test_config4_one_rank_of_eight_fp8_at_full_size():

@@ -548,3 +548,9 @@ def test_quantizer_sequence_shards_write_the_bytes_of_one_call(P, T):
                          center_k=True, phase="convert", token_offset=0, total_tokens=S + T, video_tokens=S, src_map=part_map)
     assert torch.equal(q8b[0], whole.q[3, :Sl]) and torch.equal(k8b[2], whole.k[4, :Sl])
     assert (q8b[[1, 3, 4]] == 77).all() and (k8b[[1, 3, 4]] == 77).all()
+    # a statistics call whose shard cuts a sample chunk is refused (nobody would sum that chunk: empty sample, no error)
+    for off, n in ((0, Sl - 8), (8, Sl - 8), (S // 8 + 16, S // 8)):
+        with pytest.raises(ValueError):  # VORTA_EINVAL
+            ops.fp8_quantize_qkv(q[:, off:off + n], k[:, off:off + n], None,
+                                 out=ops.Fp8Operands(dummy, dummy, dummy, whole.v_descale, ws), center_k=True, phase="stats",
+                                 token_offset=off, total_tokens=S + T, video_tokens=S)

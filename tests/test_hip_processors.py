@@ -357,7 +357,7 @@ def _sp_worker(rank, world, port, ret):
     for sc, ref in ((score, full), (score2, full2)):
         for groups in (1, 2):
             _sp.SP_PLACEMENT, _sp.SP_GROUPS = "uneven", groups
-            _sp._LAYOUTS.clear()
+            _sp._LAYOUTS.clear(); _sp._BUFFERS.clear()
             part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
             err = max(err, float((part.float() - ref[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item()))
             counts |= {k[-1] for k in _sp._LAYOUTS if isinstance(k[-1], tuple)}
@@ -421,7 +421,7 @@ def _sp_worker_fp8(rank, world, port, ret):
     for groups, v_wire, placement in ((1, True, "even"), (1, False, "even"), (2, True, "even"), (3, False, "even"),
                                       (1, True, "uneven"), (2, False, "uneven")):
         _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = groups, v_wire, placement
-        _sp._LAYOUTS.clear()
+        _sp._LAYOUTS.clear(); _sp._BUFFERS.clear()
         for center in (False, True):
             routed.FP8_CENTER_K = center
             sc, fl, nt = (score2, full2, nat2) if placement == "uneven" else (score, full, nat)
@@ -431,7 +431,7 @@ def _sp_worker_fp8(rank, world, port, ret):
     vorta_amd.set_attention_precision("fp8pv")
     for groups, placement in ((1, "even"), (2, "even"), (2, "uneven")):
         _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = groups, True, placement
-        _sp._LAYOUTS.clear()
+        _sp._LAYOUTS.clear(); _sp._BUFFERS.clear()
         sc, fl, nt = (score2, fullpv2, nat2) if placement == "uneven" else (score, fullpv, nat)
         part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
         ref = fl[:, rank * Sl:(rank + 1) * Sl].float()

@@ -3,6 +3,8 @@
 //           64 x 32 output tile per wave and the same FLOPs per iteration; zeros as the control (cycles only);
 //   part B  the same with the A operand of every MFMA re-read from LDS by ds_read_b128 (1 KiB per 32 pipe cycles in both
 //           shapes: a 16x16x32 fragment feeds two MFMAs);
+//   part D  (argv[1] & 8) the product step with the K/V tile stream beside it (LDS-DMA, 32 or 16 KiB per step and workgroup,
+//           from an L2-resident region or from beyond the L2)
 //   part C  an attention-shaped step (scores one block ahead, exp2 / row sum / convert on the VALU, P V, one barrier per
 //           step, the product kernel's issue recipe) in three forms: 32x32x16 with 1 KiB of LDS fragment reads per MFMA
 //           (= the product loop, 32 query rows per wave), the same with every fragment feeding TWO MFMAs (0.5 KiB per
@@ -122,12 +124,32 @@ __global__ __launch_bounds__(512) void bare(long long* out, int iters) {
 // MODE 0: 16 + 16 MFMAs (32x32x16), 16 K-fragment reads + 32 transposed V reads.
 // MODE 1: the same MFMAs, every fragment read feeding two of them (8 + 16 reads).
 // MODE 2: 32 + 32 MFMAs (16x16x32), 16 K-fragment reads + 32 transposed V reads (a fragment feeds both query tiles).
-template <typename T, int MODE, int VALU>
-__global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters) {
+// DMA (MODE 0, 1): the K/V stream of the product loop beside the step -- per step and workgroup 32 KiB (DMA = 1: a 256-row
+// workgroup) or 16 KiB (DMA = 2: what a 512-row workgroup would stream per FLOP) of 256-byte rows from `src` (consecutive rows
+// of a `src_rows`-row region, a different region per workgroup) by LDS-DMA into a ring behind the tiles the fragments read;
+// s_waitcnt vmcnt(0) before the step's barrier, as in the product.
+template <typename T, int MODE, int VALU, int DMA = 0>
+__global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters, const char* src = nullptr, int src_rows = 0) {
   using V8 = typename M<T>::v8;
   using V4 = typename M<T>::v4;
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+  __shared__ __attribute__((aligned(16))) char smem[(DMA ? 6 : 2) * TILE];
   fill_lds<T, 1>(smem);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
+  int dma_row = (int)((blockIdx.x * 7919u) % (unsigned)(src_rows > 0 ? src_rows : 1));
+#define PROBE_DMA(slot_)                                                                                        \
+  if (DMA) {                                                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < (DMA == 1 ? 4 : 2); ++i_) {                                        \
+      const int row_ = dma_row + 4 * (4 * wave + i_) + ((threadIdx.x & 63) >> 4);                               \
+      const int off_ = (int)__umul24((unsigned)(row_ < src_rows ? row_ : row_ - src_rows), 256u) +              \
+                       ((((threadIdx.x & 15) ^ (row_ & 15))) << 4);                                             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)(smem + (2 + 2 * (slot_)) * TILE + (4 * wave + i_) * 1024), \
+                                               16, off_, 0, 0, 0);                                              \
+    }                                                                                                           \
+    dma_row += 128;                                                                                             \
+    if (dma_row >= src_rows) dma_row -= src_rows;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  }
   const int lane = threadIdx.x & 63;
   const int r32 = lane & 31, hh = lane >> 5;
   V8 qf[8];
@@ -152,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters) {
     asm volatile("" : "+v"(minit));
 #define STEP32(c0_, c1_, n0_, n1_, kslot_)                                                                       \
   {                                                                                                              \
+    PROBE_DMA(kslot_)                                                                                            \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                                                        \
       if (MODE == 0) {                                                                                           \
         const V8 k0_ = *(const V8*)(smem + k_rd[ks_] + (kslot_) * 0);                                            \
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    \
       }                                                                                                          \
     }                                                                                                            \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
   }
     V8 vf_;
     _Pragma("unroll") for (int i = 0; i < 8; ++i) vf_[i] = (T)0.f;
@@ -350,6 +373,8 @@ void run(const char* label, long long* d, int grid, double flop_per_wave_iter, d
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
+static char* g_src = nullptr;
+
 template <typename T>
 void all(long long* d, int parts) {
   const int G = 256;
@@ -366,6 +391,19 @@ void all(long long* d, int parts) {
            VALU ? "exp+sum+cvt+max" : "cvt only");                                                                         \
   run(lab, d, G, 2.0 * 32 * 64 * 128 * 2 * 2, 2.0, 12000, [&](int it) { hipLaunchKernelGGL((attn_like<T, MODE, VALU>), dim3(G), dim3(512), 0, 0, d, it); });
   if (parts & 4) { ATT(0, 1) ATT(1, 1) ATT(2, 1) ATT(0, 0) ATT(1, 0) ATT(2, 0) }
+#define ATTD(MODE, DMA, ROWS, WHERE)                                                                                       \
+  snprintf(lab, sizeof lab, "%s step %s + %d KiB K/V stream per step (%s)", M<T>::name(),                                  \
+           MODE == 0 ? "1 KiB LDS/MFMA" : "0.5 KiB LDS/MFMA", DMA == 1 ? 32 : 16, WHERE);                                  \
+  run(lab, d, G, 2.0 * 32 * 64 * 128 * 2 * 2, 2.0, 12000, [&](int it) {                                                    \
+    hipLaunchKernelGGL((attn_like<T, MODE, 1, DMA>), dim3(G), dim3(512), 0, 0, d, it, (const char*)g_src, ROWS); });
+  if (parts & 8) {
+    ATT(0, 1)
+    ATTD(0, 1, 8192, "2 MiB region: L2 hits")
+    ATTD(0, 1, 1 << 20, "256 MiB region: beyond L2")
+    ATTD(0, 2, 8192, "2 MiB region: L2 hits")
+    ATTD(1, 2, 8192, "2 MiB region: L2 hits")
+    ATTD(1, 2, 1 << 20, "256 MiB region: beyond L2")
+  }
 }
 
 int main(int argc, char** argv) {
@@ -373,6 +411,8 @@ int main(int argc, char** argv) {
   const int rounds = argc > 2 ? atoi(argv[2]) : 2;
   long long* d;
   hipMalloc(&d, sizeof(long long) * 4 * 1024);
+  hipMalloc(&g_src, (size_t)(1 << 20) * 256 + 65536);
+  hipMemset(g_src, 0x3c, (size_t)(1 << 20) * 256 + 65536);  // finite 16-bit patterns; the landed tiles are never read
   for (int r = 0; r < rounds; ++r) {
     printf("---- round %d ----\n", r);
     all<_Float16>(d, parts);

@@ -17,6 +17,7 @@ from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balance
                               slot_groups)
 
 _LAYOUTS = {}
+_BUFFERS = {}  # receive buffers per (geometry, head-slot count): a handful, kept when the layout cache is trimmed
 _ROUTINGS = {}  # (local expert ids, device) -> HeadRouting: the device tables are built once per distinct local mix
 SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
 # fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
@@ -37,6 +38,7 @@ class _SpBuffers:
         self.bufs = [lay.new_buffer() for _ in range(4)]
         self.f8 = None
         self.vwire = None
+        self._wire = None
 
     def fp8(self, mode=True):
         """(operands, v wire) of the e4m3 path; mode "fp8pv" (16-bit scores): only the e4m3 receive buffer of v"""
@@ -48,7 +50,10 @@ class _SpBuffers:
             return None, self.vwire
         if self.f8 is None:
             self.f8 = self.lay.fp8_operands()
+            self._wire = None
+        if self._wire != SP_V_WIRE:  # (the switch may change between calls in A/B runs: the wire follows it)
             self.vwire = VWire(self.lay, self.f8.v[0]) if SP_V_WIRE else None
+            self._wire = SP_V_WIRE
         return self.f8, self.vwire
 
 
@@ -62,10 +67,12 @@ def _layout(H, S, T, D, device, dtype, counts=None):
             _LAYOUTS.clear()
         _LAYOUTS[lkey] = UlyssesLayout(H, S, T, D, P, rank, device, dtype, SP_STATE.group, counts=counts)
     lay = _LAYOUTS[lkey]
-    bkey = (H, S, T, D, P, rank, str(device), dtype, "buffers", lay.Hl)
-    if bkey not in _LAYOUTS:
-        _LAYOUTS[bkey] = _SpBuffers(lay)
-    return lay, _LAYOUTS[bkey]
+    # one buffer set per distinct slot count (at most 2 H / P of them); layouts -- one per distinct tuple of head counts, cheap:
+    # a few integers and a shared row map -- are evicted on their own, so trimming them never drops gigabytes mid-run
+    bkey = (H, S, T, D, P, rank, str(device), dtype, lay.Hl)
+    if bkey not in _BUFFERS:
+        _BUFFERS[bkey] = _SpBuffers(lay)
+    return lay, _BUFFERS[bkey]
 
 
 def _routing(local_experts: tuple, device) -> HeadRouting:

@@ -454,6 +454,17 @@ extern "C" int vorta_fp8_quantize_qkv(const vorta_fp8_quant_args* a, void* hip_s
     head_tokens = p.video_tokens + p.tail_len;
   }
   p.total_tokens = head_tokens;
+  if (stats_only && p.seg_len <= 0 && (a->token_offset || a->total_tokens)) {
+    // a statistics call over a shard owns the sample chunks that lie wholly inside it; a chunk cut by a shard edge would be
+    // summed by nobody (empty sample -> centre 0, unbalanced multipliers, no error): both edges must be chunk boundaries
+    auto boundary = [&](int64_t t) {
+      if (t == head_tokens) return true;
+      for (int b = 0; b <= SAMPLE_CHUNKS; ++b)
+        if ((int64_t)b * p.video_tokens / SAMPLE_CHUNKS == t) return true;
+      return false;
+    };
+    if (!boundary(a->token_offset) || !boundary((int64_t)a->token_offset + a->n_tokens)) return VORTA_EINVAL;
+  }
   p.mean_stride = (int)(head_tokens / MEAN_SAMPLES);
   if (p.mean_stride < 1) p.mean_stride = 1;
   p.mean_stride |= 1;

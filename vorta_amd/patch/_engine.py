@@ -306,7 +306,14 @@ def install_token_shard(model: nn.Module, first_block: nn.Module, gather_before:
             if not ctx.sp_coherent:  # once per pipeline call: one read-back of 2 P floats
                 sums = torch.stack([x.float().sum(), x.float().abs().sum()]).reshape(1, 2)
                 every = all_gather(sums, dim=0)
-                if not bool((every == every[:1]).all()):
+                if not bool(torch.isfinite(every).all()):
+                    raise RuntimeError(
+                        f"the hidden states entering the transformer are not finite on some rank (checksums {every.tolist()}): "
+                        "NaN / inf in the latents or the patch embedding, not a rank-coherence problem")
+                # the embedded sequence comes out of a conv / GEMM whose kernel choice may differ between processes: the
+                # checksums of IDENTICAL latents agree to rounding, those of different noise differ in the first digits
+                tol = 1e-3 * every.abs().max(dim=0, keepdim=True).values + 1e-6
+                if not bool(((every - every[:1]).abs() <= tol).all()):
                     raise RuntimeError(
                         "sequence-parallel ranks entered the transformer with different latents (checksums "
                         f"{every.tolist()}): pass the pipeline a generator seeded identically on every rank, or none")
