@@ -31,17 +31,19 @@ extern "C" {
 #define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
 #define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
 
-#define VORTA_ABI_VERSION 5 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
+#define VORTA_ABI_VERSION 6 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
                                 4: vorta_fp8_quant_args gains slot_first / slot_count and flags bit2, adds vorta_fp8_v_absmax /
                                 vorta_fp8_v_convert; every earlier call means what it meant
                                 5: vorta_fp8_quant_args gains video_tokens / token_offset / total_tokens / src_map and flags
-                                bit3 / bit4 (sequence shards), adds vorta_fp8_quant_ws_partials */
+                                bit3 / bit4 (sequence shards), adds vorta_fp8_quant_ws_partials
+                                6: adds the int8-score entry points (vorta_i8_quantize_k, vorta_attn_fwd_i8, vorta_attn_fwd_batch_i8) */
 
 typedef enum vorta_dtype {
   VORTA_BF16 = 0,
   VORTA_FP16 = 1,
   VORTA_FP32 = 2,    /* vorta_route_scores only */
-  VORTA_FP8E4M3 = 3  /* OCP e4m3fn bytes: q/k/v of vorta_attn_fwd_fp8, output of vorta_fp8_quantize_qkv */
+  VORTA_FP8E4M3 = 3, /* OCP e4m3fn bytes: q/k/v of vorta_attn_fwd_fp8, output of vorta_fp8_quantize_qkv */
+  VORTA_INT8 = 4     /* two's-complement bytes: k8 of vorta_i8_quantize_k / vorta_attn_fwd_i8 (vorta_permute_heads: any 1-byte rows) */
 } vorta_dtype;
 
 /* One (H,S,D) operand: element (h,s,d) lives at ptr + h*stride_h + s*stride_s + d. */
@@ -264,6 +266,70 @@ int vorta_attn_fwd_fp8(const vorta_attn_args* args, const vorta_attn_fp8_ext* ex
 int vorta_attn_fwd_batch_fp8(const vorta_attn_args* args, const vorta_attn_fp8_ext* ext, int32_t n, void* hip_stream);
 
 /*
+ * Int8 scores (ABI 6; BASELINE.json configs[4], no reference counterpart: the reference computes the three experts of
+ * wan.py:243-294 / hunyuan.py:410-507 in the dtype of q, k, v).  precision "i8pv": q k^T on v_mfma_i32_32x32x32_i8 (the
+ * e4m3 MFMA rate) with 7 bits next to every ROW's maximum -- the all-e4m3 path loses 40 dB on peaked or outlier-carried
+ * logits because e4m3 has 3 mantissa bits wherever a value sits -- and P V in e4m3 as in the mixed kernel.
+ *
+ * vorta_i8_quantize_k -- per head h, from ~1024 evenly spaced tokens (the same tokens in the (H,S,D) view and in the segmented
+ *   Ulysses receive layout): centre c[h][d] = mean k (softmax-invariant), smoothing s[h][d] = (var_k[d] / mean q[d]^2)^(1/4)
+ *   clamped to [1/8, 8] (q diag(s) . k diag(1/s) = q . k exactly; balances the channel ranges of the two operands, which is
+ *   what a FIXED-point format needs when a few qk-norm channels carry the logits).  Then one pass over k:
+ *       kt = (k - c[h]) / s[h]        sk[row] = max_d |kt| / 127  (1 for an all-zero row)      k8[row][d] = rint(kt / sk[row])
+ *   Outputs: k8 (int8 rows of head_dim bytes), k_scale (one float per row) and q_smooth = s (heads x head_dim floats; the
+ *   attention kernel multiplies its query rows by it before quantising them itself).
+ */
+typedef struct vorta_i8_quant_args {
+  uint32_t struct_size;
+  int32_t dtype;            /* input dtype: VORTA_BF16 / VORTA_FP16 */
+  int32_t head_dim, heads;  /* 128, H */
+  int32_t n_tokens;         /* rows of every head (seg_len == 0) or of the row array (seg_len > 0) */
+  vorta_tensor q, k;        /* inputs, strides in elements; q is only sampled (smoothing statistics) */
+  vorta_tensor k8;          /* out: int8, strides in bytes, rows 16-byte aligned; same head / row geometry as k */
+  float* k_scale;           /* out: k_scale[h * k_scale_stride_h + row]  (seg_len > 0: k_scale[row]) */
+  int64_t k_scale_stride_h;
+  float* q_smooth;          /* out [heads][head_dim]: s */
+  float* ws;                /* workspace, 2 * heads * head_dim floats: centre | 1 / s */
+  int32_t flags;            /* bit0: no smoothing (s = 1); bit1: no centring (c = 0) */
+  int32_t seg_len;          /* as vorta_fp8_quant_args: 0 = (heads, n_tokens, D) views; > 0 = one row array, row r belongs to */
+  int32_t tail_first;       /* head (r / seg_len) % heads, tail (text) rows from tail_first on, tail_len per segment */
+  int32_t tail_len;
+  int32_t slot_first;       /* seg_len > 0: only head slots [slot_first, slot_first + slot_count) (0, 0 = all) */
+  int32_t slot_count;
+  int32_t video_tokens;     /* seg_len == 0: tokens before a head's tail (text) tokens, 0 = all (the sample's token order is */
+  int32_t reserved;         /* video tokens then tail tokens in both layouts) */
+} vorta_i8_quant_args;
+
+int vorta_i8_quantize_k(const vorta_i8_quant_args* args, void* hip_stream);
+
+/*
+ * vorta_attn_fwd_i8 -- the gather flash-attention of vorta_attn_fwd with int8 scores and e4m3 P V.
+ *   args->q: 16-bit (args->dtype), strides in elements.  Every wave multiplies its 32 query rows by q_smooth[head], takes
+ *            each row's abs-max (sq = amax / 127) and rounds the row to int8 itself -- queries are read once per workgroup;
+ *   args->k: the int8 rows of vorta_i8_quantize_k, strides in BYTES; k_scale its per-row scales (indexed like k rows:
+ *            head * k_scale_stride_h + row, through kv_rows when given);
+ *   args->v: e4m3 (vorta_fp8_v_absmax / vorta_fp8_v_convert), strides in bytes, with v_descale as in vorta_attn_fp8_ext;
+ *   args->o: 16-bit (args->dtype).
+ *   score of (query i, key j) in the exp2 domain = scale log2(e) sq[i] sk[j] (q8[i] . k8[j]); probabilities P 2^p_bias are
+ *   packed to e4m3 per 64-key block against the wave's reference point exactly as in the mixed kernel (ext->flags bit1 of
+ *   vorta_attn_fwd_fp8), whose tables, groups, duplicates, split keys and fused grid this entry shares.
+ */
+typedef struct vorta_attn_i8_ext {
+  uint32_t struct_size;
+  int32_t flags;               /* reserved, 0 */
+  const float* k_scale;
+  int64_t k_scale_stride_h;    /* floats between heads of k_scale */
+  const float* q_smooth;       /* [..][head_dim], indexed by the head id */
+  int64_t q_smooth_stride_h;
+  const float* v_descale;      /* [..][head_dim], indexed by the head id */
+  int64_t v_descale_stride_h;
+  float p_bias, defer;         /* as vorta_attn_fp8_ext (0 = defaults 5 and 3) */
+} vorta_attn_i8_ext;
+
+int vorta_attn_fwd_i8(const vorta_attn_args* args, const vorta_attn_i8_ext* ext, void* hip_stream);
+int vorta_attn_fwd_batch_i8(const vorta_attn_args* args, const vorta_attn_i8_ext* ext, int32_t n, void* hip_stream);
+
+/*
  * vorta_coreset_select -- coreset_select.py:68-124 (ranking part) + :159-166 (scatter destinations).
  *
  * For every head slot and every window group of g = gw[0]*gw[1]*gw[2] tokens of the (t,h,w) latent:
@@ -434,7 +500,8 @@ int vorta_abi_version(void);
 const char* vorta_build_info(void); /* static string: arch, compiler */
 int vorta_last_hip_error(void);     /* last hipError_t seen by a failed launch in this thread */
 int vorta_sizeof(int which);        /* 0 tensor, 1 attn_args, 2 coreset_args, 3 sta_args, 4 router_args, 5 norm_rope_args,
-                                       6 mix_args, 7 fp8_quant_args, 8 attn_fp8_ext, 9 permute_args, 10 fp8_v_args */
+                                       6 mix_args, 7 fp8_quant_args, 8 attn_fp8_ext, 9 permute_args, 10 fp8_v_args,
+                                       11 i8_quant_args, 12 attn_i8_ext */
 
 #ifdef __cplusplus
 }

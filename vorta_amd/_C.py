@@ -11,8 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvorta_hip.so")
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
-VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3 = 0, 1, 2, 3
-ABI_VERSION = 5
+VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3, VORTA_INT8 = 0, 1, 2, 3, 4
+ABI_VERSION = 6
 
 _i32, _i64, _u32, _f32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
 
@@ -119,6 +119,23 @@ class AttnFp8Ext(C.Structure):
     ]
 
 
+class I8QuantArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32), ("n_tokens", _i32),
+        ("q", Tensor), ("k", Tensor), ("k8", Tensor), ("k_scale", _vp), ("k_scale_stride_h", _i64),
+        ("q_smooth", _vp), ("ws", _vp), ("flags", _i32), ("seg_len", _i32), ("tail_first", _i32), ("tail_len", _i32),
+        ("slot_first", _i32), ("slot_count", _i32), ("video_tokens", _i32), ("reserved", _i32),
+    ]
+
+
+class AttnI8Ext(C.Structure):
+    _fields_ = [
+        ("struct_size", _u32), ("flags", _i32), ("k_scale", _vp), ("k_scale_stride_h", _i64),
+        ("q_smooth", _vp), ("q_smooth_stride_h", _i64), ("v_descale", _vp), ("v_descale_stride_h", _i64),
+        ("p_bias", _f32), ("defer", _f32),
+    ]
+
+
 # every symbol include/vorta_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "vorta_attn_fwd": (C.c_int, [C.POINTER(AttnArgs), _vp]),
@@ -132,6 +149,9 @@ SYMBOLS = {
     "vorta_fp8_v_convert": (C.c_int, [C.POINTER(Fp8VArgs), _vp]),
     "vorta_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _vp]),
     "vorta_attn_fwd_batch_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _i32, _vp]),
+    "vorta_i8_quantize_k": (C.c_int, [C.POINTER(I8QuantArgs), _vp]),
+    "vorta_attn_fwd_i8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnI8Ext), _vp]),
+    "vorta_attn_fwd_batch_i8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnI8Ext), _i32, _vp]),
     "vorta_coreset_select": (C.c_int, [C.POINTER(CoresetArgs), _vp]),
     "vorta_sta_table_sizes": (C.c_int, [C.POINTER(StaArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "vorta_sta_build_tables": (C.c_int, [C.POINTER(StaArgs), _vp]),
@@ -180,7 +200,7 @@ def lib():
     if h.vorta_abi_version() != ABI_VERSION:
         raise VortaHipError(f"ABI mismatch: library {h.vorta_abi_version()} vs binding {ABI_VERSION}")
     for which, st in enumerate((Tensor, AttnArgs, CoresetArgs, StaArgs, RouterArgs, NormRopeArgs, MixArgs, Fp8QuantArgs,
-                                AttnFp8Ext, PermuteArgs, Fp8VArgs)):
+                                AttnFp8Ext, PermuteArgs, Fp8VArgs, I8QuantArgs, AttnI8Ext)):
         if h.vorta_sizeof(which) != C.sizeof(st):
             raise VortaHipError(f"struct layout mismatch for {st.__name__}: "
                                 f"C {h.vorta_sizeof(which)} vs ctypes {C.sizeof(st)}")

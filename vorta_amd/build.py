@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(CSRC, "libvorta_hip.so")
-SOURCES = ["api.hip", "attn_fwd.hip", "attn_fwd_fp8.hip", "attn_fwd_mx.hip", "fp8_quant.hip", "coreset.hip", "sta_tables.hip", "router.hip",
-           "qk_norm_rope.hip", "mix.hip", "permute.hip"]
+SOURCES = ["api.hip", "attn_fwd.hip", "attn_fwd_fp8.hip", "attn_fwd_mx.hip", "attn_fwd_i8.hip", "fp8_quant.hip", "i8_quant.hip", "coreset.hip",
+           "sta_tables.hip", "router.hip", "qk_norm_rope.hip", "mix.hip", "permute.hip"]
 # -fno-slp-vectorize: the SLP vectoriser packs adjacent fp32 adds of the softmax row sum into v_pk_add_f32 plus the
 # v_mov pairs to feed them -- more instructions on the VALU issue port that bounds the attention loop (+2 % without)
 # -enable-post-misched=0: the post-RA scheduler re-orders the hand-interleaved MFMA / VALU / LDS stream of the attention

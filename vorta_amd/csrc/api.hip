@@ -77,6 +77,15 @@ static const char kBuildInfo[] = "libvorta_hip gfx950 (CDNA4) hipcc " __VERSION_
 #ifdef VORTA_MX_PV_VALU
     " -DVORTA_MX_PV_VALU=" VORTA_STR_(VORTA_MX_PV_VALU)
 #endif
+#ifdef VORTA_I8_SCHED
+    " -DVORTA_I8_SCHED=" VORTA_STR_(VORTA_I8_SCHED)
+#endif
+#ifdef VORTA_I8_SC_VALU
+    " -DVORTA_I8_SC_VALU=" VORTA_STR_(VORTA_I8_SC_VALU)
+#endif
+#ifdef VORTA_I8_PV_VALU
+    " -DVORTA_I8_PV_VALU=" VORTA_STR_(VORTA_I8_PV_VALU)
+#endif
 #ifdef VORTA_SCHED8
     " -DVORTA_SCHED8=" VORTA_STR_(VORTA_SCHED8)
 #endif
@@ -107,6 +116,8 @@ extern "C" int vorta_sizeof(int which) {
     case 8: return (int)sizeof(vorta_attn_fp8_ext);
     case 9: return (int)sizeof(vorta_permute_args);
     case 10: return (int)sizeof(vorta_fp8_v_args);
+    case 11: return (int)sizeof(vorta_i8_quant_args);
+    case 12: return (int)sizeof(vorta_attn_i8_ext);
     default: return -1;
   }
 }

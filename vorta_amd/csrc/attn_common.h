@@ -75,7 +75,8 @@ struct MultiParams {
 
 // attn_fwd.hip: argument validation + launch geometry (in_esize = bytes per q/k element, v_esize per v element: 0 = the
 // same; args->dtype names the 2-byte type, or e4m3 when in_esize = 1)
-int fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize, int v_esize = 0);
+// (k_esize: bytes per k element when it differs from q's -- the int8-score kernel reads 16-bit q and int8 k; 0 = the same)
+int fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize, int v_esize = 0, int k_esize = 0);
 // attn_fwd_mx.hip: 16-bit scores, e4m3 P V (vorta_attn_fwd_fp8 / _batch_fp8 with ext->flags bit1)
 int mx_fwd(const vorta_attn_args* a, const vorta_attn_fp8_ext* ext, void* hip_stream);
 int mx_fwd_batch(const vorta_attn_args* args, const vorta_attn_fp8_ext* ext, int32_t n, void* hip_stream);

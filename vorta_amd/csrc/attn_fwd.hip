@@ -821,8 +821,9 @@ int launch(const Params& p, hipStream_t st, bool pipe) {
 
 // argument validation + launch geometry, shared with the fp8 kernels (attn_fwd_fp8.hip): in_esize = bytes per q/k/v
 // element (2: bf16/fp16, 1: e4m3); the output is always 16-bit
-int vorta_attn::fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize, int v_esize) {
+int vorta_attn::fill_params(const vorta_attn_args* a, Params& p, int& block_rows, int in_esize, int v_esize, int k_esize) {
   if (v_esize == 0) v_esize = in_esize;
+  if (k_esize == 0) k_esize = in_esize;
   if (!a || a->struct_size != sizeof(vorta_attn_args)) return VORTA_EINVAL;
   if (in_esize == 2 ? (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) : a->dtype != VORTA_FP8E4M3) return VORTA_EUNSUPPORTED;
   if (a->head_dim != D) return VORTA_EUNSUPPORTED;
@@ -833,7 +834,7 @@ int vorta_attn::fill_params(const vorta_attn_args* a, Params& p, int& block_rows
   const vorta_tensor* ts[4] = {&a->q, &a->k, &a->v, &a->o};
   for (int i = 0; i < 4; ++i) {
     const vorta_tensor* t = ts[i];
-    const int al = 16 / (i < 2 ? in_esize : i == 2 ? v_esize : 2);  // elements per 16 bytes
+    const int al = 16 / (i == 0 ? in_esize : i == 1 ? k_esize : i == 2 ? v_esize : 2);  // elements per 16 bytes
     if (((uintptr_t)t->ptr & 15) || (t->stride_s % al) || (t->stride_h % al) || t->stride_s < D) return VORTA_EINVAL;
   }
   if (a->n_splits < 1 || a->n_splits > 1024) return VORTA_EINVAL;
@@ -843,18 +844,18 @@ int vorta_attn::fill_params(const vorta_attn_args* a, Params& p, int& block_rows
   if (a->dup_rows && (a->n_dup < 0 || a->n_dup_pos < 0 || a->n_dup_pos > a->n_q)) return VORTA_EINVAL;
   if (a->block_rows != 0 && a->block_rows != 128 && a->block_rows != 256) return VORTA_EINVAL;
   if (a->variant < 0 || a->variant > 2) return VORTA_EINVAL;
-  if (a->variant != 1 && (a->k.stride_s * in_esize >= (1 << 24) || a->v.stride_s * v_esize >= (1 << 24))) return VORTA_EUNSUPPORTED;
+  if (a->variant != 1 && (a->k.stride_s * k_esize >= (1 << 24) || a->v.stride_s * v_esize >= (1 << 24))) return VORTA_EUNSUPPORTED;
   // the pipelined kernel addresses K/V rows with 32-bit buffer offsets (24-bit row x 24-bit stride, 2 GiB window per
   // head): checked here for contiguous key ranges; with a kv_rows table the caller guarantees it (vorta_hip.h)
   if (a->variant != 1 && !a->kv_rows) {
     const int64_t last = (int64_t)a->kv_row_offset + a->n_kv;
-    const int64_t ks = a->k.stride_s * in_esize, vs = a->v.stride_s * v_esize;
+    const int64_t ks = a->k.stride_s * k_esize, vs = a->v.stride_s * v_esize;
     const int64_t ss = ks > vs ? ks : vs;
     if (last >= (1 << 24) || last * ss > 0x7fffffffll) return VORTA_EUNSUPPORTED;
   }
   p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr; p.o = (char*)a->o.ptr;
-  p.q_sh = a->q.stride_h * in_esize; p.k_sh = a->k.stride_h * in_esize; p.v_sh = a->v.stride_h * v_esize; p.o_sh = a->o.stride_h * 2;
-  p.q_ss = a->q.stride_s * in_esize; p.k_ss = a->k.stride_s * in_esize; p.v_ss = a->v.stride_s * v_esize; p.o_ss = a->o.stride_s * 2;
+  p.q_sh = a->q.stride_h * in_esize; p.k_sh = a->k.stride_h * k_esize; p.v_sh = a->v.stride_h * v_esize; p.o_sh = a->o.stride_h * 2;
+  p.q_ss = a->q.stride_s * in_esize; p.k_ss = a->k.stride_s * k_esize; p.v_ss = a->v.stride_s * v_esize; p.o_ss = a->o.stride_s * 2;
   p.head_list = a->head_list; p.n_heads_dev = a->n_heads_dev; p.n_heads = a->n_heads;
   p.n_q = a->n_q; p.q_group_len = a->q_group_len > 0 ? a->q_group_len : a->n_q;
   p.q_row_offset = a->q_row_offset; p.q_valid = a->q_valid;
