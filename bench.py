@@ -184,7 +184,7 @@ def processor_level(cfg, mix, dev, dt, fp8):
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
     width = H * 128
-    vorta_amd.set_attention_precision("fp8pv" if fp8 == "fp8pv" else "fp8" if fp8 else "native")
+    vorta_amd.set_attention_precision(fp8 if fp8 in ("fp8pv", "i8pv") else "fp8" if fp8 else "native")
     gen = torch.Generator(device=dev).manual_seed(1234)
 
     def lin(i, o):
@@ -302,10 +302,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="hunyuan-129f", choices=sorted(CONFIGS))
     ap.add_argument("--mix", default="uniform", choices=sorted(MIXES))
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp8", "fp8pv"],
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp8", "fp8pv", "i8pv"],
                     help="fp8: bf16 inputs, converted to e4m3 inside the timed step (vorta_fp8_quantize_qkv), both "
                          "contractions on the fp8 MFMA, bf16 output; fp8pv: scores in bf16, P V in e4m3 (only v is converted, "
-                         "inside the step)")
+                         "inside the step); i8pv: scores on the int8 MFMA with one scale per row (k converted inside the step, q "
+                         "by the attention kernel), P V in e4m3")
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
     ap.add_argument("--sp-groups", type=int, default=int(os.environ.get("VORTA_SP_GROUPS", "1")),
                     help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
@@ -393,11 +394,12 @@ def main():
     from vorta_amd import ops
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
 
-    dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16
-    fp8 = True if cfg["dtype"] == "fp8" else ("fp8pv" if cfg["dtype"] == "fp8pv" else False)
+    dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16  # (the 8-bit paths take and return bf16)
+    fp8 = True if cfg["dtype"] == "fp8" else (cfg["dtype"] if cfg["dtype"] in ("fp8pv", "i8pv") else False)
     # mixed precision: half of a layer's FLOPs run at the 16-bit rate, half at the e4m3 rate: harmonic mean of the peaks
-    peak = PEAK_MFMA_FP8_TFLOPS if fp8 is True else (2.0 / (1.0 / PEAK_MFMA_TFLOPS + 1.0 / PEAK_MFMA_FP8_TFLOPS)
-                                                     if fp8 == "fp8pv" else PEAK_MFMA_TFLOPS)
+    # (int8 scores run at the e4m3 MFMA rate: the all-8-bit peak)
+    peak = PEAK_MFMA_FP8_TFLOPS if fp8 in (True, "i8pv") else (2.0 / (1.0 / PEAK_MFMA_TFLOPS + 1.0 / PEAK_MFMA_FP8_TFLOPS)
+                                                               if fp8 == "fp8pv" else PEAK_MFMA_TFLOPS)
     H, L, T, te = cfg["heads"], cfg["layers"], cfg["text"], cfg["text_valid"]
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
@@ -431,7 +433,8 @@ def main():
         out = torch.empty_like(sets[0][0])
         # e4m3 operand buffers reused by every layer (the conversion itself runs per layer, inside the step)
         f8buf = (ops.fp8_quantize_qkv(*(x[0] for x in sets[0])) if fp8 is True else
-                 ops.fp8_quantize_v(sets[0][2][0]) if fp8 == "fp8pv" else None)
+                 ops.fp8_quantize_v(sets[0][2][0]) if fp8 == "fp8pv" else
+                 (ops.fp8_quantize_v(sets[0][2][0]), ops.i8_quantize_k(sets[0][0][0], sets[0][1][0])) if fp8 == "i8pv" else None)
         if te:
             geom.sta_tables(te)  # built once per prompt, outside the step (pipeline_hunyuan.py:378-392)
 
@@ -581,7 +584,10 @@ def main():
                               + ") inside the timed step; bf16 in / out"} if fp8 is True else
                       {"fp8pv": "scores on the bf16 MFMA, probabilities and v in e4m3 on the fp8 MFMA; v converted inside the "
                                 "timed step; bf16 in / out; roofline.peak = harmonic mean of the two MFMA peaks (3 333)"}
-                      if fp8 == "fp8pv" else {}),
+                      if fp8 == "fp8pv" else
+                      {"i8pv": "scores on the int8 MFMA (k: centred, channel-balanced, one scale per row, converted inside the "
+                               "timed step; q: converted by the attention kernel), probabilities and v in e4m3 on the fp8 MFMA; "
+                               "bf16 in / out"} if fp8 == "i8pv" else {}),
                    **({"call_path": proc_info, "ms_per_layer": round(ms_per_step / (L * cfg["fwd_per_step"]), 3)}
                       if proc_info is not None else {}),
                    "step_algorithmic_pflop": round(step_flops / 1e15, 3),

@@ -596,3 +596,73 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
                         out[dup_rows[p_]] = res[i]
                         if ambiguous is not None:
                             ambiguous[dup_rows[p_]] = amb[i]
+
+
+# ---------------------------------------------------------------------------------------------- int8 scores (ABI 6)
+# No reference counterpart either: this restates include/vorta_hip.h vorta_i8_quantize_k (csrc/i8_quant.hip) and the query
+# conversion at the head of vorta_attn_fwd_i8 (csrc/attn_fwd_i8.hip) operation for operation in float32, so the kernels can be
+# held to it bit for bit; the attention itself is `fp8_attn_launch` on q8 * sq and k8 * sk (the integer dot product is exact).
+def i8_sample_tokens(n_tokens: int) -> np.ndarray:
+    """tokens of a head's sample: i * stride, stride = (n_tokens // 1024) | 1 (odd, >= 1)"""
+    stride = max(1, n_tokens // 1024) | 1
+    return np.arange(0, n_tokens, stride)
+
+
+def i8_quantize_k(q: np.ndarray, k: np.ndarray, smooth: bool = True, center: bool = True) -> dict:
+    """(H,S,D) arrays of bf16 / fp16-representable values -> dict(k8 int8 (H,S,D), k_scale f32 (H,S), q_smooth f32 (H,D),
+    center f32 (H,D)).  Sample statistics with the kernel's summation order: row lane rl of 64 adds its samples rl, rl + 64,
+    ... in order, the 64 partial sums are added pairwise at distance 32, 16, ..., 1; every product and sum rounded to float32."""
+    f32 = np.float32
+    q, k = np.asarray(q, dtype=f32), np.asarray(k, dtype=f32)
+    H, S, D = k.shape
+    tok = i8_sample_tokens(S)
+    n = f32(len(tok))
+    cen, smo = np.zeros((H, D), f32), np.ones((H, D), f32)
+    for h in range(H):
+        ks, qs = k[h, tok], q[h, tok]
+        part = np.zeros((3, 64, D), f32)
+        for i in range(len(tok)):
+            rl = i % 64
+            part[0, rl] = part[0, rl] + ks[i]
+            part[1, rl] = part[1, rl] + ks[i] * ks[i]
+            part[2, rl] = part[2, rl] + qs[i] * qs[i]
+        off = 32
+        while off > 0:
+            part[:, :off] = part[:, :off] + part[:, off:2 * off]
+            off >>= 1
+        mean = part[0, 0] / n
+        var = part[1, 0] / n - mean * mean
+        mq2 = part[2, 0] / n
+        s = np.ones(D, f32)
+        ok = (var > 0) & (mq2 > 0)
+        if smooth:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                s_all = np.sqrt(np.sqrt((var / mq2).astype(f32)).astype(f32)).astype(f32)
+            s[ok] = np.minimum(np.maximum(s_all[ok], f32(0.125)), f32(8.0))
+        cen[h] = mean if center else 0
+        smo[h] = s
+    inv_s = (f32(1.0) / smo).astype(f32)
+    kt = ((k - cen[:, None, :]).astype(f32) * inv_s[:, None, :]).astype(f32)
+    am = np.abs(kt).max(-1)
+    with np.errstate(divide="ignore"):
+        inv = np.where(am > 0, f32(127.0) / am, f32(0.0)).astype(f32)
+    k8 = np.clip(np.rint((kt * inv[..., None]).astype(f32)), -127, 127).astype(np.int8)
+    k_scale = np.where(am > 0, (am * f32(1.0 / 127.0)).astype(f32), f32(1.0)).astype(f32)
+    return dict(k8=k8, k_scale=k_scale, q_smooth=smo, center=cen)
+
+
+def i8_quantize_q_rows(q: np.ndarray, q_smooth: np.ndarray, scale: Optional[float] = None):
+    """What a wave of vorta_attn_fwd_i8 does with its query rows: (n,D) 16-bit-representable values x the head's (D,)
+    smoothing vector, per-row abs-max, q8 = rint(qt * 127 / amax).  Returns (q8 int (n,D), sqc f32 (n,)): sqc = amax / 127 *
+    scale * log2(e), what one unit of q8 is worth in the exp2 domain (times the key's scale)."""
+    f32 = np.float32
+    q = np.asarray(q, dtype=f32)
+    D = q.shape[-1]
+    c0 = f32(f32(1.0 / np.sqrt(D) if scale is None else scale) * f32(1.4426950408889634))
+    qt = (q * np.asarray(q_smooth, f32)[None, :]).astype(f32)
+    am = np.abs(qt).max(-1)
+    with np.errstate(divide="ignore"):
+        inv = np.where(am > 0, f32(127.0) / am, f32(0.0)).astype(f32)
+    q8 = np.clip(np.rint((qt * inv[:, None]).astype(f32)), -127, 127).astype(np.int64)
+    sq = np.where(am > 0, (am * f32(1.0 / 127.0)).astype(f32), f32(1.0)).astype(f32)
+    return q8, (sq * c0).astype(f32)

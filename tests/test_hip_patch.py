@@ -64,9 +64,12 @@ def _hy_inputs(seed=1):
 
 
 class _Recorder:
-    """wraps `routed_attention` inside a processor module: records the inputs and the output view per call"""
+    """wraps `vorta_amd.routed.routed_attention` -- what torch.ops.vorta.routed_attention, the operator the processors launch
+    through, runs (vorta_amd/torch_ops.py): records the inputs and the output view per call"""
 
-    def __init__(self, module):
+    def __init__(self, module=None):
+        import vorta_amd.routed as routed_module
+        module = routed_module
         self.module, self.calls, self.stock = module, [], module.routed_attention
 
     def __enter__(self):

@@ -237,6 +237,73 @@ def test_hunyuan_triple_eval_vs_oracle(dual):
 
 
 @pytest.mark.parametrize("dual", [True, False])
+@pytest.mark.parametrize("precision", ["native", "fp8", "i8pv"])
+def test_hunyuan_processor_call_compiles_fullgraph(dual, precision):
+    """the production processor call goes through torch.ops.vorta.* (vorta_amd/torch_ops.py), so
+    `torch.compile(fullgraph=True)` traces `HunyuanVideoFlashAttnProcessorTripleEval.__call__` without a graph break
+    (aot_eager: fake-tensor tracing through the registered shape functions, no code generation) and the compiled call equals
+    the eager one bit for bit -- with the routes dispatched inside the call from the score tensor, and with the device lists
+    of a route plan handed in."""
+    import vorta_amd
+    from vorta_amd import ops
+    from vorta_amd.attention import (HunyuanVideoFlashAttnProcessorTripleEval, create_sliding_tile_attn_mask_func,
+                                     get_group_info)
+    from vorta_amd.routed import HeadRouting
+    dtype = torch.bfloat16
+    hidden_dim, T, te = 64, 16, 11
+    attn = _HyFakeAttn(hidden_dim, dual, dtype, seed=23 + dual)
+    torch.manual_seed(9)
+    hidden = torch.randn((1, S, hidden_dim), device=dev()).to(dtype)
+    enc = torch.randn((1, T, hidden_dim), device=dev()).to(dtype)
+    ang = torch.rand((S, 64), device=dev()) * 6.28
+    rope = (ang.cos().repeat_interleave(2, dim=1).contiguous(), ang.sin().repeat_interleave(2, dim=1).contiguous())
+    mask = torch.zeros((1, 1, 1, S + T), dtype=torch.bool, device=dev())
+    mask[..., :S + te] = True
+    score = torch.softmax(torch.randn((1, H, 3), device=dev()) * 2, dim=-1)
+    kw = dict(lowres_group_info=get_group_info(LATENT, GROUP, 0.5, dev()), window_size=WINDOW, tile_size=TILE,
+              latent_shape=LATENT,
+              flex_attn_mask_func=create_sliding_tile_attn_mask_func(LATENT, WINDOW, TILE, T, te, dev()))
+    proc = HunyuanVideoFlashAttnProcessorTripleEval()
+    vorta_amd.set_attention_precision(precision)
+    try:
+        def call(h, e, sc):
+            return proc(attn, h, e, mask, rope, routing_score=sc, tau_sparse=0.3, **kw)
+
+        eager = call(hidden, enc, score)
+        compiled = torch.compile(call, backend="aot_eager", fullgraph=True)(hidden, enc, score)
+        assert torch.equal(eager[0], compiled[0]) and torch.equal(eager[1], compiled[1])
+        # the route plan's form: device head lists + counts handed in
+        _, lists, counts = ops.route_scores(score, 0.3)
+
+        def call_planned(h, e, sc, lists_, counts_):
+            return proc(attn, h, e, mask, rope, routing_score=sc, tau_sparse=0.3,
+                        head_routing=HeadRouting.from_device(lists_, counts_), **kw)
+
+        planned = torch.compile(call_planned, backend="aot_eager", fullgraph=True)(hidden, enc, score, lists, counts)
+        assert torch.equal(eager[0], planned[0]) and torch.equal(eager[1], planned[1])
+    finally:
+        vorta_amd.set_attention_precision("native")
+
+
+def test_wan_processor_call_compiles_fullgraph(golden):
+    from vorta_amd.attention import WanAttnProcessorTripleEval
+    g = golden("g8_eval_calls")
+    dtype = torch.bfloat16
+    attn = _WanFakeAttn(g, dtype)
+    hidden = torch.tensor(g["wan_hidden"]).to(dtype).to(dev())
+    score = torch.tensor(g["routing_score"]).to(dev())
+    proc = WanAttnProcessorTripleEval()
+    kw = _wan_kwargs()
+
+    def call(h, sc):
+        return proc(attn, h, None, None, None, tau_sparse=0.3, routing_score=sc, **kw)
+
+    eager = call(hidden, score)
+    compiled = torch.compile(call, backend="aot_eager", fullgraph=True)(hidden, score)
+    assert torch.equal(eager, compiled)
+
+
+@pytest.mark.parametrize("dual", [True, False])
 @pytest.mark.parametrize("precision", ["native", "fp8"])
 def test_hunyuan_processor_call_is_sync_free_and_graph_capturable(dual, precision):
     """The production call -- projections into one buffer, qk-norm + RoPE, device-resident routes from the score tensor

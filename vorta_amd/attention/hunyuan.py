@@ -10,7 +10,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from .. import ops
-from ..routed import HeadRouting, geometry_for, routed_attention, soft_mixture_attention
+from .. import torch_ops as _torch_ops  # registers torch.ops.vorta.*: what the processors launch through
+from ..routed import HeadRouting
 from ..ulysses import SP_STATE, shrink_dim
 from .coreset_select import LowresGroupInfo
 from .sliding_tile import SlidingTileDescriptor
@@ -43,7 +44,7 @@ def fused_norm_rope(x: torch.Tensor, norm, rope: Optional[Tuple[torch.Tensor, to
     kernel (hunyuan.py:62-104 are two module calls and ~10 elementwise passes)."""
     w = getattr(norm, "weight", None)
     cos, sin = rope if rope is not None else (None, None)
-    ops.qk_norm_rope(x[0], w, float(norm.eps), cos=cos, sin=sin, rope_tokens=rope_tokens if rope is not None else 0)
+    torch.ops.vorta.qk_norm_rope(x[0], w, float(norm.eps), cos, sin, rope_tokens if rope is not None else 0)
     return x
 
 
@@ -215,7 +216,7 @@ class HunyuanVideoFlashAttnProcessor:
         # L = attention_mask.sum() stays on the device: no host sync (the reference syncs at hunyuan.py:169)
         L = _valid_keys(attention_mask)
         N = q.shape[2]
-        ops.attn_fwd(q[0], k[0], v[0], out[0], n_q=N, n_kv=N, q_valid=N, n_kv_dev=L, q_valid_dev=L)
+        torch.ops.vorta.attn_fwd(q[0], k[0], v[0], out[0], N, N, q_valid=N, n_kv_dev=L, q_valid_dev=L)
         return buf
 
     @torch.no_grad()  # forward only: the HIP ops have no backward (training is out of scope)
@@ -268,14 +269,14 @@ class HunyuanVideoFlashAttnProcessorTripleEval(HunyuanVideoFlashAttnProcessor):
                                lowres_group_info=lowres_group_info, window_size=window_size, tile_size=tile_size,
                                latent_shape=latent_shape, experts_host=experts_host)
             return self._output(attn, buf, T)
-        geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
-                            lowres_group_info.reduction_rate, q.device)
         # top-1 / tau dispatch on the device: no torch.nonzero host sync (hunyuan.py:612-640)
         if head_routing is None:
-            _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+            _, lists, counts = torch.ops.vorta.route_scores(routing_score, float(tau_sparse))
             head_routing = HeadRouting.from_device(lists, counts)
         buf, out = self._new_out(q)
-        routed_attention(q, k, v, head_routing, geom, model="hunyuan", text_len=T, text_valid=te, out=out)
+        torch.ops.vorta.routed_attention(q, k, v, out, **_torch_ops.routing_args(head_routing),
+                                         **_torch_ops.geometry_args(lowres_group_info, window_size, tile_size, latent_shape),
+                                         model="hunyuan", text_len=T, text_valid=te)
         return self._output(attn, buf, T)
 
 
@@ -304,8 +305,9 @@ class HunyuanVideoFlashAttnProcessorTripleTrain(HunyuanVideoFlashAttnProcessorTr
             q, k, v, T = self._project(attn, hidden_states, encoder_hidden_states, image_rotary_emb)
             assert q.shape[0] == 1, f"Batch size {q.shape[0]} is not supported for {self.__class__.__name__}."
             te = self._text_valid(attention_mask, T, flex_attn_mask_func)
-            geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
-                                lowres_group_info.reduction_rate, q.device)
             buf, out = self._new_out(q)
-            soft_mixture_attention(q, k, v, routing_score, geom, model="hunyuan", text_len=T, text_valid=te, out=out)
+            torch.ops.vorta.soft_mixture_attention(q, k, v, routing_score, out,
+                                                   **_torch_ops.geometry_args(lowres_group_info, window_size, tile_size,
+                                                                              latent_shape),
+                                                   model="hunyuan", text_len=T, text_valid=te)
             return self._output(attn, buf, T)

@@ -8,7 +8,8 @@ from typing import List, Optional, Tuple
 import torch
 
 from .. import ops
-from ..routed import HeadRouting, dense_attention, geometry_for, routed_attention, soft_mixture_attention
+from .. import torch_ops as _torch_ops  # registers torch.ops.vorta.*: what the processors launch through
+from ..routed import HeadRouting, dense_attention
 from ..ulysses import SP_STATE, shrink_dim
 from .coreset_select import LowresGroupInfo
 from .sliding_tile import SlidingTileDescriptor
@@ -65,8 +66,8 @@ class WanAttnProcessor2_0:
             # RMSNorm over all H*D channels of a token + rotation, one in-place HIP pass per tensor
             cos, sin = _cos_sin(rope) if rope is not None else (None, None)
             q, k, v = (x.unflatten(2, (H, -1)).transpose(1, 2) for x in (q, k, v))
-            ops.qk_norm_rope(q[0], attn.norm_q.weight, float(attn.norm_q.eps), cos=cos, sin=sin, across_heads=True)
-            ops.qk_norm_rope(k[0], attn.norm_k.weight, float(attn.norm_k.eps), cos=cos, sin=sin, across_heads=True)
+            torch.ops.vorta.qk_norm_rope(q[0], attn.norm_q.weight, float(attn.norm_q.eps), cos, sin, -1, True)
+            torch.ops.vorta.qk_norm_rope(k[0], attn.norm_k.weight, float(attn.norm_k.eps), cos, sin, -1, True)
         else:
             if attn.norm_q is not None:
                 q = attn.norm_q(q)
@@ -160,13 +161,13 @@ class WanAttnProcessorTripleEval(WanAttnProcessor2_0):
                                window_size=window_size, tile_size=tile_size, latent_shape=latent_shape,
                                experts_host=experts_host)
             return self._output_proj(attn, buf)
-        geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
-                            lowres_group_info.reduction_rate, q.device)
         if head_routing is None:
-            _, lists, counts = ops.route_scores(routing_score, tau_sparse)
+            _, lists, counts = torch.ops.vorta.route_scores(routing_score, float(tau_sparse))
             head_routing = HeadRouting.from_device(lists, counts)
         buf, out = self._new_out(q)
-        routed_attention(q, k, v, head_routing, geom, model="wan", out=out)
+        torch.ops.vorta.routed_attention(q, k, v, out, **_torch_ops.routing_args(head_routing),
+                                         **_torch_ops.geometry_args(lowres_group_info, window_size, tile_size, latent_shape),
+                                         model="wan")
         return self._output_proj(attn, buf)
 
 
@@ -192,8 +193,8 @@ class WanAttnProcessorTripleTrain(WanAttnProcessorTripleEval):
             self._check_input(hidden_states, lowres_group_info, latent_shape, window_size, tile_size)
             q, k, v, _ = self._input_proj(attn, hidden_states, None, rotary_emb)
             assert q.shape[0] == 1, "the soft mixture runs one batch item per call"
-            geom = geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
-                                lowres_group_info.reduction_rate, q.device)
             buf, out = self._new_out(q)
-            soft_mixture_attention(q, k, v, routing_score, geom, model="wan", out=out)
+            torch.ops.vorta.soft_mixture_attention(q, k, v, routing_score, out,
+                                                   **_torch_ops.geometry_args(lowres_group_info, window_size, tile_size,
+                                                                              latent_shape), model="wan")
             return self._output_proj(attn, buf)

@@ -94,22 +94,37 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
                n_kv_dev: Optional[torch.Tensor] = None, q_valid_dev: Optional[torch.Tensor] = None,
                variant: int = 0, tag: str = "", flops: float = 0.0,
                v_descale: Optional[torch.Tensor] = None, fp8_opts: Optional[dict] = None,
-               q_block_table: Optional[torch.Tensor] = None, n_key_lists: int = 0):
+               q_block_table: Optional[torch.Tensor] = None, n_key_lists: int = 0,
+               k_scale: Optional[torch.Tensor] = None, q_smooth: Optional[torch.Tensor] = None):
     """Fill a vorta_attn_args; returns (args, workspace tensors to keep alive until the launch is enqueued).
     q,k,v of dtype uint8 = e4m3 operands from `fp8_quantize_qkv` (then `v_descale` is required and `out` is 16-bit):
-    the args carry `_ext`, the vorta_attn_fp8_ext of the fp8 entry points."""
+    the args carry `_ext`, the vorta_attn_fp8_ext of the fp8 entry points.
+    k of dtype int8 = the rows of `i8_quantize_k` (then `k_scale` (heads, rows) and `q_smooth` (heads, D) are required, q and
+    out are 16-bit, v is e4m3): `_ext` is the vorta_attn_i8_ext of the int8-score entry points."""
     _require_gpu(q, k, v, out)
     fp8 = q.dtype == FP8_STORAGE
-    mixed = (not fp8) and v.dtype == FP8_STORAGE  # 16-bit scores, e4m3 P V (csrc/attn_fwd_mx.hip)
+    i8 = (not fp8) and k.dtype == torch.int8  # int8 scores, e4m3 P V (csrc/attn_fwd_i8.hip)
+    mixed = (not fp8) and (not i8) and v.dtype == FP8_STORAGE  # 16-bit scores, e4m3 P V (csrc/attn_fwd_mx.hip)
+    if i8:
+        if q.dtype not in _DT or q.dtype != out.dtype or v.dtype != FP8_STORAGE:
+            raise ValueError("int8-score attention takes 16-bit q and out of one dtype, int8 k and e4m3 (uint8) v")
+        if k_scale is None or k_scale.dtype != torch.float32 or k_scale.dim() != 2 or k_scale.stride(1) != 1 \
+                or k_scale.shape[0] < k.shape[0] or k_scale.shape[1] < k.shape[1]:
+            raise ValueError("int8-score attention needs k_scale: float32 (heads, rows) with unit row stride (i8_quantize_k)")
+        if q_smooth is None or q_smooth.dtype != torch.float32 or q_smooth.dim() != 2 or q_smooth.shape[1] != q.shape[-1] \
+                or not q_smooth.is_contiguous():
+            raise ValueError("int8-score attention needs q_smooth: contiguous float32 (heads, D) from i8_quantize_k")
     if fp8:
         if not (k.dtype == v.dtype == FP8_STORAGE) or out.dtype not in _DT:
             raise ValueError("fp8 attention takes e4m3 (uint8) q,k,v and a bf16 / fp16 output")
     elif mixed:
         if q.dtype not in _DT or not (q.dtype == k.dtype == out.dtype):
             raise ValueError("mixed-precision attention takes 16-bit q, k, out of one dtype and an e4m3 (uint8) v")
+    elif i8:
+        pass  # checked above
     elif q.dtype not in _DT or not (q.dtype == k.dtype == v.dtype == out.dtype):
         raise ValueError("q,k,v,out must share dtype bf16 or fp16")
-    if fp8 or mixed:
+    if fp8 or mixed or i8:
         if v_descale is None or v_descale.dtype != torch.float32 or v_descale.dim() != 2 or v_descale.shape[1] != q.shape[-1] \
                 or not v_descale.is_contiguous():
             raise ValueError("fp8 attention needs v_descale: contiguous float32 (heads, D) from fp8_quantize_qkv / fp8_quantize_v")
@@ -118,7 +133,17 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     a.dtype = _C.VORTA_FP8E4M3 if fp8 else _DT[q.dtype]
     a._ext = None
     a._mixed = mixed
-    if fp8 or mixed:
+    a._i8 = i8
+    if i8:
+        ext = _C.AttnI8Ext()
+        ext.struct_size = C.sizeof(_C.AttnI8Ext)
+        ext.k_scale, ext.k_scale_stride_h = k_scale.data_ptr(), k_scale.stride(0)
+        ext.q_smooth, ext.q_smooth_stride_h = q_smooth.data_ptr(), q_smooth.stride(0)
+        ext.v_descale, ext.v_descale_stride_h = v_descale.data_ptr(), v_descale.stride(0)
+        o = fp8_opts or FP8_OPTS
+        ext.p_bias, ext.defer = float(o.get("p_bias", 0.0)), float(o.get("defer", 0.0))
+        a._ext = ext
+    elif fp8 or mixed:
         ext = _C.AttnFp8Ext()
         ext.struct_size = C.sizeof(_C.AttnFp8Ext)
         ext.out_dtype = _DT[out.dtype]
@@ -182,14 +207,14 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     a.block_rows = block_rows
     a.n_splits = n_splits
     a.n_kv_dev, a.q_valid_dev = _ptr(n_kv_dev), _ptr(q_valid_dev)
-    a.variant = 0 if (fp8 or mixed) else (variant or DEFAULT_VARIANT)
+    a.variant = 0 if (fp8 or mixed or i8) else (variant or DEFAULT_VARIANT)
     if a.variant != 1:
         # the pipelined kernel's 32-bit K/V offsets (vorta_hip.h): beyond a 2 GiB window per head, or 2^24 rows, use
         # the plain HIP kernel (64-bit addressing) instead
         for t in (k, v):
             esz = t.element_size()
             if t.shape[1] >= (1 << 24) or t.shape[1] * t.stride(1) * esz > 0x7fffffff or t.stride(1) * esz >= (1 << 24):
-                if fp8 or mixed:
+                if fp8 or mixed or i8:
                     raise ValueError("fp8 attention addresses K/V rows with 32-bit offsets: a head must fit a 2 GiB window")
                 a.variant = 1
     a.reserved = NO_XCD_REMAP
@@ -206,7 +231,9 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
 
 
 def _launch_one(a):
-    if a._ext is not None:
+    if a._i8:
+        _C.check(_C.lib().vorta_attn_fwd_i8(C.byref(a), C.byref(a._ext), _stream()), "vorta_attn_fwd_i8")
+    elif a._ext is not None:
         _C.check(_C.lib().vorta_attn_fwd_fp8(C.byref(a), C.byref(a._ext), _stream()), "vorta_attn_fwd_fp8")
     else:
         _C.check(_C.lib().vorta_attn_fwd(C.byref(a), _stream()), "vorta_attn_fwd")
@@ -217,6 +244,8 @@ def _plan(a) -> Tuple[int, int, str]:
     _C.check(_C.lib().vorta_attn_plan(C.byref(a), C.byref(br), C.byref(nwg), C.byref(kid)), "vorta_attn_plan")
     tname = "_Float16" if a.dtype == _C.VORTA_FP16 else "__bf16"
     nw, kk = kid.value // 16, kid.value % 16
+    if a._i8:
+        return br.value, nwg.value, f"attn_i8_kernel<{tname},{nw},{'true' if kk & 2 else 'false'}>"
     if a._ext is not None:
         tname = "_Float16" if a._ext.out_dtype == _C.VORTA_FP16 else "__bf16"
         if a._ext.flags & 2:
@@ -275,7 +304,7 @@ def attn_fwd_batch(calls) -> None:
         return
 
     def fusable_one(a):
-        return _plan(a)[0] == 256 and a.variant != 1 and not (a._ext is not None and a._ext.flags & 1)
+        return _plan(a)[0] == 256 and a.variant != 1 and not (a._ext is not None and not a._i8 and a._ext.flags & 1)
 
     ok = [fusable_one(a) for a, _, _, _ in built]
     fuse_all = 1 < len(built) <= 4 and all(ok)
@@ -310,18 +339,23 @@ def attn_fwd_batch_built(built, fuse: bool = True) -> None:
         return
     arr = (_C.AttnArgs * len(built))(*[a for a, _, _, _ in built])
     ext = built[0][0]._ext  # one operand set per layer: every fused launch shares v_descale and the options
-    if any((a._ext is None) != (ext is None) or (ext is not None and (a._ext.flags & 2) != (ext.flags & 2))
-           for a, _, _, _ in built):
-        raise ValueError("a fused grid is all 16-bit, all e4m3 or all mixed-precision")
+    i8 = built[0][0]._i8
+    if any(a._i8 != i8 for a, _, _, _ in built) or (not i8 and any(
+            (a._ext is None) != (ext is None) or (ext is not None and (a._ext.flags & 2) != (ext.flags & 2)) for a, _, _, _ in built)):
+        raise ValueError("a fused grid is all 16-bit, all e4m3, all mixed-precision or all int8-score")
 
     def go():
-        if ext is not None:
+        if i8:
+            _C.check(_C.lib().vorta_attn_fwd_batch_i8(arr, C.byref(ext), len(built), _stream()), "vorta_attn_fwd_batch_i8")
+        elif ext is not None:
             _C.check(_C.lib().vorta_attn_fwd_batch_fp8(arr, C.byref(ext), len(built), _stream()), "vorta_attn_fwd_batch_fp8")
         else:
             _C.check(_C.lib().vorta_attn_fwd_batch(arr, len(built), _stream()), "vorta_attn_fwd_batch")
 
     if _timeline is not None:
-        if ext is not None:
+        if i8:
+            sym = f"attn_i8_multi_kernel<{'_Float16' if built[0][0].dtype == _C.VORTA_FP16 else '__bf16'}>"
+        elif ext is not None:
             sym = ("attn_mx_multi_kernel" if ext.flags & 2 else "attn8_multi_kernel") + \
                 f"<{'_Float16' if ext.out_dtype == _C.VORTA_FP16 else '__bf16'}>"
         else:
@@ -450,6 +484,60 @@ def fp8_quantize_v(v: torch.Tensor, out: Optional[Tuple[torch.Tensor, torch.Tens
     amax.zero_()
     fp8_v_absmax(v, amax)
     fp8_v_convert(v, amax, v8, v_descale=vd)
+    return out
+
+
+class I8Operands:
+    """int8 keys of one layer for the int8-score attention: k8 (same geometry as k, int8), k_scale (one float per row),
+    q_smooth (heads, D): the channel multipliers the attention kernel applies to its query rows; ws: centre | 1 / smooth"""
+    __slots__ = ("k8", "k_scale", "q_smooth", "ws")
+
+    def __init__(self, k8, k_scale, q_smooth, ws):
+        self.k8, self.k_scale, self.q_smooth, self.ws = k8, k_scale, q_smooth, ws
+
+    def k_center(self):
+        H, D = self.q_smooth.shape
+        return self.ws[:H * D].view(H, D)
+
+
+def i8_quantize_k(q: torch.Tensor, k: torch.Tensor, *, out: Optional[I8Operands] = None, smooth: bool = True,
+                  center: bool = True, heads: Optional[int] = None, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0,
+                  slots: Optional[Tuple[int, int]] = None, video_tokens: int = 0) -> I8Operands:
+    """vorta_i8_quantize_k: (H,S,D) bf16 / fp16 views of q (sampled only) and k -> int8 keys with one scale per row, the
+    keys centred and the channel ranges of q and k balanced (include/vorta_hip.h).  `seg_len > 0`: (1,rows,D) row arrays in
+    the Ulysses receive layout, `heads` head slots, tail (text) rows from `tail_first`; `slots` = (first, end): only those
+    head slots.  `out` = a previous result to overwrite."""
+    _require_gpu(q, k)
+    if q.dtype not in _DT or q.dtype != k.dtype or q.shape != k.shape or q.dim() != 3:
+        raise ValueError("i8_quantize_k takes (H,S,D) bf16 / fp16 views of q and k of equal shape")
+    Hx, S, D = k.shape
+    if seg_len > 0:
+        if Hx != 1 or not heads or heads < 1:
+            raise ValueError("i8_quantize_k: the segmented layout takes (1,rows,D) row arrays and the number of heads")
+        H = heads
+    else:
+        if heads not in (None, Hx):
+            raise ValueError("i8_quantize_k: `heads` only applies to the segmented layout")
+        H = Hx
+    dev = k.device
+    if out is None:
+        out = I8Operands(torch.empty((Hx, S, D), dtype=torch.int8, device=dev),
+                         torch.empty((Hx, S), dtype=torch.float32, device=dev),
+                         torch.empty((H, D), dtype=torch.float32, device=dev),
+                         torch.empty(2 * H * D, dtype=torch.float32, device=dev))
+    a = _C.I8QuantArgs()
+    a.struct_size = C.sizeof(_C.I8QuantArgs)
+    a.dtype, a.head_dim, a.heads, a.n_tokens = _DT[k.dtype], D, H, S
+    a.q, a.k, a.k8 = _tensor(q), _tensor(k), _tensor(out.k8)
+    a.k_scale, a.k_scale_stride_h = out.k_scale.data_ptr(), out.k_scale.stride(0)
+    a.q_smooth, a.ws = out.q_smooth.data_ptr(), out.ws.data_ptr()
+    a.flags = (0 if smooth else 1) | (0 if center else 2)
+    a.seg_len, a.tail_first, a.tail_len, a.video_tokens = seg_len, tail_first, tail_len, video_tokens
+    if slots is not None:
+        if seg_len <= 0 or not (0 <= slots[0] < slots[1] <= H):
+            raise ValueError(f"i8_quantize_k: slots {slots} need the segmented layout and 0 <= first < end <= {H}")
+        a.slot_first, a.slot_count = slots[0], slots[1] - slots[0]
+    _C.check(_C.lib().vorta_i8_quantize_k(C.byref(a), _stream()), "vorta_i8_quantize_k")
     return out
 
 

@@ -77,7 +77,11 @@ class RoutePlan:
         x = temb.detach().to(dtype)
         if self._out is not None and self._out[0].shape[1] != x.shape[0]:
             self._out = None
-        self._out = ops.route_plan(x, w, b, self.heads, float(tau), self.num_experts, out=self._out)
+        if self._out is None:  # first step (or new shapes): allocate the four buffers
+            self._out = ops.route_plan(x, w, b, self.heads, float(tau), self.num_experts)
+        else:  # the same buffers at the same addresses, through the custom op (traceable; hipGraph replay reads them)
+            from .. import torch_ops  # noqa: F401
+            torch.ops.vorta.route_plan_(x, w, b, self.heads, float(tau), self.num_experts, *self._out)
         self._experts_host = None
         self.tau = float(tau)
 

@@ -155,9 +155,9 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
 STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
 # process-wide default of `routed_attention(fp8=None)`: the processors of vorta.attention call it that way, so the
 # unchanged inference scripts pick the e4m3 path up from the environment or from `set_attention_precision("fp8")`
-# False (native), True (all e4m3) or "fp8pv" (16-bit scores, e4m3 P V)
+# False (native), True (all e4m3), "fp8pv" (16-bit scores, e4m3 P V) or "i8pv" (int8 scores with a scale per row, e4m3 P V)
 _PREC_ENV = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower()
-DEFAULT_FP8 = True if _PREC_ENV == "fp8" else ("fp8pv" if _PREC_ENV == "fp8pv" else False)
+DEFAULT_FP8 = True if _PREC_ENV == "fp8" else (_PREC_ENV if _PREC_ENV in ("fp8pv", "i8pv") else False)
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
 # the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
 FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
@@ -175,12 +175,13 @@ FUSED_TEXT_FIRST = FUSED_TEXT_SPLITS > 0
 
 def set_attention_precision(precision: str) -> None:
     """"native" (the dtype of q,k,v: the reference's behaviour), "fp8" (both contractions in e4m3: fastest, 40 dB against
-    native only where the softmax is flat) or "fp8pv" (scores in 16 bits, P V in e4m3: >= 42 dB on every input family
-    tried); 16-bit output in every case"""
+    native only where the softmax is flat), "fp8pv" (scores in 16 bits, P V in e4m3: >= 42 dB on every input family
+    tried) or "i8pv" (scores in int8 with a scale per row at the e4m3 MFMA rate, P V in e4m3: >= 40 dB on every family,
+    DESIGN.md (c)); 16-bit output in every case"""
     global DEFAULT_FP8
-    if precision not in ("native", "fp8", "fp8pv"):
-        raise ValueError("precision is 'native', 'fp8' or 'fp8pv'")
-    DEFAULT_FP8 = True if precision == "fp8" else ("fp8pv" if precision == "fp8pv" else False)
+    if precision not in ("native", "fp8", "fp8pv", "i8pv"):
+        raise ValueError("precision is 'native', 'fp8', 'fp8pv' or 'i8pv'")
+    DEFAULT_FP8 = True if precision == "fp8" else (precision if precision in ("fp8pv", "i8pv") else False)
 _SIDE_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
 
 
@@ -244,8 +245,15 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         fp8 = DEFAULT_FP8
     if fp8_views is not None:
         base = dict(q=fp8_views[0], k=fp8_views[1], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
+        if len(fp8_views) == 6:  # int8 keys: + their row scales and the heads' smoothing vectors
+            base.update(k_scale=fp8_views[4], q_smooth=fp8_views[5])
+    elif fp8 == "i8pv":  # int8 scores: k -> int8 rows (centred, smoothed, one scale per row), v -> e4m3; q is quantised by the kernel
+        vo, ko = fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 2 else (None, None)
+        v8, vd, _ = ops.fp8_quantize_v(v3, out=vo)
+        i8 = ops.i8_quantize_k(q3, k3, out=ko)
+        base = dict(q=q3, k=i8.k8, v=v8, scale=scale, v_descale=vd, k_scale=i8.k_scale, q_smooth=i8.q_smooth)
     elif fp8 == "fp8pv":  # scores in 16 bits, P V in e4m3: only v is converted (exact per-channel abs-max, one pass + one)
-        v8, vd, _ = ops.fp8_quantize_v(v3, out=fp8_operands if isinstance(fp8_operands, tuple) else None)
+        v8, vd, _ = ops.fp8_quantize_v(v3, out=fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 3 else None)
         base = dict(q=q3, k=k3, v=v8, scale=scale, v_descale=vd)
     elif fp8:
         # (video_tokens: the sample is summed in eighths of the video tokens + the text, as the sequence-parallel send side sums it)
@@ -375,8 +383,10 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, kv_val
     if out is None:
         out = torch.empty_like(q)
     Sq, Skv = q.shape[-2], k.shape[-2]
-    ops.attn_fwd(ops.fold_heads(q), ops.fold_heads(k), ops.fold_heads(v), ops.fold_heads(out), n_q=Sq,
-                 n_kv=Skv if kv_valid is None else kv_valid, q_valid=Sq if q_valid is None else q_valid, scale=scale)
+    from . import torch_ops  # noqa: F401  (the launch goes through the custom op: traceable, same launcher)
+    torch.ops.vorta.attn_fwd(ops.fold_heads(q), ops.fold_heads(k), ops.fold_heads(v), ops.fold_heads(out), Sq,
+                             Skv if kv_valid is None else kv_valid, q_valid=Sq if q_valid is None else q_valid,
+                             scale=0.0 if scale is None else scale)
     return out
 
 

@@ -4,8 +4,10 @@ The C ABI (include/vorta_hip.h) is the boundary; ops.py binds it with ctypes.  T
 behind `torch.library.custom_op`, so code that is traced (`torch.compile`, export) sees them as opaque, stream-correct
 operators with declared mutations and shape functions instead of Python it cannot follow (BASELINE.json north star:
 "Python host code calls into hand-written HIP kernels through PyTorch-ROCm custom ops (thin C-ABI ...)").  The
-attention processors call ops.py directly -- the custom-op dispatcher adds nothing to an eager launch -- and both ways
-run the very same code.
+attention processors of vorta_amd/attention call THESE operators (`vorta::routed_attention`, `vorta::attn_fwd`,
+`vorta::qk_norm_rope`, `vorta::route_scores`, `vorta::soft_mixture_attention`; the route plan of patch/_engine.py
+`vorta::route_plan_`): a processor `__call__` traces under `torch.compile(fullgraph=True)` with no graph break, and the
+eager path runs the very same launchers behind one dispatcher hop per operator.
 
 Registered (tensors are (H,S,D) views as in ops.py; optional tensors may be None):
     vorta::attn_fwd(q,k,v,out, n_q,n_kv, ...)         -> ()    mutates out        vorta_attn_fwd
@@ -15,6 +17,10 @@ Registered (tensors are (H,S,D) views as in ops.py; optional tensors may be None
     vorta::router_route(temb, weight, bias, heads, tau) -> (scores, expert_of_head, head_lists, head_counts)
     vorta::qk_norm_rope(x, weight, eps, cos, sin, rope_tokens, across_heads) -> () mutates x
     vorta::mix_experts(x0,x1,x2, scores, out)         -> ()    mutates out
+    vorta::routed_attention(q,k,v,out, head_lists, head_counts, counts_host, latent, tile, window, group, rate, model, ...)
+                                                      -> ()    mutates out        the per-layer routed op (routed.py)
+    vorta::soft_mixture_attention(q,k,v, scores, out, latent, ...) -> () mutates out   the training-time forward
+    vorta::route_plan_(temb, weight, bias, heads, tau, n_experts, scores, expert, lists, counts) -> () mutates the four
 """
 from typing import List, Optional, Tuple
 
@@ -113,7 +119,9 @@ def _(temb, weight, bias, heads, tau, n_experts=3):
 @torch.library.custom_op("vorta::qk_norm_rope", mutates_args=("x",), device_types="cuda")
 def qk_norm_rope(x: torch.Tensor, weight: Optional[torch.Tensor], eps: float, cos: Optional[torch.Tensor] = None,
                  sin: Optional[torch.Tensor] = None, rope_tokens: int = 0, across_heads: bool = False) -> None:
-    ops.qk_norm_rope(x, weight, eps, cos=cos, sin=sin, rope_tokens=rope_tokens, across_heads=across_heads)
+    """rope_tokens < 0: every token the cos / sin tables cover (ops.qk_norm_rope's default)"""
+    ops.qk_norm_rope(x, weight, eps, cos=cos, sin=sin, rope_tokens=None if rope_tokens < 0 else rope_tokens,
+                     across_heads=across_heads)
 
 
 @qk_norm_rope.register_fake
@@ -129,3 +137,67 @@ def mix_experts(x0: torch.Tensor, x1: torch.Tensor, x2: torch.Tensor, scores: to
 @mix_experts.register_fake
 def _(x0, x1, x2, scores, out) -> None:
     return None
+
+
+@torch.library.custom_op("vorta::routed_attention", mutates_args=("out",), device_types="cuda")
+def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, head_lists: torch.Tensor,
+                     head_counts: Optional[torch.Tensor], counts_host: Optional[List[int]], latent: List[int],
+                     tile: List[int], window: List[int], group: List[int], rate: float, model: str, text_len: int = 0,
+                     text_valid: int = 0, scale: float = 0.0, precision: str = "",
+                     row_map: Optional[torch.Tensor] = None) -> None:
+    """The routed sparse-attention op of one layer (vorta_amd/routed.py: hunyuan.py:556-605 / wan.py:351-383): q,k,v,out
+    (1,H,N,D) views; head_lists (3,H) int32 + head_counts (3,) int32 on the device (the route plan's / vorta::route_scores'
+    output: no host read) or `counts_host` = the three counts known on the host; the geometry by value (its tables are
+    cached per process, routed.geometry_for).  precision "" = the process default (set_attention_precision)."""
+    from . import routed
+    geom = routed.geometry_for(latent, tile, window, group, rate, q.device, row_map=row_map)
+    routing = routed.HeadRouting(head_lists, list(counts_host) if counts_host is not None else None, head_counts)
+    fp8 = None if precision == "" else (False if precision == "native" else True if precision == "fp8" else precision)
+    routed.routed_attention(q, k, v, routing, geom, model=model, text_len=text_len, text_valid=text_valid, out=out,
+                            scale=None if scale <= 0.0 else scale, fp8=fp8)
+
+
+@routed_attention.register_fake
+def _(q, k, v, out, head_lists, head_counts, counts_host, latent, tile, window, group, rate, model, text_len=0,
+      text_valid=0, scale=0.0, precision="", row_map=None) -> None:
+    return None
+
+
+@torch.library.custom_op("vorta::soft_mixture_attention", mutates_args=("out",), device_types="cuda")
+def soft_mixture_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing_score: torch.Tensor, out: torch.Tensor,
+                           latent: List[int], tile: List[int], window: List[int], group: List[int], rate: float, model: str,
+                           text_len: int = 0, text_valid: int = 0, scale: float = 0.0) -> None:
+    """hunyuan.py:375-408,509-513 / wan.py:226-241,296-300, forward only (routed.soft_mixture_attention)"""
+    from . import routed
+    geom = routed.geometry_for(latent, tile, window, group, rate, q.device)
+    routed.soft_mixture_attention(q, k, v, routing_score, geom, model=model, text_len=text_len, text_valid=text_valid,
+                                  out=out, scale=None if scale <= 0.0 else scale)
+
+
+@soft_mixture_attention.register_fake
+def _(q, k, v, routing_score, out, latent, tile, window, group, rate, model, text_len=0, text_valid=0, scale=0.0) -> None:
+    return None
+
+
+@torch.library.custom_op("vorta::route_plan_", mutates_args=("scores", "expert", "lists", "counts"), device_types="cuda")
+def route_plan_(temb: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, heads: int, tau: float, n_experts: int,
+                scores: torch.Tensor, expert: torch.Tensor, lists: torch.Tensor, counts: torch.Tensor) -> None:
+    """vorta_route_plan into caller-owned buffers at fixed addresses (patch/_engine.py RoutePlan; hipGraph replay)"""
+    ops.route_plan(temb, weight, bias, heads, tau, n_experts, out=(scores, expert, lists, counts))
+
+
+@route_plan_.register_fake
+def _(temb, weight, bias, heads, tau, n_experts, scores, expert, lists, counts) -> None:
+    return None
+
+
+def geometry_args(lowres_group_info, window_size, tile_size, latent_shape) -> dict:
+    """the geometry keywords of vorta::routed_attention / vorta::soft_mixture_attention from a processor's keywords"""
+    return dict(latent=[int(x) for x in latent_shape], tile=[int(x) for x in tile_size], window=[int(x) for x in window_size],
+                group=[int(x) for x in lowres_group_info.window_size], rate=float(lowres_group_info.reduction_rate))
+
+
+def routing_args(head_routing) -> dict:
+    """head_lists / head_counts / counts_host of a routed.HeadRouting"""
+    return dict(head_lists=head_routing.lists, head_counts=head_routing.counts_dev,
+                counts_host=None if head_routing.counts_host is None else [int(c) for c in head_routing.counts_host])
