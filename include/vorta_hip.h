@@ -268,59 +268,70 @@ int vorta_attn_fwd_batch_fp8(const vorta_attn_args* args, const vorta_attn_fp8_e
 /*
  * Int8 scores (ABI 6; BASELINE.json configs[4], no reference counterpart: the reference computes the three experts of
  * wan.py:243-294 / hunyuan.py:410-507 in the dtype of q, k, v).  precision "i8pv": q k^T on v_mfma_i32_32x32x32_i8 (the
- * e4m3 MFMA rate) with 7 bits next to every ROW's maximum -- the all-e4m3 path loses 40 dB on peaked or outlier-carried
+ * e4m3 MFMA rate) with 7 bits next to the operand's maximum -- the all-e4m3 path loses 40 dB on peaked or outlier-carried
  * logits because e4m3 has 3 mantissa bits wherever a value sits -- and P V in e4m3 as in the mixed kernel.
+ * With cq, ck the per-head means of q and k (from ~1024 sampled tokens) and s a per-channel balance vector,
+ *     q . k  =  (q - cq) . (k - ck)  +  cq . (k - ck)  +  (a term that does not depend on the key: softmax does not see it)
+ *            =  [(q - cq) s] . [(k - ck) / s]  +  b[key]
+ * the first product runs in int8 (both operands centred: no common component eats the 8 bits; channel ranges balanced, which
+ * is what a FIXED-point format needs when a few qk-norm channels carry the logits), b[key] is computed in float32 and enters
+ * the int32 accumulator as its initial value.
  *
  * vorta_i8_quantize_k -- per head h, from ~1024 evenly spaced tokens (the same tokens in the (H,S,D) view and in the segmented
- *   Ulysses receive layout): centre c[h][d] = mean k (softmax-invariant), smoothing s[h][d] = (var_k[d] / mean q[d]^2)^(1/4)
- *   clamped to [1/8, 8] (q diag(s) . k diag(1/s) = q . k exactly; balances the channel ranges of the two operands, which is
- *   what a FIXED-point format needs when a few qk-norm channels carry the logits).  Then one pass over k:
- *       kt = (k - c[h]) / s[h]        sk[row] = max_d |kt| / 127  (1 for an all-zero row)      k8[row][d] = rint(kt / sk[row])
- *   Outputs: k8 (int8 rows of head_dim bytes), k_scale (one float per row) and q_smooth = s (heads x head_dim floats; the
- *   attention kernel multiplies its query rows by it before quantising them itself).
+ *   Ulysses receive layout): ck[d] = mean k, cq[d] = mean q, s[d] = clamp((var k[d] / var q[d])^(1/4), 1/8, 8).  Then over every
+ *   row of the head:   kt = (k - ck) / s      amax[h] = max |kt|  (exact, over all rows)      sk[h] = amax[h] / 127
+ *                      k8[row][d] = rint(kt 127 / amax[h])          k_bias[row] = (cq . (k - ck)) 127 / amax[h]
+ *   Outputs: k8 (int8 rows of head_dim bytes), k_bias (one float per row: b[key] in units of sk[h]), q_prep (heads x 2 x
+ *   head_dim floats: cq then s -- what the attention kernel applies to its query rows before quantising them itself) and
+ *   k_head_scale = sk (heads floats).
  */
 typedef struct vorta_i8_quant_args {
   uint32_t struct_size;
   int32_t dtype;            /* input dtype: VORTA_BF16 / VORTA_FP16 */
   int32_t head_dim, heads;  /* 128, H */
   int32_t n_tokens;         /* rows of every head (seg_len == 0) or of the row array (seg_len > 0) */
-  vorta_tensor q, k;        /* inputs, strides in elements; q is only sampled (smoothing statistics) */
+  vorta_tensor q, k;        /* inputs, strides in elements; q is only sampled (centre and balance statistics) */
   vorta_tensor k8;          /* out: int8, strides in bytes, rows 16-byte aligned; same head / row geometry as k */
-  float* k_scale;           /* out: k_scale[h * k_scale_stride_h + row]  (seg_len > 0: k_scale[row]) */
-  int64_t k_scale_stride_h;
-  float* q_smooth;          /* out [heads][head_dim]: s */
-  float* ws;                /* workspace, 2 * heads * head_dim floats: centre | 1 / s */
-  int32_t flags;            /* bit0: no smoothing (s = 1); bit1: no centring (c = 0) */
+  float* k_bias;            /* out: k_bias[h * k_bias_stride_h + row]  (seg_len > 0: k_bias[row]) */
+  int64_t k_bias_stride_h;
+  float* q_prep;            /* out [heads][2][head_dim]: cq | s */
+  float* k_head_scale;      /* out [heads]: sk */
+  float* ws;                /* workspace, 2 * heads * head_dim + heads floats: ck | 1 / s | amax */
+  int32_t flags;            /* bit0: no balancing (s = 1); bit1: no centring (ck = cq = 0, k_bias = 0) */
   int32_t seg_len;          /* as vorta_fp8_quant_args: 0 = (heads, n_tokens, D) views; > 0 = one row array, row r belongs to */
   int32_t tail_first;       /* head (r / seg_len) % heads, tail (text) rows from tail_first on, tail_len per segment */
   int32_t tail_len;
   int32_t slot_first;       /* seg_len > 0: only head slots [slot_first, slot_first + slot_count) (0, 0 = all) */
   int32_t slot_count;
-  int32_t video_tokens;     /* seg_len == 0: tokens before a head's tail (text) tokens, 0 = all (the sample's token order is */
-  int32_t reserved;         /* video tokens then tail tokens in both layouts) */
 } vorta_i8_quant_args;
 
 int vorta_i8_quantize_k(const vorta_i8_quant_args* args, void* hip_stream);
 
 /*
  * vorta_attn_fwd_i8 -- the gather flash-attention of vorta_attn_fwd with int8 scores and e4m3 P V.
- *   args->q: 16-bit (args->dtype), strides in elements.  Every wave multiplies its 32 query rows by q_smooth[head], takes
- *            each row's abs-max (sq = amax / 127) and rounds the row to int8 itself -- queries are read once per workgroup;
- *   args->k: the int8 rows of vorta_i8_quantize_k, strides in BYTES; k_scale its per-row scales (indexed like k rows:
- *            head * k_scale_stride_h + row, through kv_rows when given);
+ *   args->q: 16-bit (args->dtype), strides in elements.  Every WAVE takes its 32 query rows, qt = (q - cq) s with the head's
+ *            q_prep, the abs-max over the 32 rows (sq = amax / 127) and rounds them to int8 itself -- queries are read once
+ *            per workgroup;
+ *   args->k: the int8 rows of vorta_i8_quantize_k, strides in BYTES; k_bias its per-row floats (indexed like k rows:
+ *            head * k_bias_stride_h + row, through kv_rows when given); k_head_scale[head] = sk;
  *   args->v: e4m3 (vorta_fp8_v_absmax / vorta_fp8_v_convert), strides in bytes, with v_descale as in vorta_attn_fp8_ext;
  *   args->o: 16-bit (args->dtype).
- *   score of (query i, key j) in the exp2 domain = scale log2(e) sq[i] sk[j] (q8[i] . k8[j]); probabilities P 2^p_bias are
- *   packed to e4m3 per 64-key block against the wave's reference point exactly as in the mixed kernel (ext->flags bit1 of
- *   vorta_attn_fwd_fp8), whose tables, groups, duplicates, split keys and fused grid this entry shares.
+ *   score of (query i of wave w, key j) in the exp2 domain = u (q8[i] . k8[j] + rint(k_bias[j] / sq[w])), u = scale log2(e)
+ *   sq[w] sk[head] (the int32 accumulator starts from the rounded bias; |bias| is clamped to 2 000 000 units).
+ *   Probabilities: P' = P 2^p_bias per 64-key block against the wave's reference point as in the mixed kernel, but written
+ *   to e4m3 by ONE conversion instead of exp2 + round: the byte is rint(8 x + 56) for x = log2 P' (v_cvt_pk_u8_f32,
+ *   saturating at 0), i.e. the e4m3 number whose exponent field is the integer part of x and whose mantissa is the LINEAR
+ *   interpolation of its fraction (+-3 % of 2^x: costs ~0.5-0.8 dB of output PSNR, removes the transcendental and the
+ *   pack from the loop).  Tables, groups, duplicates, split keys and the fused grid as vorta_attn_fwd_fp8.
  */
 typedef struct vorta_attn_i8_ext {
   uint32_t struct_size;
   int32_t flags;               /* reserved, 0 */
-  const float* k_scale;
-  int64_t k_scale_stride_h;    /* floats between heads of k_scale */
-  const float* q_smooth;       /* [..][head_dim], indexed by the head id */
-  int64_t q_smooth_stride_h;
+  const float* k_bias;
+  int64_t k_bias_stride_h;     /* floats between heads of k_bias */
+  const float* q_prep;         /* [..][2][head_dim], indexed by the head id */
+  int64_t q_prep_stride_h;     /* floats between heads (2 * head_dim) */
+  const float* k_head_scale;   /* [..], indexed by the head id */
   const float* v_descale;      /* [..][head_dim], indexed by the head id */
   int64_t v_descale_stride_h;
   float p_bias, defer;         /* as vorta_attn_fp8_ext (0 = defaults 5 and 3) */

@@ -495,7 +495,7 @@ _FP8_AMBIG = 1e-4
 
 
 def _fp8_flash_rows(Q: np.ndarray, K: np.ndarray, V: np.ndarray, blk_lo: int, blk_hi: int, p_bias: float, defer: float,
-                    round_p: bool, block: int = 64, ambiguous: Optional[np.ndarray] = None):
+                    round_p: bool, block: int = 64, ambiguous: Optional[np.ndarray] = None, p_mode: str = "rne"):
     """One wave of the fp8 kernel (<= 32 query rows, all sharing the reference-point decisions) over key blocks
     [blk_lo, blk_hi).  Q (n,D), K/V (n_kv,D) are decoded e4m3 values; Q . K is the score in the exp2 domain.
     Returns unnormalised O (n,D), row sums l (n,) and reference points m (n,), all relative to 2^p_bias.
@@ -528,7 +528,16 @@ def _fp8_flash_rows(Q: np.ndarray, K: np.ndarray, V: np.ndarray, blk_lo: int, bl
                     ambiguous *= a
                 m = m + g
         P = np.exp2(z - m[:, None] + p_bias)
-        if round_p:
+        if round_p and p_mode == "direct":
+            # vorta_attn_fwd_i8: the e4m3 BYTE is rint(8 x + 56), x = log2 P' (one v_cvt_pk_u8_f32, saturating at 0): exponent
+            # field = integer part of x, mantissa = linear interpolation of its fraction
+            y = 8.0 * (z - m[:, None] + p_bias) + 56.0
+            if ambiguous is not None:
+                near = np.rint(y + 2e-3) != np.rint(y - 2e-3)
+                ambiguous += (P * near).sum(1)
+            with np.errstate(invalid="ignore"):
+                P = e4m3_decode(np.clip(np.rint(np.where(np.isfinite(y), y, 0.0)), 0, 126).astype(np.int64))
+        elif round_p:
             if ambiguous is not None:
                 near = e4m3_round(P * (1 + _FP8_AMBIG)) != e4m3_round(P * (1 - _FP8_AMBIG))
                 ambiguous += (P * near).sum(1)
@@ -545,7 +554,7 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
                     p_bias: float = 5.0, defer: float = 3.0, round_p: bool = True,
                     ambiguous: Optional[np.ndarray] = None,
                     q_group_bounds: Optional[Sequence[Tuple[int, int]]] = None,
-                    wave_filter=None) -> None:
+                    wave_filter=None, wave_operands=None, p_mode: str = "rne") -> None:
     """include/vorta_hip.h vorta_attn_fwd_fp8 for ONE head: q,k,v (rows,D) decoded e4m3 values, `out` (rows,D) is
     written in place (rows named by q_rows / dup_rows only).  kv_rows: (n_kv,) or (n_groups, n_kv).
     `ambiguous` (rows,) float, optional: per output row, the total normalised probability of the keys whose e4m3
@@ -553,7 +562,10 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
     is in doubt).  Each of those may move by one e4m3 step (<= 2^-3 relative), so a correct kernel differs from this
     restatement by at most 2^-3 * that * (|v| + |o|) on top of its accumulation error.
     `wave_filter(group, first_position_in_group) -> bool`, optional: restate only the waves it accepts (sampled checks at
-    sizes where every wave would take hours); rows of the other waves are left untouched."""
+    sizes where every wave would take hours); rows of the other waves are left untouched.
+    `wave_operands(query_rows, key_rows) -> (Qw, Kw)`, optional: the score operands of ONE wave (vorta_attn_fwd_i8: the query
+    scale, hence the rounded key biases, belong to the wave -- `i8_wave_operands`); q and k are then not read.
+    `p_mode="direct"`: the probabilities' bytes are rint(8 log2 P' + 56) (see `_fp8_flash_rows`)."""
     q_valid = n_q if q_valid is None else q_valid
     glen = q_group_len if q_group_len > 0 else n_q
     if q_group_bounds is None:  # equal groups; else [start, end) of every group (vorta_attn_args.q_block_table)
@@ -569,18 +581,21 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
             kr = (kv_rows[g] if kv_rows.ndim == 2 else kv_rows)[:n_kv]
         if wave_filter is not None and not any(wave_filter(g, w0) for w0 in range(0, len(pos), 32)):
             continue
-        Kg, Vg = k[kr], v[kr]
+        Kg, Vg = (k[kr] if wave_operands is None else None), v[kr]
         for w0 in range(0, len(pos), 32):  # one wave = 32 consecutive positions of the group
             if wave_filter is not None and not wave_filter(g, w0):
                 continue
             sl = slice(w0, min(w0 + 32, len(pos)))
-            Qw = q[rows[sl]]
+            if wave_operands is None:
+                Qw = q[rows[sl]]
+            else:
+                Qw, Kg = wave_operands(rows[sl], kr)
             parts, ambs = [], []
             for s in range(n_splits):
                 if s * bps < nblk:
                     ambs.append(np.zeros(Qw.shape[0]) if ambiguous is not None else None)
                     parts.append(_fp8_flash_rows(Qw, Kg, Vg, s * bps, min((s + 1) * bps, nblk), p_bias, defer, round_p,
-                                                 ambiguous=ambs[-1]))
+                                                 ambiguous=ambs[-1], p_mode=p_mode))
             mm = np.max([p[2] for p in parts], axis=0)
             O = sum(p[0] * np.exp2(p[2] - mm)[:, None] for p in parts)
             l = sum(p[1] * np.exp2(p[2] - mm) for p in parts)
@@ -601,7 +616,11 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
 # ---------------------------------------------------------------------------------------------- int8 scores (ABI 6)
 # No reference counterpart either: this restates include/vorta_hip.h vorta_i8_quantize_k (csrc/i8_quant.hip) and the query
 # conversion at the head of vorta_attn_fwd_i8 (csrc/attn_fwd_i8.hip) operation for operation in float32, so the kernels can be
-# held to it bit for bit; the attention itself is `fp8_attn_launch` on q8 * sq and k8 * sk (the integer dot product is exact).
+# held to it bit for bit; the attention itself is `fp8_attn_launch` with `wave_operands` (the scores of a wave are
+# u (q8 . k8 + seed), an exact integer dot product) and `p_mode="direct"` (the probabilities' e4m3 bytes are rint(8 x + 56)).
+I8_MAGIC_LIMIT = 2000000.0  # |bias| in integer score units is clamped to this (the int32 accumulator is read as a float)
+
+
 def i8_sample_tokens(n_tokens: int) -> np.ndarray:
     """tokens of a head's sample: i * stride, stride = (n_tokens // 1024) | 1 (odd, >= 1)"""
     stride = max(1, n_tokens // 1024) | 1
@@ -609,60 +628,77 @@ def i8_sample_tokens(n_tokens: int) -> np.ndarray:
 
 
 def i8_quantize_k(q: np.ndarray, k: np.ndarray, smooth: bool = True, center: bool = True) -> dict:
-    """(H,S,D) arrays of bf16 / fp16-representable values -> dict(k8 int8 (H,S,D), k_scale f32 (H,S), q_smooth f32 (H,D),
-    center f32 (H,D)).  Sample statistics with the kernel's summation order: row lane rl of 64 adds its samples rl, rl + 64,
-    ... in order, the 64 partial sums are added pairwise at distance 32, 16, ..., 1; every product and sum rounded to float32."""
+    """(H,S,D) arrays of bf16 / fp16-representable values -> dict(k8 int8 (H,S,D), k_bias f32 (H,S), q_prep f32 (H,2,D) = cq | s,
+    k_head_scale f32 (H,), center_k f32 (H,D)).  Sample statistics with the kernel's summation order: row lane rl of 64 adds
+    its samples rl, rl + 64, ... in order, the 64 partial sums are added pairwise at distance 32, 16, ..., 1; the bias dot
+    product: 8 channels per lane in order, the 16 lanes pairwise at distance 1, 2, 4, 8; every product and sum rounded to
+    float32 on its own."""
     f32 = np.float32
     q, k = np.asarray(q, dtype=f32), np.asarray(k, dtype=f32)
     H, S, D = k.shape
     tok = i8_sample_tokens(S)
     n = f32(len(tok))
-    cen, smo = np.zeros((H, D), f32), np.ones((H, D), f32)
+    ck, cq, smo = np.zeros((H, D), f32), np.zeros((H, D), f32), np.ones((H, D), f32)
     for h in range(H):
         ks, qs = k[h, tok], q[h, tok]
-        part = np.zeros((3, 64, D), f32)
+        part = np.zeros((4, 64, D), f32)
         for i in range(len(tok)):
             rl = i % 64
             part[0, rl] = part[0, rl] + ks[i]
             part[1, rl] = part[1, rl] + ks[i] * ks[i]
-            part[2, rl] = part[2, rl] + qs[i] * qs[i]
+            part[2, rl] = part[2, rl] + qs[i]
+            part[3, rl] = part[3, rl] + qs[i] * qs[i]
         off = 32
         while off > 0:
             part[:, :off] = part[:, :off] + part[:, off:2 * off]
             off >>= 1
-        mean = part[0, 0] / n
-        var = part[1, 0] / n - mean * mean
-        mq2 = part[2, 0] / n
-        s = np.ones(D, f32)
-        ok = (var > 0) & (mq2 > 0)
+        mean_k, mean_q = part[0, 0] / n, part[2, 0] / n
+        var_k = part[1, 0] / n - mean_k * mean_k
+        var_q = part[3, 0] / n - mean_q * mean_q
+        sv = np.ones(D, f32)
+        ok = (var_k > 0) & (var_q > 0)
         if smooth:
             with np.errstate(divide="ignore", invalid="ignore"):
-                s_all = np.sqrt(np.sqrt((var / mq2).astype(f32)).astype(f32)).astype(f32)
-            s[ok] = np.minimum(np.maximum(s_all[ok], f32(0.125)), f32(8.0))
-        cen[h] = mean if center else 0
-        smo[h] = s
+                s_all = np.sqrt(np.sqrt((var_k / var_q).astype(f32)).astype(f32)).astype(f32)
+            sv[ok] = np.minimum(np.maximum(s_all[ok], f32(0.125)), f32(8.0))
+        if center:
+            ck[h], cq[h] = mean_k, mean_q
+        smo[h] = sv
     inv_s = (f32(1.0) / smo).astype(f32)
-    kt = ((k - cen[:, None, :]).astype(f32) * inv_s[:, None, :]).astype(f32)
-    am = np.abs(kt).max(-1)
+    d = (k - ck[:, None, :]).astype(f32)
+    kt = (d * inv_s[:, None, :]).astype(f32)
+    am = np.abs(kt).reshape(H, -1).max(-1)
     with np.errstate(divide="ignore"):
         inv = np.where(am > 0, f32(127.0) / am, f32(0.0)).astype(f32)
-    k8 = np.clip(np.rint((kt * inv[..., None]).astype(f32)), -127, 127).astype(np.int8)
-    k_scale = np.where(am > 0, (am * f32(1.0 / 127.0)).astype(f32), f32(1.0)).astype(f32)
-    return dict(k8=k8, k_scale=k_scale, q_smooth=smo, center=cen)
+    k8 = np.clip(np.rint((kt * inv[:, None, None]).astype(f32)), -127, 127).astype(np.int8)
+    pr = (cq[:, None, :] * d).astype(f32).reshape(H, S, 16, 8)
+    lane = np.zeros((H, S, 16), f32)
+    for e in range(8):
+        lane = lane + pr[..., e]
+    while lane.shape[-1] > 1:
+        lane = lane[..., 0::2] + lane[..., 1::2]
+    k_bias = (lane[..., 0] * inv[:, None]).astype(f32)
+    k_head_scale = np.where(am > 0, (am * f32(1.0 / 127.0)).astype(f32), f32(1.0)).astype(f32)
+    return dict(k8=k8, k_bias=k_bias, q_prep=np.stack([cq, smo], 1), k_head_scale=k_head_scale, center_k=ck)
 
 
-def i8_quantize_q_rows(q: np.ndarray, q_smooth: np.ndarray, scale: Optional[float] = None):
-    """What a wave of vorta_attn_fwd_i8 does with its query rows: (n,D) 16-bit-representable values x the head's (D,)
-    smoothing vector, per-row abs-max, q8 = rint(qt * 127 / amax).  Returns (q8 int (n,D), sqc f32 (n,)): sqc = amax / 127 *
-    scale * log2(e), what one unit of q8 is worth in the exp2 domain (times the key's scale)."""
+def i8_wave_operands(q_rows: np.ndarray, q_prep: np.ndarray, sk: float, k8: np.ndarray, k_bias: np.ndarray,
+                     scale: Optional[float] = None):
+    """What ONE wave of vorta_attn_fwd_i8 multiplies: q_rows (n <= 32, D) 16-bit-representable query rows of the wave, q_prep
+    (2, D) = cq | s of the head, sk its key scale, k8 (n_kv, D) / k_bias (n_kv,) the keys of the wave's list.  The wave's
+    query scale is the abs-max over ALL its rows / 127; the accumulator starts from rint(k_bias / sq) (clamped).  Returns
+    (Q (n, D+1), K (n_kv, D+1)) float64 with Q @ K.T = u (q8 . k8 + seed): the exp2-domain scores."""
     f32 = np.float32
-    q = np.asarray(q, dtype=f32)
+    q = np.asarray(q_rows, dtype=f32)
     D = q.shape[-1]
     c0 = f32(f32(1.0 / np.sqrt(D) if scale is None else scale) * f32(1.4426950408889634))
-    qt = (q * np.asarray(q_smooth, f32)[None, :]).astype(f32)
-    am = np.abs(qt).max(-1)
-    with np.errstate(divide="ignore"):
-        inv = np.where(am > 0, f32(127.0) / am, f32(0.0)).astype(f32)
-    q8 = np.clip(np.rint((qt * inv[:, None]).astype(f32)), -127, 127).astype(np.int64)
-    sq = np.where(am > 0, (am * f32(1.0 / 127.0)).astype(f32), f32(1.0)).astype(f32)
-    return q8, (sq * c0).astype(f32)
+    qt = ((q - np.asarray(q_prep[0], f32)[None, :]).astype(f32) * np.asarray(q_prep[1], f32)[None, :]).astype(f32)
+    am = f32(np.abs(qt).max())
+    inv = f32(127.0) / am if am > 0 else f32(0.0)
+    q8 = np.clip(np.rint((qt * inv).astype(f32)), -127, 127).astype(np.float64)
+    sq = (am * f32(1.0 / 127.0)) if am > 0 else f32(1.0)
+    u = f32(f32(sq * c0) * f32(sk))
+    seed = np.clip(np.rint((np.asarray(k_bias, f32) * inv).astype(f32)), -I8_MAGIC_LIMIT, I8_MAGIC_LIMIT).astype(np.float64)
+    Q = np.concatenate([q8 * float(u), np.full((q8.shape[0], 1), float(u))], 1)
+    K = np.concatenate([np.asarray(k8, np.float64), seed[:, None]], 1)
+    return Q, K

@@ -1,12 +1,13 @@
 """GPU parity of the INT8-SCORE attention (csrc/attn_fwd_i8.hip + csrc/i8_quant.hip; include/vorta_hip.h ABI 6): scores on
 v_mfma_i32_32x32x32_i8 with one scale per key row and per query row, P V in e4m3.  Gates:
-  (q)   the quantiser against the oracle's float32 restatement: int8 bytes, row scales, smoothing vector and centre BIT FOR
-        BIT (plain layout); the segmented Ulysses layout and slot groups write the bytes of the plain call;
-  (i)   kernel vs the oracle's emulator on the SAME operands -- q8 * sq (the kernel's own query conversion restated), k8 * sk,
-        v decoded from the e4m3 bytes -- with the probabilities rounded to e4m3 at the kernel's reference points: the 16-bit
-        tolerances plus the emulator's midpoint slack (dense ragged, tables / groups / duplicates / head lists, the rescale
-        branch, split keys);
-  (i')  kernel vs exact attention on the same operands: rel. Frobenius <= 3e-2;
+  (q)   the quantiser against the oracle's float32 restatement: int8 bytes, row biases, query centre / balance vector, head
+        scale and key centre BIT FOR BIT (plain layout); the segmented Ulysses layout and slot groups write the bytes of the
+        plain call;
+  (i)   kernel vs the oracle's emulator on the SAME operands -- per wave u (q8 . k8 + seed) with the wave's own query
+        conversion restated (O.i8_wave_operands), v decoded from the e4m3 bytes -- with the probabilities' bytes written as the
+        kernel writes them (rint(8 log2 P' + 56)) at the kernel's reference points: the 16-bit tolerances plus the emulator's
+        midpoint slack (dense ragged, tables / groups / duplicates / head lists, the rescale branch, split keys);
+  (i')  kernel vs exact attention on the same operands: rel. Frobenius <= 4e-2;
   (ii)  operator PSNR against the bf16 kernels on every input family of tests/_fp8_inputs.py, both geometries, every expert:
         >= 40 dB over max|x| (>= 39 on the outlier-weights-with-common-part family) -- the targets VERDICT r03 item 2 set, not
         the measurements."""
@@ -24,16 +25,19 @@ from _util import dev, rel_fro, to_dev  # noqa: E402
 from test_hip_fp8 import RELF_PACK, _check, _vmax  # noqa: E402
 
 
-def _operands(qd, i8, v8, vd, scale=None, heads=None):
-    """what the kernel multiplies, as float64 arrays: (q8 * sqc, k8 * sk, v8 decoded, v_descale)"""
-    H = qd.shape[0]
-    sm = i8.q_smooth.cpu().numpy()
-    qe = np.zeros(qd.shape, np.float64)
-    for h in range(H):
-        q8, sqc = O.i8_quantize_q_rows(qd[h].float().cpu().numpy(), sm[h], scale)
-        qe[h] = q8 * sqc.astype(np.float64)[:, None]
-    ke = i8.k8.cpu().numpy().astype(np.float64) * i8.k_scale.cpu().numpy().astype(np.float64)[..., None]
-    return qe, ke, O.e4m3_decode(v8.cpu().numpy()), vd.cpu().numpy().astype(np.float64)
+RELF_DIRECT = 4e-2  # kernel vs exact-P attention on the same operands: e4m3 rounding of P (2.0-2.4e-2) + the linear mantissa
+
+
+def _hooks(qd, i8, scale=None):
+    """per head h: the `wave_operands` hook of O.fp8_attn_launch for that head's operands (numpy copies made once)"""
+    q_np = qd.float().cpu().numpy()
+    k8, kb = i8.k8.cpu().numpy(), i8.k_bias.cpu().numpy()
+    qp, sk = i8.q_prep.cpu().numpy(), i8.k_head_scale.cpu().numpy()
+    return [(lambda qr, kr, h=h: O.i8_wave_operands(q_np[h][qr], qp[h], sk[h], k8[h][kr], kb[h][kr], scale)) for h in range(qd.shape[0])]
+
+
+def _vdec(v8, vd):
+    return O.e4m3_decode(v8.cpu().numpy()), vd.cpu().numpy().astype(np.float64)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -41,29 +45,32 @@ def test_i8_quantizer_bit_for_bit_and_layouts(dtype):
     from vorta_amd import ops
     rng = np.random.default_rng(5)
     H, S = 3, 2600
-    q = rng.standard_normal((H, S, 128)) * np.linspace(0.2, 4.0, 128)
+    q = rng.standard_normal((H, S, 128)) * np.linspace(0.2, 4.0, 128) + 1.5 * rng.standard_normal((H, 1, 128))
     k = rng.standard_normal((H, S, 128)) * np.linspace(3.0, 0.3, 128) + 2.0 * rng.standard_normal((H, 1, 128))
-    k[1, 17] = 0.0  # (an all-zero row after centring does not exist here; a zero INPUT row is an ordinary row)
+    k[1, 17] = 0.0
     qd, kd = to_dev(q, dtype), to_dev(k, dtype)
     got = ops.i8_quantize_k(qd, kd)
     torch.cuda.synchronize()
     ref = O.i8_quantize_k(qd.float().cpu().numpy(), kd.float().cpu().numpy())
-    assert np.array_equal(got.k_center().cpu().numpy(), ref["center"])
-    assert np.array_equal(got.q_smooth.cpu().numpy(), ref["q_smooth"])
-    assert np.array_equal(got.k_scale.cpu().numpy(), ref["k_scale"])
+    assert np.array_equal(got.k_center().cpu().numpy(), ref["center_k"])
+    assert np.array_equal(got.q_prep.cpu().numpy(), ref["q_prep"])
+    assert np.array_equal(got.k_head_scale.cpu().numpy(), ref["k_head_scale"])
     assert np.array_equal(got.k8.cpu().numpy(), ref["k8"])
-    assert ref["q_smooth"].min() < 0.6 and ref["q_smooth"].max() > 1.7  # the smoothing vector does something here
-    # switches: no smoothing / no centring
+    assert np.array_equal(got.k_bias.cpu().numpy(), ref["k_bias"])
+    assert ref["q_prep"][:, 1].min() < 0.6 and ref["q_prep"][:, 1].max() > 1.7  # the balance vector does something here
+    assert np.abs(ref["k8"]).max() == 127
+    # switches: no balancing / no centring
     plain = ops.i8_quantize_k(qd, kd, smooth=False, center=False)
     refp = O.i8_quantize_k(qd.float().cpu().numpy(), kd.float().cpu().numpy(), smooth=False, center=False)
-    assert np.array_equal(plain.k8.cpu().numpy(), refp["k8"]) and float(plain.q_smooth.min()) == float(plain.q_smooth.max()) == 1.0
+    assert np.array_equal(plain.k8.cpu().numpy(), refp["k8"]) and float(plain.k_bias.abs().max()) == 0.0
+    assert float(plain.q_prep[:, 1].min()) == float(plain.q_prep[:, 1].max()) == 1.0 and float(plain.q_prep[:, 0].abs().max()) == 0.0
     # strided input views (the projection buffer's (S, H*D) layout) give the same bytes
     kb = torch.empty((S, H, 128), dtype=dtype, device=dev())
     kb.copy_(kd.transpose(0, 1))
     qb = torch.empty((S, H, 128), dtype=dtype, device=dev())
     qb.copy_(qd.transpose(0, 1))
     strided = ops.i8_quantize_k(qb.transpose(0, 1), kb.transpose(0, 1))
-    assert torch.equal(strided.k8, got.k8) and torch.equal(strided.k_scale, got.k_scale)
+    assert torch.equal(strided.k8, got.k8) and torch.equal(strided.k_bias, got.k_bias)
 
 
 @pytest.mark.parametrize("T", [0, 40])
@@ -76,7 +83,7 @@ def test_i8_quantizer_segmented_layout_and_slot_groups_write_the_same_bytes(T):
     Hl, P, Sl = 3, 4, 520
     S = P * Sl
     rng = np.random.default_rng(6 + T)
-    q = rng.standard_normal((Hl, S + T, 128))
+    q = rng.standard_normal((Hl, S + T, 128)) + rng.standard_normal((Hl, 1, 128))
     k = rng.standard_normal((Hl, S + T, 128)) * np.linspace(0.5, 2.0, 128) + rng.standard_normal((Hl, 1, 128))
     qd, kd = to_dev(q, dtype), to_dev(k, dtype)
     plain = ops.i8_quantize_k(qd, kd)
@@ -95,23 +102,26 @@ def test_i8_quantizer_segmented_layout_and_slot_groups_write_the_same_bytes(T):
     def fresh():
         return ops.I8Operands(torch.zeros((1, lay.rows_total, 128), dtype=torch.int8, device=dev()),
                               torch.zeros((1, lay.rows_total), dtype=torch.float32, device=dev()),
-                              torch.zeros((Hl, 128), dtype=torch.float32, device=dev()),
-                              torch.zeros(2 * Hl * 128, dtype=torch.float32, device=dev()))
+                              torch.zeros((Hl, 2, 128), dtype=torch.float32, device=dev()),
+                              torch.zeros((Hl,), dtype=torch.float32, device=dev()),
+                              torch.zeros(2 * Hl * 128 + Hl, dtype=torch.float32, device=dev()))
 
     def views(o):
         k8 = lay.head_view(o.k8[0])
-        sc = o.k_scale[0].as_strided((Hl, lay.rows_total - (Hl - 1) * Sl), (Sl, 1))
-        return k8[:, rm[:S + T]], sc[:, rm[:S + T]]
+        kb = o.k_bias[0].as_strided((Hl, lay.rows_total - (Hl - 1) * Sl), (Sl, 1))
+        return k8[:, rm[:S + T]], kb[:, rm[:S + T]]
 
     kw = dict(heads=Hl, seg_len=Sl, tail_first=lay.rows_video, tail_len=T)
     one = ops.i8_quantize_k(bufs[0][None], bufs[1][None], out=fresh(), **kw)
-    k8, sc = views(one)
-    assert torch.equal(k8, plain.k8) and torch.equal(sc, plain.k_scale) and torch.equal(one.q_smooth, plain.q_smooth)
+    k8, kb = views(one)
+    assert torch.equal(k8, plain.k8) and torch.equal(kb, plain.k_bias) and torch.equal(one.q_prep, plain.q_prep)
+    assert torch.equal(one.k_head_scale, plain.k_head_scale)
     grouped = fresh()
     for g0, g1 in ((0, 2), (2, 3)):
         ops.i8_quantize_k(bufs[0][None], bufs[1][None], out=grouped, slots=(g0, g1), **kw)
-    k8, sc = views(grouped)
-    assert torch.equal(k8, plain.k8) and torch.equal(sc, plain.k_scale) and torch.equal(grouped.q_smooth, plain.q_smooth)
+    k8, kb = views(grouped)
+    assert torch.equal(k8, plain.k8) and torch.equal(kb, plain.k_bias) and torch.equal(grouped.q_prep, plain.q_prep)
+    assert torch.equal(grouped.k_head_scale, plain.k_head_scale)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -120,28 +130,31 @@ def test_i8_dense_ragged_vs_emulator(dtype, block_rows):
     from vorta_amd import ops
     rng = np.random.default_rng(1)
     H, Sq, Skv = 3, 333, 417
-    q, k, v = rng.standard_normal((H, Skv, 128)), rng.standard_normal((H, Skv, 128)), rng.standard_normal((H, Skv, 128))
+    q = rng.standard_normal((H, Skv, 128)) + 0.8 * rng.standard_normal((H, 1, 128))
+    k, v = rng.standard_normal((H, Skv, 128)) + 0.5, rng.standard_normal((H, Skv, 128))
     n_kv, q_valid = 401, 300
     qd, kd = to_dev(q, dtype), to_dev(k, dtype)
     i8 = ops.i8_quantize_k(qd, kd)
-    v8, vd, _ = ops.fp8_quantize_v(to_dev(v * np.linspace(0.05, 8.0, 128), dtype))
+    vdev = to_dev(v * np.linspace(0.05, 8.0, 128), dtype)
+    v8, vd, _ = ops.fp8_quantize_v(vdev)
     out = torch.full((H, Sq, 128), 7.0, dtype=dtype, device=dev())
-    ops.attn_fwd(qd[:, :Sq], i8.k8, v8, out, n_q=Sq, n_kv=n_kv, q_valid=q_valid, block_rows=block_rows, v_descale=vd,
-                 k_scale=i8.k_scale, q_smooth=i8.q_smooth)
+    ops.attn_fwd(qd[:, :Sq], i8.k8, v8, out, n_q=Sq, n_kv=n_kv, q_valid=q_valid, block_rows=block_rows, v_descale=vd, i8=i8)
     torch.cuda.synchronize()
-    qe, ke, ve, vde = _operands(qd[:, :Sq], i8, v8, vd)
+    hooks = _hooks(qd, i8)
+    ve, vde = _vdec(v8, vd)
     ref, exact, amb = np.zeros((H, Sq, 128)), np.zeros((H, Sq, 128)), np.zeros((H, Sq))
     for h in range(H):
-        O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, ambiguous=amb[h])
-        O.fp8_attn_launch(qe[h], ke[h], ve[h], exact[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, round_p=False)
+        O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, ambiguous=amb[h],
+                          wave_operands=hooks[h], p_mode="direct")
+        O.fp8_attn_launch(None, None, ve[h], exact[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, round_p=False,
+                          wave_operands=hooks[h])
     _check(out, ref, dtype, amb, _vmax(ve, vde))
-    assert rel_fro(out.float().cpu().numpy(), exact) <= RELF_PACK
+    assert rel_fro(out.float().cpu().numpy(), exact) <= RELF_DIRECT
     assert torch.all(out[:, q_valid:] == 0)
     # and against exact attention on the 16-bit inputs: what int8 scores + e4m3 P, V cost together
     full = np.stack([O.dense_attention(qd[h, :Sq].double().cpu().numpy(), kd[h].double().cpu().numpy(),
-                                       (to_dev(v * np.linspace(0.05, 8.0, 128), dtype))[h].double().cpu().numpy(),
-                                       kv_valid=n_kv, q_valid=q_valid) for h in range(H)])
-    assert rel_fro(out.float().cpu().numpy(), full) <= 0.05
+                                       vdev[h].double().cpu().numpy(), kv_valid=n_kv, q_valid=q_valid) for h in range(H)])
+    assert rel_fro(out.float().cpu().numpy(), full) <= 0.06
 
 
 def test_i8_rescale_branch_long_keys_and_split_keys():
@@ -157,14 +170,15 @@ def test_i8_rescale_branch_long_keys_and_split_keys():
     qd, kd = to_dev(q, dtype), to_dev(k, dtype)
     i8 = ops.i8_quantize_k(qd, kd)
     v8, vd, _ = ops.fp8_quantize_v(to_dev(v, dtype))
-    qe, ke, ve, vde = _operands(qd[:, :Sq], i8, v8, vd)
+    hooks = _hooks(qd, i8)
+    ve, vde = _vdec(v8, vd)
     for n_splits in (1, 3, 8):
         out = torch.empty((H, Sq, 128), dtype=dtype, device=dev())
-        ops.attn_fwd(qd[:, :Sq], i8.k8, v8, out, n_q=Sq, n_kv=Skv, v_descale=vd, n_splits=n_splits, k_scale=i8.k_scale,
-                     q_smooth=i8.q_smooth)
+        ops.attn_fwd(qd[:, :Sq], i8.k8, v8, out, n_q=Sq, n_kv=Skv, v_descale=vd, n_splits=n_splits, i8=i8)
         ref, amb = np.zeros((H, Sq, 128)), np.zeros((H, Sq))
         for h in range(H):
-            O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=Sq, n_kv=Skv, n_splits=n_splits, ambiguous=amb[h])
+            O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=Sq, n_kv=Skv, n_splits=n_splits, ambiguous=amb[h],
+                              wave_operands=hooks[h], p_mode="direct")
         _check(out, ref, dtype, amb, _vmax(ve, vde))
 
 
@@ -175,7 +189,7 @@ def test_i8_tables_groups_duplicates_heads(block_rows):
     rng = np.random.default_rng(3)
     H, rows = 4, 700
     x = [rng.standard_normal((H, rows, 128)) for _ in range(3)]
-    qd, kd = to_dev(x[0], dtype), to_dev(x[1], dtype)
+    qd, kd = to_dev(x[0] + 0.7, dtype), to_dev(x[1], dtype)
     i8 = ops.i8_quantize_k(qd, kd)
     v8, vd, _ = ops.fp8_quantize_v(to_dev(x[2], dtype))
     n_q, glen, n_kv = 520, 200, 391  # 3 groups (200, 200, 120), own key list per group
@@ -189,13 +203,15 @@ def test_i8_tables_groups_duplicates_heads(block_rows):
     ops.attn_fwd(qd, i8.k8, v8, out, head_list=heads, n_heads_dev=count, n_q=n_q, q_group_len=glen, n_kv=n_kv,
                  q_rows=torch.as_tensor(q_rows, device=dev()), kv_rows=torch.as_tensor(kv_rows, device=dev()),
                  kv_rows_stride_g=n_kv, dup_rows=torch.as_tensor(dup, device=dev()), n_dup_pos=60,
-                 block_rows=block_rows, v_descale=vd, k_scale=i8.k_scale, q_smooth=i8.q_smooth)
+                 block_rows=block_rows, v_descale=vd, i8=i8)
     torch.cuda.synchronize()
-    qe, ke, ve, vde = _operands(qd, i8, v8, vd)
+    hooks = _hooks(qd, i8)
+    ve, vde = _vdec(v8, vd)
     ref, amb = np.zeros((H, rows, 128)), np.zeros((H, rows))
     for h in (3, 0):
-        O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=n_q, n_kv=n_kv, q_rows=q_rows, q_group_len=glen,
-                          kv_rows=kv_rows, dup_rows=dup, n_dup_pos=60, ambiguous=amb[h])
+        O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=n_q, n_kv=n_kv, q_rows=q_rows, q_group_len=glen,
+                          kv_rows=kv_rows, dup_rows=dup, n_dup_pos=60, ambiguous=amb[h], wave_operands=hooks[h],
+                          p_mode="direct")
     _check(out, ref, dtype, amb, _vmax(ve, vde))
     assert torch.all(out[2] == 0) and torch.all(out[1] == 0)
 
@@ -236,7 +252,7 @@ def test_i8_routed_attention_vs_oracle(model, fused):
     o = out[0].float().cpu().numpy()
     rfs = [rel_fro(o[h], full[h]) for h in range(H)]
     print("i8pv routed vs the fp64 oracle on the 16-bit inputs, rel. Frobenius per head:", [round(x, 4) for x in rfs])
-    assert max(rfs) < 0.05, rfs
+    assert max(rfs) < 0.06, rfs
     if T:
         assert torch.all(out[0, :, S + te:] == 0)
 

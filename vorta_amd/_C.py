@@ -122,16 +122,16 @@ class AttnFp8Ext(C.Structure):
 class I8QuantArgs(C.Structure):
     _fields_ = [
         ("struct_size", _u32), ("dtype", _i32), ("head_dim", _i32), ("heads", _i32), ("n_tokens", _i32),
-        ("q", Tensor), ("k", Tensor), ("k8", Tensor), ("k_scale", _vp), ("k_scale_stride_h", _i64),
-        ("q_smooth", _vp), ("ws", _vp), ("flags", _i32), ("seg_len", _i32), ("tail_first", _i32), ("tail_len", _i32),
-        ("slot_first", _i32), ("slot_count", _i32), ("video_tokens", _i32), ("reserved", _i32),
+        ("q", Tensor), ("k", Tensor), ("k8", Tensor), ("k_bias", _vp), ("k_bias_stride_h", _i64),
+        ("q_prep", _vp), ("k_head_scale", _vp), ("ws", _vp), ("flags", _i32), ("seg_len", _i32), ("tail_first", _i32),
+        ("tail_len", _i32), ("slot_first", _i32), ("slot_count", _i32),
     ]
 
 
 class AttnI8Ext(C.Structure):
     _fields_ = [
-        ("struct_size", _u32), ("flags", _i32), ("k_scale", _vp), ("k_scale_stride_h", _i64),
-        ("q_smooth", _vp), ("q_smooth_stride_h", _i64), ("v_descale", _vp), ("v_descale_stride_h", _i64),
+        ("struct_size", _u32), ("flags", _i32), ("k_bias", _vp), ("k_bias_stride_h", _i64),
+        ("q_prep", _vp), ("q_prep_stride_h", _i64), ("k_head_scale", _vp), ("v_descale", _vp), ("v_descale_stride_h", _i64),
         ("p_bias", _f32), ("defer", _f32),
     ]
 

@@ -39,10 +39,14 @@ class _SpBuffers:
         self.f8 = None
         self.vwire = None
         self._wire = None
+        self.i8 = None
 
     def fp8(self, mode=True):
-        """(operands, v wire) of the e4m3 path; mode "fp8pv" (16-bit scores): only the e4m3 receive buffer of v"""
-        if mode == "fp8pv":
+        """(operands, v wire) of the e4m3 path; mode "fp8pv" (16-bit scores) / "i8pv" (int8 scores: + `self.i8`, the int8 key
+        buffers): only the e4m3 receive buffer of v"""
+        if mode == "i8pv" and self.i8 is None:
+            self.i8 = self.lay.i8_operands()
+        if mode in ("fp8pv", "i8pv"):
             if self.vwire is None or self.f8 is not None:
                 self.f8 = None
                 self.vwire = VWire(self.lay, torch.zeros((self.lay.rows_total, self.lay.D), dtype=torch.uint8,
@@ -142,14 +146,17 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     # the precision switch (set_attention_precision / VORTA_ATTENTION_PRECISION) is about the ROUTED operator; dense
     # attention -- --native_attention, the PSNR reference -- stays in the dtype of q,k,v on one GPU and under SP alike
     from .. import routed as _routed
-    fp8 = _routed.DEFAULT_FP8 if not dense_only else False  # False, True (all e4m3) or "fp8pv" (16-bit scores)
+    fp8 = _routed.DEFAULT_FP8 if not dense_only else False  # False, True (all e4m3), "fp8pv" (16-bit scores), "i8pv" (int8)
     f8, vwire = sb.fp8(fp8) if fp8 else (None, None)
     if vwire is not None:
         vwire.lay = lay  # the layouts of one slot count share the buffers; the head offsets are this layer's
 
     def attend(g0, g1, gi):
         views = None
-        if fp8 == "fp8pv":  # q, k as they landed; v arrived as e4m3 (converted on the send side)
+        if fp8 == "i8pv":  # k of the slot group that has landed -> int8 (q by the kernel); v arrived as e4m3
+            i8 = lay.i8_views(bufs, sb.i8, slots=(g0, g1))
+            views = (qv[g0:g1], i8.k8[g0:g1], lay.head_view(vwire.buf)[g0:g1], vwire.descale(g0, g1), i8.heads(g0, g1))
+        elif fp8 == "fp8pv":  # q, k as they landed; v arrived as e4m3 (converted on the send side)
             views = (qv[g0:g1], kv[g0:g1], lay.head_view(vwire.buf)[g0:g1], vwire.descale(g0, g1))
         elif fp8:  # the slot group that has landed is converted while the next one is in flight
             q8, k8, v8, vd, _ = lay.fp8_views(bufs, out=f8, slots=(g0, g1), vwire=vwire)

@@ -1,14 +1,15 @@
-// vorta_i8_quantize_k (include/vorta_hip.h, ABI 6): keys -> int8 rows with one scale per ROW, for the int8-score attention
-// kernel (attn_fwd_i8.hip).  No reference counterpart (the reference computes in the dtype of q, k, v: wan.py:243-294).
+// vorta_i8_quantize_k (include/vorta_hip.h, ABI 6): keys -> int8 rows + one float32 bias per row, for the int8-score
+// attention kernel (attn_fwd_i8.hip).  No reference counterpart (the reference computes in the dtype of q, k, v:
+// wan.py:243-294).
 //
 // Per head h, from the SAMPLE -- tokens i * stride, i < cand (~1024 of them; stride odd, so it does not lock onto a
 // segment length), video tokens then tail tokens, the same tokens in the (H,S,D) view and in the segmented Ulysses
 // receive layout -- in float32 with a FIXED summation order (the oracle restates it bit for bit):
-//     c[d]  = mean k[d]                                  (subtracted from every key: softmax does not see it)
-//     s[d]  = clamp((var k[d] / mean q[d]^2)^(1/4), 1/8, 8)   (q diag(s) . k diag(1/s) = q . k: channel ranges balanced)
-// then one pass over the rows:  kt = (k - c) * (1 / s),  sk = max|kt| * (1 / 127)  (1 if the row is zero),
-//                               k8 = rint(kt * (127 / max|kt|)).
-// Bound: HBM (2 B in, 1 B + 4/128 B out per element).
+//     ck[d] = mean k[d],  cq[d] = mean q[d],  s[d] = clamp((var k[d] / var q[d])^(1/4), 1/8, 8)
+// then two passes over the rows (kt = (k - ck) * (1 / s)):  amax = max |kt| over the head (exact: integer atomic max of the
+// float bits), and  k8 = rint(kt * (127 / amax)),  k_bias = (cq . (k - ck)) * (127 / amax)  (the dot product summed 8
+// channels per lane in order, the 16 lanes of a row pairwise at distance 1, 2, 4, 8).
+// Bound: HBM (2 + 2 B in, 1 B + 4/128 B out per element).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -23,8 +24,8 @@ constexpr int SAMPLES = 1024;
 struct IParams {
   const char* q; const char* k; int64_t q_sh, q_ss, k_sh, k_ss;  // bytes
   char* k8; int64_t k8_sh, k8_ss;
-  float* k_scale; int64_t k_scale_sh;
-  float* q_smooth; float* ws;
+  float* k_bias; int64_t k_bias_sh;
+  float* q_prep; float* k_head_scale; float* ws;
   int heads, n_tokens, rows_per_block;
   int seg_len, chunks_per_seg, tail_first, tail_len;
   int slot_first, slot_count;
@@ -49,9 +50,9 @@ __global__ __launch_bounds__(1024) void i8_stats_kernel(const IParams p) {
   };
   const char* kb = p.k + (p.seg_len > 0 ? 0 : (int64_t)h * p.k_sh) + cg * 16;
   const char* qb = p.q + (p.seg_len > 0 ? 0 : (int64_t)h * p.q_sh) + cg * 16;
-  float sk[8], sk2[8], sq2[8];
+  float sk[8], sk2[8], sq[8], sq2[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { sk[i] = 0.f; sk2[i] = 0.f; sq2[i] = 0.f; }
+  for (int i = 0; i < 8; ++i) { sk[i] = 0.f; sk2[i] = 0.f; sq[i] = 0.f; sq2[i] = 0.f; }
   for (int i = rl; i < p.cand; i += 64) {
     const int64_t r = row_of((int64_t)i * p.stride);
     const T8 kv = *(const T8*)(kb + r * p.k_ss);
@@ -62,21 +63,23 @@ __global__ __launch_bounds__(1024) void i8_stats_kernel(const IParams p) {
       const float k2 = kf * kf, q2 = qf * qf;
       sk[e] = sk[e] + kf;
       sk2[e] = sk2[e] + k2;
+      sq[e] = sq[e] + qf;
       sq2[e] = sq2[e] + q2;
     }
   }
-  __shared__ float red[3][64][D];
+  __shared__ float red[4][64][D];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     red[0][rl][cg * 8 + e] = sk[e];
     red[1][rl][cg * 8 + e] = sk2[e];
-    red[2][rl][cg * 8 + e] = sq2[e];
+    red[2][rl][cg * 8 + e] = sq[e];
+    red[3][rl][cg * 8 + e] = sq2[e];
   }
   __syncthreads();
   for (int off = 32; off > 0; off >>= 1) {
     if (rl < off) {
 #pragma unroll
-      for (int w = 0; w < 3; ++w)
+      for (int w = 0; w < 4; ++w)
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[w][rl][cg * 8 + e] = red[w][rl][cg * 8 + e] + red[w][rl + off][cg * 8 + e];
     }
@@ -84,20 +87,23 @@ __global__ __launch_bounds__(1024) void i8_stats_kernel(const IParams p) {
   }
   if (t < D) {
     const float n = (float)p.cand;
-    const float mean = red[0][0][t] / n;
-    const float c = p.no_center ? 0.f : mean;
+    const float mean_k = red[0][0][t] / n;
     const float mk2 = red[1][0][t] / n;
-    const float var = mk2 - mean * mean;
-    const float mq2 = red[2][0][t] / n;
+    const float var_k = mk2 - mean_k * mean_k;
+    const float mean_q = red[2][0][t] / n;
+    const float mq2 = red[3][0][t] / n;
+    const float var_q = mq2 - mean_q * mean_q;
     float s = 1.f;
-    if (!p.no_smooth && var > 0.f && mq2 > 0.f) {
-      s = sqrtf(sqrtf(var / mq2));
+    if (!p.no_smooth && var_k > 0.f && var_q > 0.f) {
+      s = sqrtf(sqrtf(var_k / var_q));
       s = fminf(fmaxf(s, 0.125f), 8.f);
     }
-    p.ws[h * D + t] = c;
+    p.ws[h * D + t] = p.no_center ? 0.f : mean_k;
     p.ws[(p.heads + h) * D + t] = 1.f / s;
-    p.q_smooth[h * D + t] = s;
+    p.q_prep[(2 * h) * D + t] = p.no_center ? 0.f : mean_q;
+    p.q_prep[(2 * h + 1) * D + t] = s;
   }
+  if (t == 0) ((int*)p.ws)[2 * p.heads * D + h] = 0;  // the head's abs-max slot (raised by the next launch)
 }
 
 // the rows a block works on: [r0, r1) of head `head` (physical head index `hphys` of the (H,S,D) views; 0 in the row array)
@@ -120,21 +126,29 @@ __device__ __forceinline__ void block_rows(const IParams& p, int& r0, int& r1, i
   }
 }
 
-// 256 threads: 16 lanes (8 channels each) per row, 16 rows per pass, UNR passes in flight
-template <typename T>
-__global__ __launch_bounds__(256) void i8_convert_kernel(const IParams p) {
+// 256 threads: 16 lanes (8 channels each) per row, 16 rows per pass, UNR passes in flight.  PASS 0: the head's abs-max of
+// kt (one integer atomic max of the float bits per workgroup); PASS 1: int8 rows and the row biases.
+template <typename T, int PASS>
+__global__ __launch_bounds__(256) void i8_rows_kernel(const IParams p) {
 #pragma clang fp contract(off)
   typedef __attribute__((ext_vector_type(8))) T T8;
   int r0, r1, h, hphys;
   block_rows(p, r0, r1, h, hphys);
   if (r0 >= r1) return;
   const int t = threadIdx.x, cg = t & 15, rl = t >> 4;
-  float c[8], is[8];
+  float c[8], is[8], cq[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { c[e] = p.ws[h * D + cg * 8 + e]; is[e] = p.ws[(p.heads + h) * D + cg * 8 + e]; }
+  for (int e = 0; e < 8; ++e) {
+    c[e] = p.ws[h * D + cg * 8 + e];
+    is[e] = p.ws[(p.heads + h) * D + cg * 8 + e];
+    cq[e] = p.q_prep[(2 * h) * D + cg * 8 + e];
+  }
   const char* src = p.k + (int64_t)hphys * p.k_sh + cg * 16;
   char* dst = p.k8 + (int64_t)hphys * p.k8_sh + cg * 8;
-  float* sc = p.k_scale + (int64_t)hphys * p.k_scale_sh;
+  float* bias = p.k_bias + (int64_t)hphys * p.k_bias_sh;
+  const float am_head = PASS == 1 ? __int_as_float(((const int*)p.ws)[2 * p.heads * D + h]) : 0.f;
+  const float inv = am_head > 0.f ? 127.f / am_head : 0.f;
+  float am = 0.f;
   constexpr int UNR = 4;
   for (int rb = r0 + rl; rb < r1; rb += 16 * UNR) {
     T8 a[UNR];
@@ -147,28 +161,50 @@ __global__ __launch_bounds__(256) void i8_convert_kernel(const IParams p) {
     for (int u = 0; u < UNR; ++u) {
       const int r = rb + 16 * u;  // rows past the end: the lanes still take part in the exchanges below with zeros
       float f[8];
-      float am = 0.f;
+      float dot = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        f[e] = r < r1 ? ((float)a[u][e] - c[e]) * is[e] : 0.f;
-        am = fmaxf(am, fabsf(f[e]));
+        const float d = r < r1 ? (float)a[u][e] - c[e] : 0.f;
+        f[e] = d * is[e];
+        if (PASS == 0) am = fmaxf(am, fabsf(f[e]));
+        else { const float pr = cq[e] * d; dot = dot + pr; }
       }
-      // abs-max over the row's 16 lanes (max is order-free: any exchange pattern gives the same value)
+      if (PASS == 1) {
 #pragma unroll
-      for (int m = 1; m < 16; m <<= 1) am = fmaxf(am, __shfl_xor(am, m, 16));
-      const float inv = am > 0.f ? 127.f / am : 0.f;
-      uint32_t w[2] = {0u, 0u};
+        for (int m = 1; m < 16; m <<= 1) dot = dot + __shfl_xor(dot, m, 16);
+        uint32_t w[2] = {0u, 0u};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        int v = (int)__builtin_rintf(f[e] * inv);
-        v = max(-127, min(127, v));
-        w[e >> 2] |= ((uint32_t)v & 0xffu) << (8 * (e & 3));
-      }
-      if (r < r1) {
-        *(u32x2*)(dst + (int64_t)r * p.k8_ss) = u32x2{w[0], w[1]};
-        if (cg == 0) sc[r] = am > 0.f ? am * (1.f / 127.f) : 1.f;
+        for (int e = 0; e < 8; ++e) {
+          int v = (int)__builtin_rintf(f[e] * inv);
+          v = max(-127, min(127, v));
+          w[e >> 2] |= ((uint32_t)v & 0xffu) << (8 * (e & 3));
+        }
+        if (r < r1) {
+          *(u32x2*)(dst + (int64_t)r * p.k8_ss) = u32x2{w[0], w[1]};
+          if (cg == 0) bias[r] = dot * inv;
+        }
       }
     }
+  }
+  if (PASS == 0) {
+    __shared__ float red[256];
+    red[t] = am;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (t < s) red[t] = fmaxf(red[t], red[t + s]);
+      __syncthreads();
+    }
+    if (t == 0) atomicMax((int*)p.ws + 2 * p.heads * D + h, __float_as_int(red[0]));  // non-negative floats order as ints
+  }
+}
+
+// grid (heads of the slot range), 64 threads: sk = amax / 127 (1 for an all-zero head)
+__global__ void i8_head_scale_kernel(const IParams p) {
+#pragma clang fp contract(off)
+  const int h = p.slot_first + blockIdx.x;
+  if (threadIdx.x == 0) {
+    const float am = __int_as_float(((const int*)p.ws)[2 * p.heads * D + h]);
+    p.k_head_scale[h] = am > 0.f ? am * (1.f / 127.f) : 1.f;
   }
 }
 
@@ -178,15 +214,13 @@ extern "C" int vorta_i8_quantize_k(const vorta_i8_quant_args* a, void* hip_strea
   if (!a || a->struct_size != sizeof(vorta_i8_quant_args)) return VORTA_EINVAL;
   if (a->dtype != VORTA_BF16 && a->dtype != VORTA_FP16) return VORTA_EUNSUPPORTED;
   if (a->head_dim != D) return VORTA_EUNSUPPORTED;
-  if (a->heads < 0 || a->n_tokens < 0 || a->seg_len < 0 || a->tail_first < 0 || a->tail_len < 0 || a->video_tokens < 0)
-    return VORTA_EINVAL;
+  if (a->heads < 0 || a->n_tokens < 0 || a->seg_len < 0 || a->tail_first < 0 || a->tail_len < 0) return VORTA_EINVAL;
   if (a->seg_len > 0 && (a->tail_first > 0 || a->tail_len > 0) && (a->tail_first % a->seg_len || a->tail_len > a->seg_len))
     return VORTA_EINVAL;
   if (a->slot_first < 0 || a->slot_count < 0 || (int64_t)a->slot_first + a->slot_count > a->heads) return VORTA_EINVAL;
   if ((a->slot_first || a->slot_count) && a->seg_len <= 0) return VORTA_EINVAL;
-  if (a->seg_len > 0 && a->video_tokens) return VORTA_EINVAL;  // the segmented layout derives it from tail_first
   if (a->heads == 0 || a->n_tokens == 0) return VORTA_OK;
-  if (!a->q.ptr || !a->k.ptr || !a->k8.ptr || !a->k_scale || !a->q_smooth || !a->ws) return VORTA_EINVAL;
+  if (!a->q.ptr || !a->k.ptr || !a->k8.ptr || !a->k_bias || !a->q_prep || !a->k_head_scale || !a->ws) return VORTA_EINVAL;
   const vorta_tensor* in[2] = {&a->q, &a->k};
   for (int i = 0; i < 2; ++i)
     if (((uintptr_t)in[i]->ptr & 15) || (in[i]->stride_s % 8) || (in[i]->stride_h % 8) || in[i]->stride_s < D) return VORTA_EINVAL;
@@ -195,8 +229,8 @@ extern "C" int vorta_i8_quantize_k(const vorta_i8_quant_args* a, void* hip_strea
   p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr;
   p.q_sh = a->q.stride_h * 2; p.q_ss = a->q.stride_s * 2; p.k_sh = a->k.stride_h * 2; p.k_ss = a->k.stride_s * 2;
   p.k8 = (char*)a->k8.ptr; p.k8_sh = a->k8.stride_h; p.k8_ss = a->k8.stride_s;
-  p.k_scale = a->k_scale; p.k_scale_sh = a->seg_len > 0 ? 0 : a->k_scale_stride_h;
-  p.q_smooth = a->q_smooth; p.ws = a->ws;
+  p.k_bias = a->k_bias; p.k_bias_sh = a->seg_len > 0 ? 0 : a->k_bias_stride_h;
+  p.q_prep = a->q_prep; p.k_head_scale = a->k_head_scale; p.ws = a->ws;
   p.heads = a->heads; p.n_tokens = a->n_tokens;
   p.seg_len = a->seg_len;
   const bool has_tail = a->seg_len > 0 && (a->tail_first > 0 || a->tail_len > 0);
@@ -207,8 +241,7 @@ extern "C" int vorta_i8_quantize_k(const vorta_i8_quant_args* a, void* hip_strea
   p.no_smooth = a->flags & 1; p.no_center = (a->flags >> 1) & 1;
   const int H = a->heads, hn = p.slot_count;
   int64_t head_tokens = a->n_tokens;
-  p.video_tokens = a->video_tokens ? a->video_tokens : head_tokens;
-  if (p.video_tokens > head_tokens) return VORTA_EINVAL;
+  p.video_tokens = head_tokens;
   if (p.seg_len > 0) {
     const int64_t data_rows = has_tail ? (int64_t)a->tail_first : (int64_t)a->n_tokens;
     p.video_tokens = (data_rows / p.seg_len / H) * p.seg_len;
@@ -238,8 +271,13 @@ extern "C" int vorta_i8_quantize_k(const vorta_i8_quant_args* a, void* hip_strea
   else hipLaunchKernelGGL((i8_stats_kernel<_Float16>), dim3(hn), dim3(1024), 0, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
-  if (bf) hipLaunchKernelGGL((i8_convert_kernel<__bf16>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((i8_convert_kernel<_Float16>), grid, dim3(256), 0, st, p);
+  if (bf) hipLaunchKernelGGL((i8_rows_kernel<__bf16, 0>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((i8_rows_kernel<_Float16, 0>), grid, dim3(256), 0, st, p);
+  e = hipGetLastError();
+  if (e != hipSuccess) return vorta_set_hip_error(e);
+  hipLaunchKernelGGL(i8_head_scale_kernel, dim3(hn), dim3(64), 0, st, p);
+  if (bf) hipLaunchKernelGGL((i8_rows_kernel<__bf16, 1>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((i8_rows_kernel<_Float16, 1>), grid, dim3(256), 0, st, p);
   e = hipGetLastError();
   if (e != hipSuccess) return vorta_set_hip_error(e);
   return VORTA_OK;

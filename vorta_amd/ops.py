@@ -95,25 +95,27 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
                variant: int = 0, tag: str = "", flops: float = 0.0,
                v_descale: Optional[torch.Tensor] = None, fp8_opts: Optional[dict] = None,
                q_block_table: Optional[torch.Tensor] = None, n_key_lists: int = 0,
-               k_scale: Optional[torch.Tensor] = None, q_smooth: Optional[torch.Tensor] = None):
+               i8: Optional["I8Operands"] = None):
     """Fill a vorta_attn_args; returns (args, workspace tensors to keep alive until the launch is enqueued).
     q,k,v of dtype uint8 = e4m3 operands from `fp8_quantize_qkv` (then `v_descale` is required and `out` is 16-bit):
     the args carry `_ext`, the vorta_attn_fp8_ext of the fp8 entry points.
-    k of dtype int8 = the rows of `i8_quantize_k` (then `k_scale` (heads, rows) and `q_smooth` (heads, D) are required, q and
-    out are 16-bit, v is e4m3): `_ext` is the vorta_attn_i8_ext of the int8-score entry points."""
+    k of dtype int8 = the rows of `i8_quantize_k` (then `i8` = its I8Operands, or views of them with k's geometry, is
+    required, q and out are 16-bit, v is e4m3): `_ext` is the vorta_attn_i8_ext of the int8-score entry points."""
     _require_gpu(q, k, v, out)
     fp8 = q.dtype == FP8_STORAGE
+    i8ops = i8
     i8 = (not fp8) and k.dtype == torch.int8  # int8 scores, e4m3 P V (csrc/attn_fwd_i8.hip)
     mixed = (not fp8) and (not i8) and v.dtype == FP8_STORAGE  # 16-bit scores, e4m3 P V (csrc/attn_fwd_mx.hip)
     if i8:
         if q.dtype not in _DT or q.dtype != out.dtype or v.dtype != FP8_STORAGE:
             raise ValueError("int8-score attention takes 16-bit q and out of one dtype, int8 k and e4m3 (uint8) v")
-        if k_scale is None or k_scale.dtype != torch.float32 or k_scale.dim() != 2 or k_scale.stride(1) != 1 \
-                or k_scale.shape[0] < k.shape[0] or k_scale.shape[1] < k.shape[1]:
-            raise ValueError("int8-score attention needs k_scale: float32 (heads, rows) with unit row stride (i8_quantize_k)")
-        if q_smooth is None or q_smooth.dtype != torch.float32 or q_smooth.dim() != 2 or q_smooth.shape[1] != q.shape[-1] \
-                or not q_smooth.is_contiguous():
-            raise ValueError("int8-score attention needs q_smooth: contiguous float32 (heads, D) from i8_quantize_k")
+        kb, qp, hs = (None, None, None) if i8ops is None else (i8ops.k_bias, i8ops.q_prep, i8ops.k_head_scale)
+        if kb is None or kb.dtype != torch.float32 or kb.dim() != 2 or kb.stride(1) != 1 or kb.shape[0] < k.shape[0] \
+                or kb.shape[1] < k.shape[1]:
+            raise ValueError("int8-score attention needs i8.k_bias: float32 (heads, rows) with unit row stride (i8_quantize_k)")
+        if qp is None or qp.dtype != torch.float32 or qp.dim() != 3 or tuple(qp.shape[1:]) != (2, q.shape[-1]) \
+                or not qp.is_contiguous() or hs is None or hs.dtype != torch.float32 or not hs.is_contiguous():
+            raise ValueError("int8-score attention needs i8.q_prep (heads, 2, D) and i8.k_head_scale (heads,) float32 from i8_quantize_k")
     if fp8:
         if not (k.dtype == v.dtype == FP8_STORAGE) or out.dtype not in _DT:
             raise ValueError("fp8 attention takes e4m3 (uint8) q,k,v and a bf16 / fp16 output")
@@ -137,8 +139,10 @@ def _attn_args(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Ten
     if i8:
         ext = _C.AttnI8Ext()
         ext.struct_size = C.sizeof(_C.AttnI8Ext)
-        ext.k_scale, ext.k_scale_stride_h = k_scale.data_ptr(), k_scale.stride(0)
-        ext.q_smooth, ext.q_smooth_stride_h = q_smooth.data_ptr(), q_smooth.stride(0)
+        ext.k_bias, ext.k_bias_stride_h = i8ops.k_bias.data_ptr(), i8ops.k_bias.stride(0)
+        ext.q_prep, ext.q_prep_stride_h = i8ops.q_prep.data_ptr(), i8ops.q_prep.stride(0)
+        ext.k_head_scale = i8ops.k_head_scale.data_ptr()
+        a._i8ops = i8ops  # (keeps the operand tensors alive until the launch is enqueued)
         ext.v_descale, ext.v_descale_stride_h = v_descale.data_ptr(), v_descale.stride(0)
         o = fp8_opts or FP8_OPTS
         ext.p_bias, ext.defer = float(o.get("p_bias", 0.0)), float(o.get("defer", 0.0))
@@ -488,25 +492,31 @@ def fp8_quantize_v(v: torch.Tensor, out: Optional[Tuple[torch.Tensor, torch.Tens
 
 
 class I8Operands:
-    """int8 keys of one layer for the int8-score attention: k8 (same geometry as k, int8), k_scale (one float per row),
-    q_smooth (heads, D): the channel multipliers the attention kernel applies to its query rows; ws: centre | 1 / smooth"""
-    __slots__ = ("k8", "k_scale", "q_smooth", "ws")
+    """int8 keys of one layer for the int8-score attention: k8 (same geometry as k, int8), k_bias (one float per row: the
+    query centre's product with the row, in units of the head's key scale), q_prep (heads, 2, D): centre and channel
+    multipliers the attention kernel applies to its query rows, k_head_scale (heads,), ws: key centre | 1 / multipliers | amax"""
+    __slots__ = ("k8", "k_bias", "q_prep", "k_head_scale", "ws")
 
-    def __init__(self, k8, k_scale, q_smooth, ws):
-        self.k8, self.k_scale, self.q_smooth, self.ws = k8, k_scale, q_smooth, ws
+    def __init__(self, k8, k_bias, q_prep, k_head_scale, ws):
+        self.k8, self.k_bias, self.q_prep, self.k_head_scale, self.ws = k8, k_bias, q_prep, k_head_scale, ws
 
     def k_center(self):
-        H, D = self.q_smooth.shape
+        H, _, D = self.q_prep.shape
         return self.ws[:H * D].view(H, D)
+
+    def heads(self, h0: int, h1: int, k8=None, k_bias=None) -> "I8Operands":
+        """the operands of heads [h0, h1) (views), optionally with other k8 / k_bias views of those heads"""
+        return I8Operands(self.k8[h0:h1] if k8 is None else k8, self.k_bias[h0:h1] if k_bias is None else k_bias,
+                          self.q_prep[h0:h1], self.k_head_scale[h0:h1], self.ws)
 
 
 def i8_quantize_k(q: torch.Tensor, k: torch.Tensor, *, out: Optional[I8Operands] = None, smooth: bool = True,
                   center: bool = True, heads: Optional[int] = None, seg_len: int = 0, tail_first: int = 0, tail_len: int = 0,
-                  slots: Optional[Tuple[int, int]] = None, video_tokens: int = 0) -> I8Operands:
-    """vorta_i8_quantize_k: (H,S,D) bf16 / fp16 views of q (sampled only) and k -> int8 keys with one scale per row, the
-    keys centred and the channel ranges of q and k balanced (include/vorta_hip.h).  `seg_len > 0`: (1,rows,D) row arrays in
-    the Ulysses receive layout, `heads` head slots, tail (text) rows from `tail_first`; `slots` = (first, end): only those
-    head slots.  `out` = a previous result to overwrite."""
+                  slots: Optional[Tuple[int, int]] = None) -> I8Operands:
+    """vorta_i8_quantize_k: (H,S,D) bf16 / fp16 views of q (sampled only) and k -> int8 keys (one scale per head), a float
+    bias per row, the heads' query centres and channel multipliers (include/vorta_hip.h).  `seg_len > 0`: (1,rows,D) row
+    arrays in the Ulysses receive layout, `heads` head slots, tail (text) rows from `tail_first`; `slots` = (first, end):
+    only those head slots.  `out` = a previous result to overwrite."""
     _require_gpu(q, k)
     if q.dtype not in _DT or q.dtype != k.dtype or q.shape != k.shape or q.dim() != 3:
         raise ValueError("i8_quantize_k takes (H,S,D) bf16 / fp16 views of q and k of equal shape")
@@ -523,16 +533,17 @@ def i8_quantize_k(q: torch.Tensor, k: torch.Tensor, *, out: Optional[I8Operands]
     if out is None:
         out = I8Operands(torch.empty((Hx, S, D), dtype=torch.int8, device=dev),
                          torch.empty((Hx, S), dtype=torch.float32, device=dev),
-                         torch.empty((H, D), dtype=torch.float32, device=dev),
-                         torch.empty(2 * H * D, dtype=torch.float32, device=dev))
+                         torch.empty((H, 2, D), dtype=torch.float32, device=dev),
+                         torch.empty((H,), dtype=torch.float32, device=dev),
+                         torch.empty(2 * H * D + H, dtype=torch.float32, device=dev))
     a = _C.I8QuantArgs()
     a.struct_size = C.sizeof(_C.I8QuantArgs)
     a.dtype, a.head_dim, a.heads, a.n_tokens = _DT[k.dtype], D, H, S
     a.q, a.k, a.k8 = _tensor(q), _tensor(k), _tensor(out.k8)
-    a.k_scale, a.k_scale_stride_h = out.k_scale.data_ptr(), out.k_scale.stride(0)
-    a.q_smooth, a.ws = out.q_smooth.data_ptr(), out.ws.data_ptr()
+    a.k_bias, a.k_bias_stride_h = out.k_bias.data_ptr(), out.k_bias.stride(0)
+    a.q_prep, a.k_head_scale, a.ws = out.q_prep.data_ptr(), out.k_head_scale.data_ptr(), out.ws.data_ptr()
     a.flags = (0 if smooth else 1) | (0 if center else 2)
-    a.seg_len, a.tail_first, a.tail_len, a.video_tokens = seg_len, tail_first, tail_len, video_tokens
+    a.seg_len, a.tail_first, a.tail_len = seg_len, tail_first, tail_len
     if slots is not None:
         if seg_len <= 0 or not (0 <= slots[0] < slots[1] <= H):
             raise ValueError(f"i8_quantize_k: slots {slots} need the segmented layout and 0 <= first < end <= {H}")

@@ -245,13 +245,14 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         fp8 = DEFAULT_FP8
     if fp8_views is not None:
         base = dict(q=fp8_views[0], k=fp8_views[1], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
-        if len(fp8_views) == 6:  # int8 keys: + their row scales and the heads' smoothing vectors
-            base.update(k_scale=fp8_views[4], q_smooth=fp8_views[5])
-    elif fp8 == "i8pv":  # int8 scores: k -> int8 rows (centred, smoothed, one scale per row), v -> e4m3; q is quantised by the kernel
+        if len(fp8_views) == 5:  # int8 keys: + their I8Operands (row biases, query preparation, head scales)
+            base.update(i8=fp8_views[4])
+    elif fp8 == "i8pv":  # int8 scores: k -> int8 rows (centred, balanced, one scale per head) + a float bias per row, v -> e4m3;
+        # q is centred, balanced and rounded by the attention kernel itself
         vo, ko = fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 2 else (None, None)
         v8, vd, _ = ops.fp8_quantize_v(v3, out=vo)
         i8 = ops.i8_quantize_k(q3, k3, out=ko)
-        base = dict(q=q3, k=i8.k8, v=v8, scale=scale, v_descale=vd, k_scale=i8.k_scale, q_smooth=i8.q_smooth)
+        base = dict(q=q3, k=i8.k8, v=v8, scale=scale, v_descale=vd, i8=i8)
     elif fp8 == "fp8pv":  # scores in 16 bits, P V in e4m3: only v is converted (exact per-channel abs-max, one pass + one)
         v8, vd, _ = ops.fp8_quantize_v(v3, out=fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 3 else None)
         base = dict(q=q3, k=k3, v=v8, scale=scale, v_descale=vd)

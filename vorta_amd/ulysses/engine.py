@@ -384,6 +384,27 @@ class UlyssesLayout:
         vd = f8.v_descale if vwire is None else vwire.descale(0, self.Hl)
         return hv(f8.q), hv(f8.k), hv(f8.v), vd, f8
 
+    def i8_operands(self) -> "ops.I8Operands":
+        """int8 key buffers of the receive layout for precision "i8pv" (allocated once per layout; `i8_views` fills them)"""
+        dev = self.device
+        return ops.I8Operands(torch.zeros((1, self.rows_total, self.D), dtype=torch.int8, device=dev),
+                              torch.zeros((1, self.rows_total), dtype=torch.float32, device=dev),
+                              torch.zeros((self.Hl, 2, self.D), dtype=torch.float32, device=dev),
+                              torch.ones((self.Hl,), dtype=torch.float32, device=dev),
+                              torch.zeros(2 * self.Hl * self.D + self.Hl, dtype=torch.float32, device=dev))
+
+    def i8_views(self, bufs: Sequence[torch.Tensor], out: "ops.I8Operands", slots: Optional[Sequence[int]] = None):
+        """int8 keys of the k receive buffer (q's is sampled for the statistics): ONE conversion of the buffer in the
+        quantiser's segmented row layout, every local head with its own centres, balance vector and scale; `slots` = (g0, g1):
+        only those head slots (the slot group that has landed).  Returns the I8Operands whose k8 / k_bias are head views."""
+        ops.i8_quantize_k(bufs[0].view(1, self.rows_total, self.D), bufs[1].view(1, self.rows_total, self.D), out=out,
+                          heads=self.Hl, seg_len=self.Sl, tail_first=self.rows_video, tail_len=self.T,
+                          slots=None if slots is None or tuple(slots) == (0, self.Hl) else tuple(slots))
+        rows = self.rows_total - (self.Hl - 1) * self.Sl
+        k8 = out.k8[0].as_strided((self.Hl, rows, self.D), (self.Sl * self.D, self.D, 1))
+        kb = out.k_bias[0].as_strided((self.Hl, rows), (self.Sl, 1))
+        return ops.I8Operands(k8, kb, out.q_prep, out.k_head_scale, out.ws)
+
     def head_view(self, buf: torch.Tensor) -> torch.Tensor:
         """(Hl, rows, D) overlapping view: head slot i starts i*Sl rows into the buffer."""
         return buf.as_strided((self.Hl, self.rows_total - (self.Hl - 1) * self.Sl, self.D),
@@ -679,10 +700,13 @@ class _RankState:
         if loopback:  # the chunks no peer will fill: finite values of the same distribution
             for b in self.bufs[:3]:
                 b.normal_()
-        self.f8 = self.vwire = None
-        if fp8 == "fp8pv":  # scores in 16 bits: only v is e4m3, converted on the send side (it always travels as bytes)
+        self.f8 = self.vwire = self.i8 = None
+        if fp8 in ("fp8pv", "i8pv"):  # only v is e4m3, converted on the send side (it always travels as bytes); "i8pv": k is
+            # rounded to int8 on this side, slot group by slot group (q by the attention kernel)
             if not v_wire:
-                raise ValueError("precision 'fp8pv' under sequence parallelism converts v on the send side (v_wire)")
+                raise ValueError(f"precision '{fp8}' under sequence parallelism converts v on the send side (v_wire)")
+            if fp8 == "i8pv":
+                self.i8 = lay.i8_operands()
             buf8 = torch.zeros((lay.rows_total, lay.D), dtype=torch.uint8, device=lay.device)
             if loopback:
                 buf8.random_(0, 120)
@@ -778,7 +802,11 @@ class UlyssesRoutedAttention:
 
         def attend(g0, g1, gi):
             views = None
-            if self.fp8 == "fp8pv":  # 16-bit q, k as they landed; v arrived as e4m3
+            if self.fp8 == "i8pv":  # k of the slot group that has landed -> int8; q as it landed; v arrived as e4m3
+                i8 = lay.i8_views(st.bufs, st.i8, slots=(g0, g1))
+                views = (q[g0:g1], i8.k8[g0:g1], lay.head_view(st.vwire.buf)[g0:g1], st.vwire.descale(g0, g1),
+                         i8.heads(g0, g1))
+            elif self.fp8 == "fp8pv":  # 16-bit q, k as they landed; v arrived as e4m3
                 views = (q[g0:g1], k[g0:g1], lay.head_view(st.vwire.buf)[g0:g1], st.vwire.descale(g0, g1))
             elif self.fp8:  # the slot group that has landed is converted while the next one is in flight
                 q8, k8, v8, vd, st.f8 = lay.fp8_views(st.bufs, out=st.f8, slots=(g0, g1), vwire=st.vwire)
