@@ -93,6 +93,27 @@ def test_wan_triple_eval_whole_call_golden(golden, tau):
     assert (err.max(-1) > 3e-2).mean() < 0.02
 
 
+def test_wan_triple_eval_batch_follows_item_zero_routes(golden):
+    """B > 1: the reference routes every batch item by item 0's scores (wan.py:388-416); here a batch is a loop over its
+    items with those routes -- equal to the items run one by one with item 0's score tensor"""
+    from vorta_amd.attention import WanAttnProcessorTripleEval
+    g = golden("g8_eval_calls")
+    dtype = torch.bfloat16
+    attn = _WanFakeAttn(g, dtype)
+    hidden = torch.tensor(g["wan_hidden"]).to(dtype).to(dev())
+    torch.manual_seed(3)
+    batch = torch.cat([hidden, (hidden.float() + 0.3 * torch.randn_like(hidden.float())).to(dtype)], dim=0)
+    score0 = torch.tensor(g["routing_score"]).to(dev())
+    score = torch.cat([score0, torch.softmax(torch.randn_like(score0), -1)], dim=0)  # item 1's own scores are ignored
+    proc = WanAttnProcessorTripleEval(check_input=True)
+    y = proc(attn, batch, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    assert y.shape[0] == 2
+    for b in range(2):
+        yb = proc(attn, batch[b:b + 1], None, None, None, tau_sparse=0.3, routing_score=score0, **_wan_kwargs())
+        # (the one-item call takes the fused qk-norm kernel, the batch the norm modules: bf16 rounding apart)
+        assert rel_fro(y[b:b + 1].float().cpu().numpy(), yb.float().cpu().numpy()) < 2e-2
+
+
 def test_wan_check_input_and_cross_attention(golden):
     from vorta_amd.attention import WanAttnProcessor2_0, WanAttnProcessorTripleEval
     g = golden("g8_eval_calls")

@@ -3,13 +3,11 @@
 set -e
 cd "$(dirname "$0")/../../vorta_amd/csrc"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -mllvm -enable-post-misched=0 -I../../include -I. -Wno-unused-result"
-OTHERS=$(ls *.o | grep -v '_' | grep -v '^attn_fwd_i8.o$' | tr '\n' ' ')
-OTHERS="$OTHERS attn_fwd_fp8.o attn_fwd_mx.o fp8_quant.o i8_quant.o sta_tables.o qk_norm_rope.o"
-OTHERS=$(echo $OTHERS | tr ' ' '\n' | sort -u | tr '\n' ' ')
+OTHERS="attn_fwd.o attn_fwd_fp8.o attn_fwd_mx.o fp8_quant.o i8_quant.o coreset.o sta_tables.o router.o qk_norm_rope.o mix.o permute.o"
 while [ $# -gt 1 ]; do
   n=$1; f=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $f -c attn_fwd_i8.hip -o attn_fwd_i8_v$n.o
   /opt/rocm/bin/hipcc $FLAGS $f -c api.hip -o api_v$n.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvorta_hip_$n.so attn_fwd_i8_v$n.o api_v$n.o $(echo $OTHERS | tr ' ' '\n' | grep -v '^api.o$' | tr '\n' ' ')
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvorta_hip_$n.so attn_fwd_i8_v$n.o api_v$n.o $OTHERS
   echo built libvorta_hip_$n.so "$f"
 done

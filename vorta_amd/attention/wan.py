@@ -154,20 +154,25 @@ class WanAttnProcessorTripleEval(WanAttnProcessor2_0):
                                                 rotary_emb)
         self._check_input(hidden_states, lowres_group_info, latent_shape, window_size, tile_size)
         q, k, v, _ = self._input_proj(attn, hidden_states, None, rotary_emb)
-        assert q.shape[0] == 1, "routed attention runs one batch item per call (pipeline_wan.py:322-344 does CFG as two)"
+        B = q.shape[0]
+        # the reference routes EVERY batch item by item 0's scores (wan.py:388-416: `routing_score[0].topk(1)`); the kernels
+        # take one item per launch, so a batch is a loop over its items with the same routes (the scripts run B = 1:
+        # pipeline_wan.py:322-344 does CFG as two forwards)
         if SP_STATE.enabled:
             from ._sp import sp_attention
-            buf = sp_attention(q, k, v, 0, routing_score, tau_sparse, model="wan", lowres_group_info=lowres_group_info,
-                               window_size=window_size, tile_size=tile_size, latent_shape=latent_shape,
-                               experts_host=experts_host)
-            return self._output_proj(attn, buf)
+            bufs = [sp_attention(q[b:b + 1], k[b:b + 1], v[b:b + 1], 0, routing_score, tau_sparse, model="wan",
+                                 lowres_group_info=lowres_group_info, window_size=window_size, tile_size=tile_size,
+                                 latent_shape=latent_shape, experts_host=experts_host) for b in range(B)]
+            return self._output_proj(attn, bufs[0] if B == 1 else torch.cat(bufs, dim=0))
         if head_routing is None:
             _, lists, counts = torch.ops.vorta.route_scores(routing_score, float(tau_sparse))
             head_routing = HeadRouting.from_device(lists, counts)
         buf, out = self._new_out(q)
-        torch.ops.vorta.routed_attention(q, k, v, out, **_torch_ops.routing_args(head_routing),
-                                         **_torch_ops.geometry_args(lowres_group_info, window_size, tile_size, latent_shape),
-                                         model="wan")
+        for b in range(B):
+            torch.ops.vorta.routed_attention(q[b:b + 1], k[b:b + 1], v[b:b + 1], out[b:b + 1],
+                                             **_torch_ops.routing_args(head_routing),
+                                             **_torch_ops.geometry_args(lowres_group_info, window_size, tile_size,
+                                                                        latent_shape), model="wan")
         return self._output_proj(attn, buf)
 
 

@@ -334,27 +334,35 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #define VORTA_I8_SCHED 1
 #endif
 #ifndef VORTA_I8_SC_VALU
-#define VORTA_I8_SC_VALU 8
+#define VORTA_I8_SC_VALU 4
 #endif
 #ifndef VORTA_I8_PV_VALU
-#define VORTA_I8_PV_VALU 17
+#define VORTA_I8_PV_VALU 14
 #endif
 #if VORTA_I8_SCHED == 1
-  // score phase: the 8 seed reads, then 8 MFMAs, each with its K fragment read and an eighth of the 64 byte conversions;
-  // P V phase: 5 MFMAs, each with four transposed V reads and a fifth of the 64 multiply-adds + the row max + the seeds
+  // Every fragment read is issued well ahead of the MFMA that consumes it (left to itself the compiler reads each K
+  // fragment into ONE register set right before its MFMA: eight exposed LDS round trips per step).  DS reads in program
+  // order: 8 seed reads, 8 K fragments, 16 transposed V reads, the bias read.  Score phase: the seeds and the first four
+  // K fragments up front; then per MFMA one more read (the remaining K fragments, then the V fragments of channel tiles 0 and
+  // 1) and an eighth of the 32 byte conversions.  P V phase: per MFMA the V reads of the tile two ahead and a quarter of the
+  // multiply-adds / row max / seed arithmetic; the bias read rides with the first, the seed write follows the VALU work.
+#define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
 #define SCHED_RECIPE()                                                            \
-  __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                              \
-  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, VORTA_I8_SC_VALU, 0);             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-  }                                                                               \
-  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, VORTA_I8_PV_VALU, 0);             \
-  }                                                                               \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  SG_(0x100, 12)                                                                  \
+  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, VORTA_I8_PV_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, VORTA_I8_PV_VALU)                        \
+  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_PV_VALU)                        \
+  SG_(0x008, 1) SG_(0x002, VORTA_I8_PV_VALU)                                      \
+  SG_(0x200, 1)                                                                   \
+  SG_(0x008, 1)
 #else
 #define SCHED_RECIPE()
 #endif
