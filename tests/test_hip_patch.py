@@ -548,19 +548,20 @@ def test_train_router_patch_runs_the_soft_mixture_forward():
                                                lowres_window_size=GROUP, lowres_reduction_rate=0.5), dev())
     assert "tau_sparse" not in kw
     calls = []
-    stock = hy.soft_mixture_attention
+    import vorta_amd.routed as rt  # the processors go through torch.ops.vorta.soft_mixture_attention, which lands here
+    stock = rt.soft_mixture_attention
 
     def rec(q, k, v, scores, geom, **k2):
         out = stock(q, k, v, scores, geom, **k2)
         calls.append((q.detach().clone(), k.detach().clone(), v.detach().clone(), scores.detach().clone(), out.detach().clone(), k2))
         return out
 
-    hy.soft_mixture_attention = rec
+    rt.soft_mixture_attention = rec
     try:
         with torch.no_grad():
             out = model(**_hy_inputs(), return_dict=False, self_attention_kwargs=kw, return_routing_scores=True)
     finally:
-        hy.soft_mixture_attention = stock
+        rt.soft_mixture_attention = stock
     assert len(out) == 5 and len(calls) == 4 and torch.isfinite(out[0].float()).all()
     gi = O.group_info(LATENT, GROUP, 0.5)
     for layer, (q, k, v, sc, o, k2) in enumerate(calls):

@@ -501,6 +501,9 @@ def _sp_worker_fp8(rank, world, port, ret):
     vorta_amd.set_attention_precision("fp8pv")  # scores in 16 bits, P V in e4m3
     fullpv = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
     fullpv2 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
+    vorta_amd.set_attention_precision("i8pv")  # scores in int8, P V in e4m3
+    fulli8 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    fulli8_2 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
     vorta_amd.set_attention_precision("fp8")
     SP_STATE.setup_sp_group(world)
     rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
@@ -524,6 +527,14 @@ def _sp_worker_fp8(rank, world, port, ret):
         part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
         ref = fl[:, rank * Sl:(rank + 1) * Sl].float()
         res[("fp8pv", groups, placement)] = (float((part.float() - ref).abs().max()), rel(ref, nt))
+    vorta_amd.set_attention_precision("i8pv")  # k -> int8 on the receive side, slot group by slot group; q in the kernel
+    for groups, placement in ((1, "even"), (2, "even"), (2, "uneven")):
+        _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = groups, True, placement
+        _sp._LAYOUTS.clear(); _sp._BUFFERS.clear()
+        sc, fl, nt = (score2, fulli8_2, nat2) if placement == "uneven" else (score, fulli8, nat)
+        part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
+        ref = fl[:, rank * Sl:(rank + 1) * Sl].float()
+        res[("i8pv", groups, placement)] = (float((part.float() - ref).abs().max()), rel(ref, nt))
     vorta_amd.set_attention_precision("native")
     _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = 1, True, "uneven"
     ret[rank] = res
@@ -536,7 +547,8 @@ def test_processor_under_sequence_parallel_rehearsal_fp8():
     layout with the per-head abs-max and the key centre (the mean of the same TOKENS) of the single-process call, so the
     result is bit-identical to it -- with the local heads converted in one go or slot group by slot group (2 + 1 and
     1 + 1 + 1 of the 3 local heads), with v converted on the send side and exchanged as e4m3 or exchanged in 16 bits, and
-    with the ranks holding equal or different numbers of heads."""
+    with the ranks holding equal or different numbers of heads.  The same for "fp8pv" and for "i8pv" (int8 keys made on the
+    receive side per slot group, queries rounded by the kernel's waves: the same waves over the same lists)."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -544,7 +556,7 @@ def test_processor_under_sequence_parallel_rehearsal_fp8():
     ret = mp.Manager().dict()
     mp.spawn(_sp_worker_fp8, args=(2, port, ret), nprocs=2, join=True)
     for r in (0, 1):
-        assert len(ret[r]) == 15
+        assert len(ret[r]) == 18
         for key, (d, one) in ret[r].items():
             assert d == 0.0 and 0.0 < one < 0.1, (key, dict(ret[r]))
 
