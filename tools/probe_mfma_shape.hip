@@ -128,7 +128,10 @@ __global__ __launch_bounds__(512) void bare(long long* out, int iters) {
 // workgroup) or 16 KiB (DMA = 2: what a 512-row workgroup would stream per FLOP) of 256-byte rows from `src` (consecutive rows
 // of a `src_rows`-row region, a different region per workgroup) by LDS-DMA into a ring behind the tiles the fragments read;
 // s_waitcnt vmcnt(0) before the step's barrier, as in the product.
-template <typename T, int MODE, int VALU, int DMA = 0>
+// PAIR (part E: where does the stream's per-step cost sit?)  1: the requests as before, but one vmcnt(0) + barrier per TWO key
+// blocks (a 128-key step);  2: the same with both blocks' requests issued together at the top of the pair;  3: a barrier per
+// block as in the product, but waiting only for the PREVIOUS block's requests (vmcnt(4): a ring one deeper).
+template <typename T, int MODE, int VALU, int DMA = 0, int PAIR = 0>
 __global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters, const char* src = nullptr, int src_rows = 0) {
   using V8 = typename M<T>::v8;
   using V4 = typename M<T>::v4;
@@ -138,15 +141,15 @@ __global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters, c
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7fffffff, 0x00020000);
   int dma_row = (int)((blockIdx.x * 7919u) % (unsigned)(src_rows > 0 ? src_rows : 1));
 #define PROBE_DMA(slot_)                                                                                        \
-  if (DMA) {                                                                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < (DMA == 1 ? 4 : 2); ++i_) {                                        \
-      const int row_ = dma_row + 4 * (4 * wave + i_) + ((threadIdx.x & 63) >> 4);                               \
+  if (DMA && (PAIR != 2 || (slot_) == 0)) {                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < (DMA == 1 ? 4 : 2) * (PAIR == 2 ? 2 : 1); ++i_) {                   \
+      const int row_ = dma_row + 4 * (4 * wave + (i_ & 3)) + ((threadIdx.x & 63) >> 4) + 128 * (i_ >> 2);       \
       const int off_ = (int)__umul24((unsigned)(row_ < src_rows ? row_ : row_ - src_rows), 256u) +              \
                        ((((threadIdx.x & 15) ^ (row_ & 15))) << 4);                                             \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)(smem + (2 + 2 * (slot_)) * TILE + (4 * wave + i_) * 1024), \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_AS void*)(smem + (2 + 2 * (slot_) + 2 * (i_ >> 2)) * TILE + (4 * wave + (i_ & 3)) * 1024), \
                                                16, off_, 0, 0, 0);                                              \
     }                                                                                                           \
-    dma_row += 128;                                                                                             \
+    dma_row += PAIR == 2 ? 256 : 128;                                                                           \
     if (dma_row >= src_rows) dma_row -= src_rows;                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                          \
   }
@@ -240,7 +243,8 @@ __global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters, c
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    \
       }                                                                                                          \
     }                                                                                                            \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                     \
+    if (PAIR == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");                     \
+    else if (PAIR == 0 || (kslot_) == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
   }
     V8 vf_;
     _Pragma("unroll") for (int i = 0; i < 8; ++i) vf_[i] = (T)0.f;
@@ -396,6 +400,17 @@ void all(long long* d, int parts) {
            MODE == 0 ? "1 KiB LDS/MFMA" : "0.5 KiB LDS/MFMA", DMA == 1 ? 32 : 16, WHERE);                                  \
   run(lab, d, G, 2.0 * 32 * 64 * 128 * 2 * 2, 2.0, 12000, [&](int it) {                                                    \
     hipLaunchKernelGGL((attn_like<T, MODE, 1, DMA>), dim3(G), dim3(512), 0, 0, d, it, (const char*)g_src, ROWS); });
+#define ATTE(PAIR, WHAT)                                                                                                   \
+  snprintf(lab, sizeof lab, "%s step 1 KiB LDS/MFMA + 32 KiB K/V stream per block (L2 hits), %s", M<T>::name(), WHAT);      \
+  run(lab, d, G, 2.0 * 32 * 64 * 128 * 2 * 2, 2.0, 12000, [&](int it) {                                                    \
+    hipLaunchKernelGGL((attn_like<T, 0, 1, 1, PAIR>), dim3(G), dim3(512), 0, 0, d, it, (const char*)g_src, 8192); });
+  if (parts & 16) {
+    ATT(0, 1)
+    ATTE(0, "vmcnt(0) + barrier per block (the product)")
+    ATTE(1, "vmcnt(0) + barrier per TWO blocks")
+    ATTE(2, "the same, both blocks' requests issued together")
+    ATTE(3, "barrier per block, waiting for the previous block's requests only")
+  }
   if (parts & 8) {
     ATT(0, 1)
     ATTD(0, 1, 8192, "2 MiB region: L2 hits")
