@@ -530,17 +530,20 @@ def main():
     # workload: `traffic` = bytes leaving the L2s (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md 'HBM'); the Infinity
     # Cache sits behind that interface, the memory controllers' own activity (tools/umc_activity.py) gives the DRAM side
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))
-        wl = pmc["workloads"].get(f"{args.config} {args.mix} {cfg['dtype']}")
+        wl, pmc_file = None, None
+        for pmc_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest table that holds this workload
+            if os.path.exists(os.path.join(ROOT, "profiles", pmc_file)):
+                wl = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["workloads"].get(
+                    f"{args.config} {args.mix} {cfg['dtype']}")
+                if wl is not None:
+                    break
         if wl is not None and world == 1 and not emu and proc_info is None:
-            mangled = {"attn_fwd_multi_kernel": "attn_fwd_multi_kernel", "attn8_multi_kernel": "attn8_multi_kernel",
-                       "attn_fwd_pipe_kernel": "attn_fwd_pipe_kernel", "attn8_kernel": "attn8_kernel"}
             base = dom_sym.split("<")[0]
-            hit = [v for k_, v in wl["kernels"].items() if mangled.get(base, base) in k_]
+            hit = [v for k_, v in wl["kernels"].items() if base in k_]
             if len(hit) == 1:
                 roofline["traffic"] = hit[0]["l2_miss_bytes_per_launch"]
                 roofline["traffic_unit"] = ("bytes per launch leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE, "
-                                            "profiles/r03_pmc_traffic.json)")
+                                            f"profiles/{pmc_file})")
                 roofline["traffic_over_minimum"] = round(hit[0]["l2_miss_bytes_per_launch"] /
                                                          wl["algorithmic_min_bytes_per_fused_launch"], 2)
         umc = os.path.join(ROOT, "profiles", f"r03_umc_activity_{args.config}_{cfg['dtype']}.json")

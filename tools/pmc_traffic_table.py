@@ -44,7 +44,7 @@ def main():
         cfg_name, mix, dt = os.path.basename(d).rsplit("_", 2)
         cfg = B.CONFIGS[cfg_name]
         S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
-        esz_in = 1 if dt == "fp8" else 2
+        esz_in = 1 if dt in ("fp8", "i8pv") else 2  # fp8pv: q, k 16-bit, v e4m3 (counted as 16-bit: an upper minimum)
         # the attention launch reads q,k,v (e4m3 copies under fp8) and writes a 16-bit output
         minimum = (S + cfg["text"]) * cfg["heads"] * 128 * (3 * esz_in + 2)
         fetch, write = kernel_sums(os.path.join(d, "FETCH_SIZE")), kernel_sums(os.path.join(d, "WRITE_SIZE"))
@@ -61,8 +61,8 @@ def main():
         table[f"{cfg_name} {mix} {dt}"] = {"kernels": kernels, "algorithmic_min_bytes_per_fused_launch": minimum}
     out = {"what": "bytes leaving the L2s (TCC -> EA requests: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024) per launch of the "
                    "attention kernels; the Infinity Cache sits BEHIND this interface (its hits are counted here), the "
-                   "DRAM-side estimate is profiles/r03_umc_activity_*.json",
-           "source": "tools/measure_r3_pmc.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, no trace "
+                   "DRAM-side estimate is profiles/r0N_umc_activity_*.json",
+           "source": "tools/measure/r4_round.sh (round 3: measure_r3_pmc.sh): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, no trace "
                      "domains, python3 bench.py --config C --mix M --dtype D --steps 1 --warmup 0",
            "workloads": table}
     json.dump(out, open(a.json, "w"), indent=1)
