@@ -274,15 +274,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
 #ifndef VORTA_RING
 // K/V ring depth of the 8-wave kernels: 2 = one step of DMA latency cover (64 KiB LDS), 3 = two steps (96 KiB).
 // Measured equal (1216 vs 1217 TFLOP/s, S=32 760 H=12 bf16, same box): the end-of-step vmcnt wait is not where
-// the loop stalls, so the smaller ring stays.
+// the loop stalls.  4 = PAIRED steps (128 KiB): the tile requests of TWO key blocks leave in one burst at the top of every
+// second step and one vmcnt(0) + barrier closes the pair -- the stream's cost is per burst, not per request or byte
+// (profiles/r04_probe_mfma_shape_energy.txt part E).
 #define VORTA_RING 2
 #endif
+
+// lane 16 g + n of `v` to every lane of row g (v_mov_b32_dpp row_newbcast:n)
+template <int N>
+__device__ __forceinline__ int row_bcast(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false);
+}
 
 template <typename T, int NW, bool KVTAB, int NS>
 __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __restrict__ smem, const int wg) {
   // NS = depth of the K and of the V tile rings (NS * 32 KiB of LDS): K(j+NS) / V(j+NS-1) are requested at the
   // top of step j, NS-1 steps before the step that reads them
-  static_assert(NS == 2 || NS == 3, "ring depth");
+  static_assert(NS == 2 || NS == 3 || NS == 4, "ring depth");
+  constexpr bool PAIR = NS == 4;
 #ifdef VORTA_TRACE
   const long long tr_e0_ = wall_clock64();  // workgroup entry, absolute (100 MHz)
 #endif
@@ -381,6 +390,36 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #define DMA_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
       v_rsrc, (LDS_AS void*)(smem + (NS + (par_)) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                     \
       (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
+  // Paired steps keep the rows of up to four key blocks in ONE register: lane 16 g + n, n = CH b + i, holds the row of key
+  // position 64 (blk + b) + 4 (CH wave + i) + g -- what piece i of block blk + b fetches for its sub-row g -- and a request
+  // reads its row with a row broadcast (one table load per pair instead of CH per step, and CH*2 - 1 registers fewer).
+  int pack = 0;
+  const int pk_off = ((lane & 15) / CH) * KVB + 4 * (CH * wave + ((lane & 15) % CH)) + (lane >> 4);
+#define PACK_OF(blk_)                                                             \
+  {                                                                               \
+    const int pos_ = min((blk_) * KVB + pk_off, n_kv - 1);                        \
+    if constexpr (KVTAB) pack = kv_rows[pos_];                                    \
+    else pack = p.kv_row_offset + pos_;                                           \
+  }
+#define DMA_PIECE(rsrc_, lds_, ss_, col_, b_, i_)                                 \
+  if constexpr ((i_) < CH) __builtin_amdgcn_raw_ptr_buffer_load_lds(              \
+      rsrc_, (LDS_AS void*)((lds_) + (CH * wave + (i_)) * 1024), 16,              \
+      (int)__umul24((unsigned)row_bcast<(CH * (b_) + (i_)) & 15>(pack), (unsigned)(ss_)) + col_[(i_) < CH ? (i_) : 0], 0, 0, 0);
+#define DMA_TILE(rsrc_, lds_, ss_, col_, b_)                                      \
+  DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 0) DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 1) \
+  DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 2) DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 3)
+#define DMA_K_P(slot_, b_) DMA_TILE(k_rsrc, smem + (slot_) * TILE_BYTES, k_ss32, k_col, b_)
+#define DMA_V_P(slot_, b_) DMA_TILE(v_rsrc, smem + (NS + (slot_)) * TILE_BYTES, v_ss32, v_col, b_)
+  // top of a pair whose first block j has ring slot s_ (0 or 2): `pack` holds the rows of blocks j+2, j+3, j+4.  V(j+2),
+  // K(j+3), V(j+3), K(j+4) go to the slots V(j-2), K(j-1), V(j-1), K(j) left during the previous pair; they are read in
+  // the NEXT pair, after the barrier that closes this one.  Then the pack of the next pair (blocks j+4 ...) is requested.
+#define STAGE_PAIR(s_, j_)                                                        \
+  DMA_V_P(((s_) + 2) & 3, 0)                                                      \
+  DMA_K_P(((s_) + 3) & 3, 1)                                                      \
+  DMA_V_P(((s_) + 3) & 3, 1)                                                      \
+  DMA_K_P((s_), 2)                                                                \
+  PACK_OF((j_) + 4)                                                               \
+  __builtin_amdgcn_sched_barrier(0);
 
   // ---- LDS read addresses ----
   int k_rd[8];
@@ -500,7 +539,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #else
 #define STEP_SYNC()                                                               \
   {                                                                               \
-    if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    if constexpr (NS == 2 || NS == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
     else if constexpr (CH == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
     else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
   }
@@ -538,6 +577,11 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, vfree_, j_)                       \
   { /* kcur_ = j % NS: slot of K(j) (free) and of V(j); knext_ = (j+1) % NS; vfree_ = (j-1) % NS */ \
     STAGE_DMA(kcur_, vfree_, j_)                                                  \
+    STEP_BODY(c0_, c1_, n0_, n1_, kcur_, knext_, j_)                              \
+    STEP_SYNC()                                                                   \
+  }
+#define STEP_BODY(c0_, c1_, n0_, n1_, kcur_, knext_, j_)                          \
+  {                                                                               \
     if (wave_active) {                                                            \
       V8 kpre_[KPRE > 0 ? KPRE : 1][2];                                                          \
       _Pragma("unroll") for (int ks_ = 0; ks_ < KPRE; ++ks_) {                    \
@@ -588,10 +632,20 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       ROW_MAX_POS(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */ \
       SCHED_RECIPE()                                                              \
     }                                                                             \
-    STEP_SYNC()                                                                   \
   }
 
   if (blk0 < blk1) {
+    if constexpr (PAIR) {
+      // prologue: K(0), K(1), K(2), V(0), V(1) -> their ring slots; then the pack of the first pair (blocks 2, 3, 4)
+      PACK_OF(blk0)
+      DMA_K_P(0, 0)
+      DMA_V_P(0, 0)
+      DMA_K_P(1, 1)
+      DMA_V_P(1, 1)
+      DMA_K_P(2, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      PACK_OF(blk0 + 2)
+    } else {
     // prologue: K(0..NS-1) and V(0..NS-2) -> their ring slots; then rowK = rows(NS), rowV = rows(NS-1)
     ROWS_OF(rowK, blk0)
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
@@ -607,6 +661,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     }
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     ROWS_OF(rowK, blk0 + NS)
+    }
     __syncthreads();
     if (wave_active) {
       QK(sA0, sA1, 0)  // seed 0: plain scores of the first block
@@ -629,7 +684,23 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     }
     __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
   }
-  if constexpr (NS == 2) {
+  if constexpr (PAIR) {
+    // ring slots cycle with period 4; the requests of two blocks per burst, one vmcnt(0) + barrier per pair
+    for (int blk = blk0; blk < blk1; blk += 4) {
+      STAGE_PAIR(0, blk)
+      STEP_BODY(sA0, sA1, sB0, sB1, 0, 1, blk)
+      if (blk + 1 >= blk1) break;
+      STEP_BODY(sB0, sB1, sA0, sA1, 1, 2, blk + 1)
+      STEP_SYNC()
+      if (blk + 2 >= blk1) break;
+      STAGE_PAIR(2, blk + 2)
+      STEP_BODY(sA0, sA1, sB0, sB1, 2, 3, blk + 2)
+      if (blk + 3 >= blk1) break;
+      STEP_BODY(sB0, sB1, sA0, sA1, 3, 0, blk + 3)
+      STEP_SYNC()
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a loop left in mid-pair still has its burst in flight
+  } else if constexpr (NS == 2) {
     for (int blk = blk0; blk < blk1; blk += 2) {
       STEP(sA0, sA1, sB0, sB1, 0, 1, 1, blk)
       if (blk + 1 >= blk1) break;
@@ -656,11 +727,18 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #undef ROW_MAX_POS
 #undef RAISE_REF
 #undef STEP
+#undef STEP_BODY
 #undef STAGE_DMA
+#undef STAGE_PAIR
 #undef STEP_SYNC
 #undef ROWS_OF
+#undef PACK_OF
 #undef DMA_K
 #undef DMA_V
+#undef DMA_PIECE
+#undef DMA_TILE
+#undef DMA_K_P
+#undef DMA_V_P
 
 #ifdef VORTA_TRACE
   if (p.n_splits == 1 && p.ws_ml && lane == 0) {

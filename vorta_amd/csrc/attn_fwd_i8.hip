@@ -22,10 +22,13 @@
 // every wave turns the block's 64 float biases (LDS-DMA'd with the K tile, one step further ahead) into integers with three
 // VALU instructions, parks them in a private 256-byte LDS slot and reads them back as the accumulators' initial values.
 //
-// Structure otherwise: the mixed kernel (attn_fwd_mx.hip) -- K tile int8 rows of 128 bytes (8 KiB, the e4m3 kernels' image),
-// scores one key block ahead, V tile e4m3 through ds_read_b64_tr_b8, O^T += V8^T P'^T on v_mfma_f32_32x32x64_f8f6f4, row sums
-// from the ones-tile MFMA, deferred rescale, v_descale in the epilogue.  Per wave and 64-key block: 8 MFMAs of 32 cycles + 5
-// of 64 = 576 pipe cycles (1 024 in 16 bits, 832 mixed, 576 all-e4m3).
+// Structure otherwise: K tile int8 rows of 128 bytes (8 KiB, the e4m3 kernels' image), V tile e4m3 through ds_read_b64_tr_b8,
+// O^T += V8^T P'^T on v_mfma_f32_32x32x64_f8f6f4, row sums from the ones-tile MFMA, deferred rescale, v_descale in the
+// epilogue; the loop is the e4m3 kernel's (attn_fwd_fp8.hip): the two waves of a SIMD take turns between a matrix part (13
+// MFMAs: per wave and 64-key block 8 of 32 cycles + 5 of 64 = 576 pipe cycles; 1 024 in 16 bits, 832 mixed, 576 all-e4m3)
+// and a VALU part.  What bounds it is the SIMD's vector issue: ~92 VALU instructions of ~5.4 cycles and 13 MFMA issues of 8
+// per wave and block, two waves = ~1 200 cycles of issue beside 1 152 of matrix pipe, plus the tile requests (~90 cycles
+// of the issuing wave each, wherever they stand) and the barrier: tools/trace_i8.py measures ~1 600 cycles per block.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -44,10 +47,11 @@ typedef __attribute__((ext_vector_type(16))) int i32x16;
 
 constexpr int ROWB8 = D;             // bytes per e4m3 row
 constexpr int TILE8 = KVB * ROWB8;   // 8 KiB
-constexpr int NSI8 = 2;              // ring depth of the K and V tiles (8 KiB each) and of the key-bias tiles (256 B)
+constexpr int NSI8 = 2;              // (template tag of the body; the rings are the constants below)
+constexpr int K_SLOTS_I8 = 2, V_SLOTS_I8 = 3, B_SLOTS_I8 = 3;  // K / V tile rings (8 KiB tiles), key-bias ring (256-B tiles)
 constexpr int SC_BYTES = KVB * 4;    // one float per key of a block
 constexpr int SEED_BYTES = 8 * 2 * SC_BYTES;  // per wave two slots of 64 int32 seeds
-constexpr int SMEM_I8 = NSI8 * (2 * TILE8 + SC_BYTES) + SEED_BYTES;  // 36.5 KiB
+constexpr int SMEM_I8 = (K_SLOTS_I8 + V_SLOTS_I8) * TILE8 + B_SLOTS_I8 * SC_BYTES + SEED_BYTES;  // 44.75 KiB
 constexpr int MAGIC_I = 0x4B400000;  // float bits of 1.5 * 2^23 = 12 582 912
 constexpr float MAGIC_F = 12582912.f;
 constexpr float SEED_LIMIT = 2000000.f;  // |q8 . k8| <= 2 064 512; the sum must stay below 2^22
@@ -76,14 +80,13 @@ __device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
 
 template <typename T, int NW, bool KVTAB, int NS>
 __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restrict__ smem, const int wg) {
-  // NS = depth of the K / V rings: K(j+NS) / V(j+NS-1) are requested at the top of step j, NS-1 steps before the step that
-  // reads them; the bias tile of K(j+NS+1) is requested with K(j+NS) (its seeds are made one step before its scores).
-  // LDS: K ring [0, NS*8K), V ring behind it, bias ring behind that, the waves' seed slots last.
-  static_assert(NS == 2, "ring depth");
+  // LDS: K ring (2 tiles) at 0, V ring (3 tiles) behind it, the bias ring (3 tiles of 64 floats) behind that, the waves'
+  // seed slots (two of 64 int32 per wave) last.  One workgroup barrier per key block.
+  static_assert(NS == 2, "body tag");
   const Params& p = pp.p;
-  constexpr int VBASE = NS * TILE8;
-  constexpr int BBASE = 2 * NS * TILE8;
-  constexpr int SEEDBASE = BBASE + NS * SC_BYTES;
+  constexpr int VBASE = K_SLOTS_I8 * TILE8;
+  constexpr int BBASE = (K_SLOTS_I8 + V_SLOTS_I8) * TILE8;
+  constexpr int SEEDBASE = BBASE + B_SLOTS_I8 * SC_BYTES;
   using V8 = typename MF<T>::v8;
   using V4 = typename MF<T>::v4;
   constexpr int QB = NW * 32;
@@ -149,6 +152,9 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     inv_q = am > 0.f ? 127.f / am : 0.f;
     const float sq = am > 0.f ? am * (1.f / 127.f) : 1.f;
     m8 = 8.f * ((sq * p.scale_log2) * pp.k_head_scale[head]);
+    // both are the same in every lane of the wave: keep them in scalar registers (the loop runs at the VGPR budget)
+    m8 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m8)));
+    inv_q = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(inv_q)));
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -197,14 +203,30 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     if constexpr (KVTAB) rowB = kv_rows[pos_];                                    \
     else rowB = p.kv_row_offset + pos_;                                           \
   }
-#define DMA_K(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(     \
-      k_rsrc, (LDS_AS void*)(smem + (par_) * TILE8 + (CH * wave + i_) * 1024), 16,                                  \
+  // in the loop the key positions are running values (one add per step); written as (block index) * 64 + ... the six
+  // unrolled steps keep six hoisted position registers each
+  int posK[CH], posB = 0;
+#define ROWS_NEXT()                                                               \
+  {                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                           \
+      posK[i_] += KVB;                                                            \
+      const int pos_ = min(posK[i_], n_kv - 1);                                   \
+      if constexpr (KVTAB) rowK[i_] = kv_rows[pos_];                              \
+      else rowK[i_] = p.kv_row_offset + pos_;                                     \
+    }                                                                             \
+    posB += KVB;                                                                  \
+    const int posb_ = min(posB, n_kv - 1);                                        \
+    if constexpr (KVTAB) rowB = kv_rows[posb_];                                   \
+    else rowB = p.kv_row_offset + posb_;                                          \
+  }
+#define DMA_K(slot_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(    \
+      k_rsrc, (LDS_AS void*)(smem + (slot_) * TILE8 + (CH * wave + i_) * 1024), 16,                                 \
       (int)__umul24((unsigned)rowK[i_], (unsigned)k_ss32) + k_col[i_], 0, 0, 0);
-#define DMA_B(par_)                                                                                                 \
-  if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (LDS_AS void*)(smem + BBASE + (par_) * SC_BYTES), 4, \
+#define DMA_B(slot_)                                                                                                \
+  if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (LDS_AS void*)(smem + BBASE + (slot_) * SC_BYTES), 4, \
                                                           rowB * 4, 0, 0, 0);
-#define DMA_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(     \
-      v_rsrc, (LDS_AS void*)(smem + VBASE + (par_) * TILE8 + (CH * wave + i_) * 1024), 16,                          \
+#define DMA_V(slot_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(    \
+      v_rsrc, (LDS_AS void*)(smem + VBASE + (slot_) * TILE8 + (CH * wave + i_) * 1024), 16,                         \
       (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
 
   // ---- LDS read addresses ----
@@ -242,16 +264,19 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = 0x22222222;
   asm volatile("" : "+v"(ones));
-  i32x8 pb_;  // bytes of the probabilities of the current block (B operand of the PV MFMAs)
+  // bytes of the probabilities (B operand of the PV MFMAs): two buffers, the matrix part of step j reads the one of block j-1
+  // while its score half fills the other with block j
+  i32x8 pbA_, pbB_;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) pb_[i] = 0;
+  for (int i = 0; i < 8; ++i) { pbA_[i] = 0; pbB_[i] = 0; }
   // Online softmax in the BYTE domain y = 8 x + 56, x = log2 P' = z - m_run + p_bias.  m_run8 = 8 x the reference point of
-  // this row (a lower bound of its running max, at most thr - p_bias below it); y0, y1 hold y of the current block.
+  // this row (a lower bound of its running max, at most thr - p_bias below it).
   float m_run8 = -1e30f;
   const float ybias = 8.f * pp.p_bias + 56.f, ythr = 8.f * pp.thr + 56.f;
-  f32x16 y0, y1;          // byte-domain scores of the current key block (keys 0-31, 32-63 of the block)
+  f32x16 y0, y1;          // byte-domain scores of one key block (keys 0-31, 32-63 of the block)
+  i32x16 n0, n1;          // raw accumulators of the block after it (written by the matrix part)
   float off8 = 0.f;       // ybias - m_run8 - MAGIC_F * m8: the addend of the conversion
-  float mx_cur = -1e30f;  // row max of the current block's y
+  float mx_cur = -1e30f;  // row max of y
 
   // seeds of a block from its bias tile (slot bslot_) into this wave's seed slot sslot_: three VALU instructions per wave
 #define MAKE_SEEDS(bslot_, sslot_)                                                \
@@ -260,27 +285,31 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     const float s_ = __builtin_amdgcn_fmed3f(b_ * inv_q, -SEED_LIMIT, SEED_LIMIT); \
     *(int*)(smem + seed_wr + (sslot_) * SC_BYTES) = MAGIC_I + (int)__builtin_rintf(s_); \
   }
-  // raw scores of a block (K ring slot par_) on top of its seeds (seed slot sslot_): int32 bits = float 1.5 2^23 + score
-#define QK(d0_, d1_, par_, sslot_)                                                \
-  {                                                                               \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                            \
-      const i32x4 s0_ = *(const i32x4*)(smem + seed_rd + (sslot_) * SC_BYTES + 32 * j_);        \
-      const i32x4 s1_ = *(const i32x4*)(smem + seed_rd + (sslot_) * SC_BYTES + 128 + 32 * j_);  \
-      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { d0_[4 * j_ + e_] = s0_[e_]; d1_[4 * j_ + e_] = s1_[e_]; } \
-    }                                                                             \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                         \
-      const i32x4 k0_ = *(const i32x4*)(smem + (par_) * TILE8 + k_rd[ks_]);       \
-      const i32x4 k1_ = *(const i32x4*)(smem + (par_) * TILE8 + k_rd[ks_] + 32 * ROWB8); \
-      d0_ = mfma_i8(k0_, qf[ks_], d0_);                                           \
-      d1_ = mfma_i8(k1_, qf[ks_], d1_);                                           \
-    }                                                                             \
+  // the seeds of key tile t_ (0, 1) of a block (seed slot sslot_) as an accumulator's initial value: int32 bits = float
+  // 1.5 2^23 + seed
+#define SEEDS_IN(d_, sslot_, t_)                                                  \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                              \
+    const i32x4 s_ = *(const i32x4*)(smem + seed_rd + (sslot_) * SC_BYTES + 128 * (t_) + 32 * j_); \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) d_[4 * j_ + e_] = s_[e_];    \
   }
+  // K fragments of key tile t_ (0, 1) of ring slot slot_
+#define KFRAGS(dst_, slot_, t_)                                                   \
+  _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                             \
+    dst_[ks_] = *(const i32x4*)(smem + (slot_) * TILE8 + (t_) * 32 * ROWB8 + k_rd[ks_]);
+#define QK_TILE(d_, kf_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) d_ = mfma_i8(kf_[ks_], qf[ks_], d_);
   // int32 bits read as floats -> byte-domain scores: y = (1.5 2^23 + score) m8 + off_  (one fused multiply-add per score)
 #define TO_Y(yd0_, yd1_, a0_, a1_, off_)                                          \
-  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                             \
-    yd0_[i_] = __builtin_fmaf(__int_as_float(a0_[i_]), m8, off_);                 \
-    yd1_[i_] = __builtin_fmaf(__int_as_float(a1_[i_]), m8, off_);                 \
+  {                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) yd0_[i_] = __builtin_fmaf(__int_as_float(a0_[i_]), m8, off_); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) yd1_[i_] = __builtin_fmaf(__int_as_float(a1_[i_]), m8, off_); \
   }
+  // P' bytes straight from y: rint, saturating at 0 (-inf of masked keys -> 0); y <= 8 thr + 56 = 120 < 0x7E
+#define PACK_Y(pb_)                                                               \
+  _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_)                                \
+    _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                            \
+      pb_[w_] = __builtin_amdgcn_cvt_pk_u8_f32(y0[4 * w_ + b_], b_, pb_[w_]);     \
+      pb_[4 + w_] = __builtin_amdgcn_cvt_pk_u8_f32(y1[4 * w_ + b_], b_, pb_[4 + w_]); \
+    }
 #define ROW_MAX(dst_, a_, b_)                                                      \
   {                                                                               \
     float mx_ = a_[0];                                                            \
@@ -288,9 +317,9 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, b_[i_]);   \
     dst_ = half_max(mx_);                                                         \
   }
-  // The loop only asks two things of the NEXT block's row max: "is it above `ythr` (> 0)?" and, if so, its value.  Both
-  // are answered by a signed-integer max over the float bit patterns (order-preserving for non-negative floats, any
-  // negative result reads as "not above"; there are no NaNs).
+  // The loop only asks two things of a block's row max: "is it above `ythr` (> 0)?" and, if so, its value.  Both are
+  // answered by a signed-integer max over the float bit patterns (order-preserving for non-negative floats, any negative
+  // result reads as "not above"; there are no NaNs).
 #define ROW_MAX_POS(dst_, a_, b_)                                                  \
   {                                                                               \
     int m0_ = max(max(__float_as_int(a_[0]), __float_as_int(a_[1])), __float_as_int(a_[2])); \
@@ -304,6 +333,165 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m0_, false, false); \
     dst_ = __int_as_float(max((int)r_[0], (int)r_[1]));                           \
   }
+  // (the empty asm makes the lane term a value of THIS step: otherwise the 16 sums lane term + register row are hoisted out
+  // of the loop into 16 registers for a branch taken once per workgroup)
+#define MASK_TAIL(jabs_)                                                          \
+  {                                                                               \
+    int h4_ = 4 * hh;                                                             \
+    asm volatile("" : "+v"(h4_));                                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+      const int row_ = (i_ & 3) + 8 * (i_ >> 2) + h4_;                            \
+      if ((jabs_) * KVB + row_ >= n_kv) y0[i_] = -INFINITY;                       \
+      if ((jabs_) * KVB + 32 + row_ >= n_kv) y1[i_] = -INFINITY;                  \
+    }                                                                             \
+  }
+#define VFRAG(dt_, slot_)                                                         \
+  _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                              \
+    const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                      \
+        (LDS_AS i32x2*)(smem + (slot_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8));   \
+    vf_[dt_][2 * n_] = t_[0]; vf_[dt_][2 * n_ + 1] = t_[1];                       \
+  }
+  // requests of step j: K(j+2) into the slot K(j) left, V(j+1) into the slot V(j-2) left, the bias tile of K(j+3) into the slot
+  // the bias of K(j) left (its last reader made the seeds of K(j) one step ago); all are read after this step's barrier
+#define STAGE_DMA(kw_, vw_, bw_, jabs_)                                           \
+  DMA_K(kw_)                                                                      \
+  DMA_V(vw_)                                                                      \
+  DMA_B(bw_)                                                                      \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
+  ROWS_NEXT() /* the rows of K(j+3) and of the bias tile of K(j+4) */             \
+  __builtin_amdgcn_sched_barrier(0);
+#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // The two waves of a SIMD (wave w and w + NW/2 of the workgroup) take turns on its pipes, as in attn_fwd_fp8.hip: while
+  // one runs its matrix part -- 13 MFMAs back to back: O += V^T P'^T and the row sums of one block (5 x 64 cycles), the raw
+  // scores of a later one (8 x 32) -- the other runs its VALU part -- the 32 byte conversions of a block, the 32
+  // multiply-adds and the row max of the next, the seeds of a later one (~85 instructions).  (With both waves in the same
+  // part at the same time -- the first build of this kernel -- the MFMA pipe was 55 % busy at 2.0 GHz and removing ALL
+  // MFMAs shortened the step by only 23 %: profiles/r04_i8_ablation.txt.)
+  //   step j, role X (waves < NW/2) :  matrix(j)  then  valu: y / max of block j+1, seeds of block j+2
+  //   step j, role Y (waves >= NW/2):  valu: y / max of block j, seeds of block j+1   then  matrix(j)
+  //   matrix(j) = PV(j-1) + row sums, [mask the tail of block j], [move the reference point for block j], QK(j+1) with the
+  //               byte conversions of block j in its MFMA gaps
+  // Both roles see the same reference points and run the same barriers.  kr_ / vr_: K / V slots read (K(j+1), V(j-1));
+  // sr_: seed slot of block j+1;  (bs_, ss_): bias and seed slot of the block whose seeds the VALU part makes.
+  // the VALU part issues, first thing, the LDS read whose round trip would otherwise be exposed at its end: the bias tile
+  // entry of its seed arithmetic.  (Reading the V fragments of channel tiles 0, 1 of the NEXT matrix part here as well --
+  // 16 registers carried across the barrier by role X -- spills ~40 registers at this budget; the matrix part hides most
+  // of that round trip under the row-sum MFMA instead, which needs no fragment.)
+  // The wave's tile requests are spread over the VALU part (qa_, qb_, qc_: the K piece, the V piece, the bias piece + the
+  // next rows): back to back at the top of the step they cost the wave ~100 cycles each -- every wave of the workgroup
+  // asks at the same moment and the address unit takes 16 pieces per step, 16 cycles apiece -- with VALU work between
+  // them the queue has drained when the next one comes (tools/trace_i8.py: 176-208 cycles per step for the requests).
+#define VALU_PART(bs_, ss_, qa_, qb_, qc_)                                        \
+  {                                                                               \
+    const float sb_ = *(const float*)(smem + bias_rd + (bs_) * SC_BYTES);         \
+    qa_                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, off8); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    qb_                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, off8); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    qc_                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    ROW_MAX_POS(mx_cur, y0, y1)                                                   \
+    {                                                                             \
+      const float s_ = __builtin_amdgcn_fmed3f(sb_ * inv_q, -SEED_LIMIT, SEED_LIMIT); \
+      *(int*)(smem + seed_wr + (ss_) * SC_BYTES) = MAGIC_I + (int)__builtin_rintf(s_); \
+    }                                                                             \
+  }
+#define ROWS_UPDATE()                                                             \
+  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
+  ROWS_NEXT()
+#define REQ_TAIL(bw_)                                                             \
+  DMA_B(bw_)                                                                      \
+  ROWS_UPDATE()
+#ifndef VORTA_I8_SCHED
+#define VORTA_I8_SCHED 1
+#endif
+// 1: the K and V tile pieces of the 8-wave kernels are requested INSIDE the matrix part, one behind the row-sum MFMA and one
+// two MFMAs later: the wave issues in order and a request holds it ~90 cycles wherever it stands -- behind an MFMA 64 of
+// them run under that MFMA, in the VALU part all of them are the wave's own (0: in the VALU part)
+#ifndef VORTA_I8_REQ_M
+#define VORTA_I8_REQ_M 0
+#endif
+  // an empty, NON-volatile asm over two values: a data dependence and nothing else (reads stay free to move) -- orders the MFMAs
+  // that produce / consume them where the recipe's greedy pick would not
+#define TIE_(a_, b_) asm("" : "+v"(a_), "+v"(b_));
+#if VORTA_I8_SCHED == 1
+  // Issue-order recipe of the PV half of the matrix part (sched_group_barrier: 0x008 MFMA, 0x100 DS read): the reads of V
+  // channel tiles 0, 1, then 5 MFMAs -- the row-sum MFMA FIRST: it needs no fragment and covers 64 cycles of the tiles'
+  // round trip -- with the later reads under the earlier ones: V tiles 2, 3, the seeds and the K fragments of key tile 0,
+  // so that the score half starts with its operands in registers.
+#define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
+#define SCHED_M()                                                                 \
+  SG_(0x100, 8)                                                                   \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1)
+  // score half (a basic block of its own behind the rare branches): the eight reads of key tile 1 under the four MFMAs of
+  // tile 0 (whose operands are in registers: the wave goes from the branch straight into an MFMA), then tile 1; per MFMA
+  // four of the 32 byte conversions of block j (the 24 issue cycles a 32-cycle MFMA leaves: the VALU part is that much
+  // shorter)
+#ifndef VORTA_I8_SCHED_S
+#define VORTA_I8_SCHED_S 1
+#endif
+#if VORTA_I8_SCHED_S == 1
+#define SCHED_S()                                                                 \
+  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) \
+  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) \
+  SG_(0x008, 1) SG_(0x002, 4) SG_(0x008, 1) SG_(0x002, 4) SG_(0x008, 1) SG_(0x002, 4) SG_(0x008, 1) SG_(0x002, 4)
+#else
+#define SCHED_S() SG_(0x100, 8) SG_(0x008, 8)
+#endif
+#else
+#define SCHED_M()
+#define SCHED_S()
+#endif
+#ifndef VORTA_I8_PRIO
+#define VORTA_I8_PRIO 1  /* s_setprio around the matrix part (the partner wave is in its VALU part then) */
+#endif
+#if VORTA_I8_PRIO == 1
+#define PRIO_HI() __builtin_amdgcn_s_setprio(2);
+#define PRIO_LO() __builtin_amdgcn_s_setprio(0);
+#else
+#define PRIO_HI()
+#define PRIO_LO()
+#endif
+  // qa_ / qb_: a tile request behind the row-sum MFMA / behind the second P V MFMA (tied to their results, so that the
+  // recipe cannot issue both together)
+#define PV_PART(vr_, pb_, qa_, qb_, mid_)                                         \
+  i32x8 vf_[4];                                                                   \
+  VFRAG(0, vr_) VFRAG(1, vr_) VFRAG(2, vr_) VFRAG(3, vr_)                         \
+  lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pb_, lacc, 4, 0, 0, 0, 0, 0); \
+  TIE_(lacc, vf_[0]) /* the row-sum MFMA before the first that needs a fragment */ \
+  qa_                                                                             \
+  mid_ /* the score half's first reads: in the source between the two requests, whose volatile ties order memory operations */ \
+  o[0] = mfma8(vf_[0], pb_, o[0]);                                                \
+  TIE_(o[0], vf_[1])                                                              \
+  o[1] = mfma8(vf_[1], pb_, o[1]);                                                \
+  qb_                                                                             \
+  o[2] = mfma8(vf_[2], pb_, o[2]);                                                \
+  TIE_(o[2], vf_[3])                                                              \
+  o[3] = mfma8(vf_[3], pb_, o[3]);
+#define REQ_K_TIED(slot_, t_, a_)                                                 \
+  {                                                                               \
+    static_assert(CH == 1, "one piece per wave");                                 \
+    int off_ = (int)__umul24((unsigned)rowK[0], (unsigned)k_ss32) + k_col[0];     \
+    TIE_(t_, off_)                                                                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (LDS_AS void*)(smem + (slot_) * TILE8 + wave * 1024), 16, off_, 0, 0, 0); \
+    asm volatile("" : "+v"(a_)); /* ... and what consumes a_ behind it */         \
+  }
+#define REQ_V_TIED(slot_, t_, a_)                                                 \
+  {                                                                               \
+    int off_ = (int)__umul24((unsigned)rowV[0], (unsigned)v_ss32) + v_col[0];     \
+    TIE_(t_, off_)                                                                \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (LDS_AS void*)(smem + VBASE + (slot_) * TILE8 + wave * 1024), 16, off_, 0, 0, 0); \
+    asm volatile("" : "+v"(a_));                                                  \
+  }
   // move the reference point of the row up by g8_ (>= 0, byte-domain units = 8 x log2): everything accumulated so far and
   // the current block's y are brought to the new reference
 #define RAISE_REF(g8_)                                                            \
@@ -316,141 +504,179 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     off8 -= (g8_);                                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { y0[i_] -= (g8_); y1[i_] -= (g8_); } \
   }
-  // top of step j: K(j+NS) -> the slot K(j) left, the bias tile of K(j+NS+1) -> the slot the bias of K(j+NS-1) left (its seeds
-  // were made in step j-1), V(j+NS-1) -> the slot V(j-1) left
-#define STAGE_DMA(kfree_, vfree_, j_)                                             \
-  DMA_K(kfree_)                                                                   \
-  DMA_B(vfree_)                                                                   \
-  DMA_V(vfree_)                                                                   \
-  ROWS_OF(rowV, (j_) + NS)                                                        \
-  ROWS_OF(rowK, (j_) + NS + 1)                                                    \
-  ROW_OF_B((j_) + NS + 2)                                                         \
-  __builtin_amdgcn_sched_barrier(0);
-#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-  // Issue-order recipe for the step's basic block (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x200 DS write, 0x002
-  // VALU); -DVORTA_I8_SCHED=0 leaves the order to the compiler.
-#ifndef VORTA_I8_SCHED
-#define VORTA_I8_SCHED 1
+#define MATRIX_PART(kr_, vr_, sr_, pbr_, pbw_, jabs_, qa_, qb_)                   \
+  {                                                                               \
+    PRIO_HI()                                                                     \
+    i32x4 kfa_[4], kfb_[4];                                                       \
+    PV_PART(vr_, pbr_, qa_, qb_, SEEDS_IN(n0, sr_, 0) KFRAGS(kfa_, kr_, 0))       \
+    SCHED_M()                                                                     \
+    /* last, partial key block: mask its tail, exact row max (once per workgroup) */ \
+    if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(jabs_) ROW_MAX(mx_cur, y0, y1) }  \
+    /* deferred rescale: the reference point moves only when some row of the wave outgrew it by more than `thr - p_bias`; */ \
+    /* O and the row sums follow AFTER block j-1 went in at the old reference                                            */ \
+    if (!__all(mx_cur <= ythr)) {                                                 \
+      const float g8_ = fmaxf(mx_cur - ybias, 0.f);                               \
+      RAISE_REF(g8_)                                                              \
+    }                                                                             \
+    SEEDS_IN(n1, sr_, 1) /* key tile 1: its seeds and fragments fly under the four MFMAs of tile 0 */ \
+    KFRAGS(kfb_, kr_, 1)                                                          \
+    QK_TILE(n0, kfa_)                                                             \
+    TIE_(n0, n1) /* tile 0 (operands in registers) before tile 1 (operands in flight) */ \
+    QK_TILE(n1, kfb_)                                                             \
+    PACK_Y(pbw_) /* the bytes of block j (its reference point is final now): four conversions per MFMA gap */ \
+    TIE_(n1, pbw_) /* (keeps the conversions in this block: nothing reads them before the next step) */ \
+    SCHED_S()                                                                     \
+    PRIO_LO()                                                                     \
+  }
+  // Timing ablations (suffixed diagnostic libraries only; each removes one ingredient of the step and gives WRONG RESULTS;
+  // tools/measure/r4_i8_ablation.sh, profiles/r04_i8_ablation.txt)
+#ifdef VORTA_I8_DIAG_NOSYNC
+#undef STEP_SYNC
+#define STEP_SYNC() asm volatile("" ::: "memory");
 #endif
-#ifndef VORTA_I8_SC_VALU
-#define VORTA_I8_SC_VALU 4
+#ifdef VORTA_I8_DIAG_NOBAR
+#undef STEP_SYNC
+#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
-#ifndef VORTA_I8_PV_VALU
-#define VORTA_I8_PV_VALU 14
+#ifdef VORTA_I8_DIAG_NODMA
+#undef STAGE_DMA
+#define STAGE_DMA(kw_, vw_, bw_, jabs_)
+#undef DMA_K
+#define DMA_K(slot_)
+#undef DMA_V
+#define DMA_V(slot_)
+#undef REQ_TAIL
+#undef ROWS_UPDATE
+#define REQ_TAIL(bw_)
 #endif
-#if VORTA_I8_SCHED == 1
-  // Every fragment read is issued well ahead of the MFMA that consumes it (left to itself the compiler reads each K
-  // fragment into ONE register set right before its MFMA: eight exposed LDS round trips per step).  DS reads in program
-  // order: 8 seed reads, 8 K fragments, 16 transposed V reads, the bias read.  Score phase: the seeds and the first four
-  // K fragments up front; then per MFMA one more read (the remaining K fragments, then the V fragments of channel tiles 0 and
-  // 1) and an eighth of the 32 byte conversions.  P V phase: per MFMA the V reads of the tile two ahead and a quarter of the
-  // multiply-adds / row max / seed arithmetic; the bias read rides with the first, the seed write follows the VALU work.
-#define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
-#define SCHED_RECIPE()                                                            \
-  SG_(0x100, 12)                                                                  \
-  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, VORTA_I8_SC_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, VORTA_I8_PV_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, VORTA_I8_PV_VALU)                        \
-  SG_(0x008, 1) SG_(0x100, 1) SG_(0x002, VORTA_I8_PV_VALU)                        \
-  SG_(0x008, 1) SG_(0x002, VORTA_I8_PV_VALU)                                      \
-  SG_(0x200, 1)                                                                   \
-  SG_(0x008, 1)
+#ifdef VORTA_I8_DIAG_NOSEED
+#undef MAKE_SEEDS
+#define MAKE_SEEDS(bslot_, sslot_)
+#endif
+#ifdef VORTA_I8_DIAG_NOVALU
+#undef VALU_PART
+#undef REQ_TAIL
+#undef ROWS_UPDATE
+#define VALU_PART(bs_, ss_, qa_, qb_, qc_) qa_ qb_ qc_ asm volatile("" : "+v"(y0), "+v"(y1) : "v"(n0), "v"(n1));
+#undef PACK_Y
+#define PACK_Y(pb_) asm volatile("" : "+v"(pb_) : "v"(y0), "v"(y1));
+#endif
+#ifdef VORTA_I8_DIAG_NOLDS
+#undef SEEDS_IN
+#define SEEDS_IN(d_, sslot_, t_) _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) d_[e_] = MAGIC_I;
+#undef KFRAGS
+#define KFRAGS(dst_, slot_, t_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) dst_[ks_] = qf[ks_ ^ (t_)];
+#undef VFRAG
+#define VFRAG(dt_, slot_) vf_[dt_] = pbA_;
+#endif
+#ifdef VORTA_I8_DIAG_NOMFMA
+#define mfma_i8(a_, b_, c_) ([&]() { i32x16 r_ = (c_); asm volatile("" : "+v"(r_) : "v"(a_), "v"(b_)); return r_; }())
+#define mfma8(a_, b_, c_) ([&]() { f32x16 r_ = (c_); asm volatile("" : "+v"(r_) : "v"(a_), "v"(b_)); return r_; }())
+#endif
+  // -DVORTA_TRACE_I8=i (diagnostic libraries, tools/trace_i8.py; one interval per build): shader cycles between stamps i-1
+  // and i of every step, summed per wave, go to ws_ml of an unsplit launch; results stay correct.
+  //   0 step start | 1 after the requests at the top (role Y's) | 2 before the matrix part | 3 after it | 4 after the requests
+  //   behind it (role X's) | 5 before the end-of-step wait | 6 before the barrier | 7 after
+#ifdef VORTA_TRACE_I8
+  unsigned tr_sum_ = 0, tr_t0_ = 0;
+#define TR_(i_)                                                                   \
+  if constexpr ((i_) == VORTA_TRACE_I8 - 1) {                                     \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    tr_t0_ = (unsigned)__builtin_readcyclecounter();                              \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  } else if constexpr ((i_) == VORTA_TRACE_I8) {                                  \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    tr_sum_ += (unsigned)__builtin_readcyclecounter() - tr_t0_;                   \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+  }
+#undef STEP_SYNC
+#define STEP_SYNC()                                                               \
+  {                                                                               \
+    TR_(5)                                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
+    TR_(6)                                                                        \
+    asm volatile("s_barrier" ::: "memory");                                       \
+    TR_(7)                                                                        \
+  }
+#define TR_FLUSH_()                                                               \
+  if (p.n_splits == 1 && p.ws_ml && lane == 0) {                                  \
+    unsigned* tr = (unsigned*)p.ws_ml + ((int64_t)wg * NW + wave) * 2;            \
+    tr[0] = tr_sum_; tr[1] = (unsigned)(nsteps - 1);                              \
+  }
 #else
-#define SCHED_RECIPE()
+#define TR_(i_)
+#define TR_FLUSH_()
 #endif
-  // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches.
-#define STEP(kcur_, knext_, vfree_, j_)                                           \
-  { /* kcur_ = j % NS: slot of K(j) (free), of V(j) and of the seeds of block j+2; knext_ = (j+1) % NS: K(j+1), its seeds and */ \
-    /* the bias tile of K(j+2); vfree_ = (j-1) % NS */                            \
-    STAGE_DMA(kcur_, vfree_, j_)                                                  \
+#ifdef VORTA_I8_DIAG_ALLX  /* every wave in the first role (no ping-pong) */
+#define ROLE_Y_ false
+#else
+#define ROLE_Y_ (NW == 8 && wave >= NW / 2)
+#endif
+  // both roles request their tile pieces inside their VALU part (role X behind its matrix part: it goes from the barrier
+  // straight into its MFMAs); the 4-wave kernels (no roles) and waves past the query rows request at the top of the step
+#define STEP(kw_, kr_, vw_, vr_, bw_, sr_, bsx_, ssx_, bsy_, ssy_, pbr_, pbw_, jabs_) \
+  {                                                                               \
+    TR_(0)                                                                        \
+    if (!wave_active || NW != 8) { STAGE_DMA(kw_, vw_, bw_, jabs_) }              \
+    TR_(1)                                                                        \
     if (wave_active) {                                                            \
-      /* mx_cur (row max of this block's y) was computed under the previous step's PV MFMAs; only the last, partial key */ \
-      /* block has to mask its tail and redo it here                                                                   */ \
-      if ((j_) * KVB + KVB > n_kv) {                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
-          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
-          if ((j_) * KVB + row_ >= n_kv) y0[i_] = -INFINITY;                      \
-          if ((j_) * KVB + 32 + row_ >= n_kv) y1[i_] = -INFINITY;                 \
-        }                                                                         \
-        ROW_MAX(mx_cur, y0, y1)                                                   \
+      if (NW == 8 && role_y) { /* (role Y's rows move on behind its matrix part, which holds its K and V requests) */ \
+        if (VORTA_I8_REQ_M) VALU_PART(bsy_, ssy_, , , DMA_B(bw_))                 \
+        else VALU_PART(bsy_, ssy_, DMA_K(kw_), DMA_V(vw_), REQ_TAIL(bw_))         \
       }                                                                           \
-      /* deferred rescale: the reference point moves only when some row of the wave outgrew it by more than */ \
-      /* `thr - p_bias` (so P' <= 2^thr: inside e4m3's range); rows that did not grow keep theirs (g = 0)      */ \
-      if (!__all(mx_cur <= ythr)) {                                               \
-        const float g8_ = fmaxf(mx_cur - ybias, 0.f);                             \
-        RAISE_REF(g8_)                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      TR_(2)                                                                      \
+      if constexpr (NW == 8 && VORTA_I8_REQ_M) MATRIX_PART(kr_, vr_, sr_, pbr_, pbw_, jabs_, REQ_K_TIED(kw_, lacc, vf_[0]), REQ_V_TIED(vw_, o[1], vf_[2])) \
+      else MATRIX_PART(kr_, vr_, sr_, pbr_, pbw_, jabs_, , )                      \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      TR_(3)                                                                      \
+      if (NW == 8 && VORTA_I8_REQ_M && role_y) { ROWS_UPDATE() }                  \
+      TR_(4)                                                                      \
+      if (NW == 8 && !role_y) {                                                   \
+        if (VORTA_I8_REQ_M) VALU_PART(bsx_, ssx_, , , REQ_TAIL(bw_))              \
+        else VALU_PART(bsx_, ssx_, DMA_K(kw_), DMA_V(vw_), REQ_TAIL(bw_))         \
       }                                                                           \
-      i32x16 n0_, n1_;                                                            \
-      QK(n0_, n1_, knext_, knext_) /* block j+1 (harmless garbage past the end) */ \
-      /* P' bytes straight from y: rint, saturating at 0 (-inf of masked keys -> 0); y <= 8 thr + 56 = 120 < 0x7E */ \
-      _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_)                            \
-        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                        \
-          pb_[w_] = __builtin_amdgcn_cvt_pk_u8_f32(y0[4 * w_ + b_], b_, pb_[w_]); \
-          pb_[4 + w_] = __builtin_amdgcn_cvt_pk_u8_f32(y1[4 * w_ + b_], b_, pb_[4 + w_]); \
-        }                                                                         \
-      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
-        i32x8 vf_;                                                                \
-        _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                        \
-          const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                \
-              (LDS_AS i32x2*)(smem + (kcur_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8)); \
-          vf_[2 * n_] = t_[0]; vf_[2 * n_ + 1] = t_[1];                           \
-        }                                                                         \
-        o[dt_] = mfma8(vf_, pb_, o[dt_]);                                         \
-      }                                                                           \
-      lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pb_, lacc, 4, 0, 0, 0, 0, 0); \
-      /* block j+1: bits -> byte-domain floats and their row max; block j+2: seeds.  VALU work under the PV MFMAs above */ \
-      TO_Y(y0, y1, n0_, n1_, off8)                                                \
-      ROW_MAX_POS(mx_cur, y0, y1)                                                 \
-      MAKE_SEEDS(kcur_, kcur_) /* block j+2: its bias tile and its seed slot have the parity of j */ \
-      SCHED_RECIPE()                                                              \
+      if (NW != 8) VALU_PART(bsx_, ssx_, , , )                                    \
     }                                                                             \
     STEP_SYNC()                                                                   \
   }
 
-  if (blk0 < blk1) {
-    // prologue: K(0..NS-1), the bias tiles of K(0), K(1) (and of K(2) once K(0)'s seeds exist), V(0..NS-2)
+  const int nsteps = blk1 - blk0;
+  const bool role_y = ROLE_Y_;  // wave-uniform
+  if (nsteps > 0) {
+    // ---- prologue: K(0), V(0), K(1) and the bias tiles of K(0), K(1), K(2); the scores of block 0 fix the reference point ----
     ROWS_OF(rowK, blk0)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     ROW_OF_B(blk0)
-    ROWS_OF(rowV, blk0)
     DMA_K(0)
-    DMA_B(0)
     DMA_V(0)
+    DMA_B(0)
     ROWS_OF(rowK, blk0 + 1)
     ROW_OF_B(blk0 + 1)
     DMA_K(1)
     DMA_B(1)
-    ROWS_OF(rowV, blk0 + NS - 1)
-    ROWS_OF(rowK, blk0 + NS)
-    ROW_OF_B(blk0 + NS)
+    ROW_OF_B(blk0 + 2)
+    DMA_B(2)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
+    ROWS_OF(rowK, blk0 + 2)
+    ROW_OF_B(blk0 + 3)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) posK[i_] = (blk0 + 2) * KVB + 8 * (CH * wave + i_) + (lane >> 3);
+    posB = (blk0 + 3) * KVB + lane;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave_active) {
       MAKE_SEEDS(0, 0)
       MAKE_SEEDS(1, 1)
-    }
-    __syncthreads();  // every wave has read the bias tiles of K(0), K(1): the bias of K(2) may land in slot 0
-    DMA_B(0)
-    ROW_OF_B(blk0 + NS + 1)
-    if (wave_active) {
-      i32x16 n0, n1;
-      QK(n0, n1, 0, 0)
+      i32x4 kfa[4], kfb[4];
+      SEEDS_IN(n0, 0, 0)
+      SEEDS_IN(n1, 0, 1)
+      KFRAGS(kfa, 0, 0)
+      KFRAGS(kfb, 0, 1)
+      QK_TILE(n0, kfa)
+      QK_TILE(n1, kfb)
       const float base = -MAGIC_F * m8;
       TO_Y(y0, y1, n0, n1, base)  // 8 x the plain exp2-domain scores of the first block
-      if (blk0 * KVB + KVB > n_kv) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (blk0 * KVB + row >= n_kv) y0[i] = -INFINITY;
-          if (blk0 * KVB + 32 + row >= n_kv) y1[i] = -INFINITY;
-        }
-      }
+      if (blk0 * KVB + KVB > n_kv) { MASK_TAIL(blk0) }
       ROW_MAX(mx_cur, y0, y1)
       // the first block fixes the reference point at its true row max (block blk0 always has a valid key);
       // O and l are still zero, so nothing is rescaled
@@ -461,23 +687,79 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
       for (int i = 0; i < 16; ++i) { y0[i] += shift; y1[i] += shift; }
       mx_cur = ybias;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // K(0) read by every wave; bias of K(2) landed
+    __syncthreads();  // every wave has read K(0) and the bias tile of K(0) before their slots are overwritten
+    {  // step 0: no PV yet -- the scores of block 1, then (role X) the VALU part of block 0
+      STAGE_DMA(0, 1, 0, blk0)
+      if (wave_active) {
+        i32x4 kfa[4], kfb[4];
+        SEEDS_IN(n0, 1, 0)
+        SEEDS_IN(n1, 1, 1)
+        KFRAGS(kfa, 1, 0)
+        KFRAGS(kfb, 1, 1)
+        QK_TILE(n0, kfa)
+        QK_TILE(n1, kfb)
+        PACK_Y(pbA_)  // the bytes of block 0
+        __builtin_amdgcn_sched_barrier(0);
+        if (!role_y) VALU_PART(2, 0, , , )
+      }
+      STEP_SYNC()
+    }
+    // K and seed slots cycle with period 2, V and bias slots with period 3: unrolled by 6.  Step j: K(j+2) -> slot j % 2,
+    // K(j+1) read from (j+1) % 2; V(j+1) -> (j+1) % 3, V(j-1) read from (j-1) % 3; bias(j+3) -> j % 3; seeds of block j+1
+    // read from (j+1) % 2; role X makes the seeds of block j+2 (bias slot (j+2) % 3, seed slot j % 2) and reads the head of
+    // V(j) (slot j % 3), role Y the seeds of block j+1 (bias slot (j+1) % 3, seed slot (j+1) % 2) and the head of V(j-1)
+    for (int jj = 1; jj < nsteps; jj += 6) {
+      STEP(1, 0, 2, 0, 1, 0, 0, 1, 2, 0, pbA_, pbB_, blk0 + jj)
+      if (jj + 1 >= nsteps) break;
+      STEP(0, 1, 0, 1, 2, 1, 1, 0, 0, 1, pbB_, pbA_, blk0 + jj + 1)
+      if (jj + 2 >= nsteps) break;
+      STEP(1, 0, 1, 2, 0, 0, 2, 1, 1, 0, pbA_, pbB_, blk0 + jj + 2)
+      if (jj + 3 >= nsteps) break;
+      STEP(0, 1, 2, 0, 1, 1, 0, 0, 2, 1, pbB_, pbA_, blk0 + jj + 3)
+      if (jj + 4 >= nsteps) break;
+      STEP(1, 0, 0, 1, 2, 0, 1, 1, 0, 0, pbA_, pbB_, blk0 + jj + 4)
+      if (jj + 5 >= nsteps) break;
+      STEP(0, 1, 1, 2, 0, 1, 2, 0, 1, 1, pbB_, pbA_, blk0 + jj + 5)
+    }
+    // ---- drain: PV of the last block ----
+    if (wave_active) {
+      const int vs = (nsteps - 1) % V_SLOTS_I8;
+      if ((nsteps - 1) & 1) pbA_ = pbB_;  // the bytes of the last block
+      PV_PART(vs, pbA_, , , )
+    }
   }
-  for (int blk = blk0; blk < blk1; blk += 2) {
-    STEP(0, 1, 1, blk)
-    if (blk + 1 >= blk1) break;
-    STEP(1, 0, 0, blk + 1)
-  }
-#undef QK
-#undef TO_Y
 #undef MAKE_SEEDS
+#undef SEEDS_IN
+#undef KFRAGS
+#undef QK_TILE
+#undef TO_Y
+#undef PACK_Y
 #undef ROW_MAX
 #undef ROW_MAX_POS
-#undef RAISE_REF
-#undef STEP
+#undef MASK_TAIL
+#undef VFRAG
 #undef STAGE_DMA
 #undef STEP_SYNC
+#undef VALU_PART
+#undef REQ_TAIL
+#undef ROWS_UPDATE
+#undef SCHED_M
+#undef SCHED_S
+#undef TIE_
+#undef PRIO_HI
+#undef PRIO_LO
+#undef PV_PART
+#undef REQ_K_TIED
+#undef REQ_V_TIED
+#undef RAISE_REF
+#undef MATRIX_PART
+#undef ROLE_Y_
+#undef STEP
+  TR_FLUSH_()
+#undef TR_
+#undef TR_FLUSH_
 #undef ROWS_OF
+#undef ROWS_NEXT
 #undef ROW_OF_B
 #undef DMA_K
 #undef DMA_B
