@@ -591,8 +591,10 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
       /* mx_cur (row max of this block's scores) was computed under the previous step's PV MFMAs; only the */ \
       /* last, partial key block has to mask its tail and redo it here                                      */ \
       if ((j_) * KVB + KVB > n_kv) {                                              \
+        int h4_ = 4 * hh; /* opaque: else the 16 sums lane term + register row are hoisted into 16 registers */ \
+        asm volatile("" : "+v"(h4_));                                             \
         _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
-          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
+          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + h4_;                        \
           if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
           if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
         }                                                                         \
