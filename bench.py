@@ -317,11 +317,12 @@ def main():
                          "over the whole sequence through the zero-copy receive layout, the send-side staging passes and the "
                          "un-permute of the output included, the transfers themselves left out.  `value` is an upper bound of "
                          "the P-GPU throughput; not a BASELINE line")
-    ap.add_argument("--placement", default=os.environ.get("VORTA_SP_PLACEMENT", "auto"), choices=["auto", "even", "uneven"],
+    ap.add_argument("--placement", default=os.environ.get("VORTA_SP_PLACEMENT", "auto"), choices=["auto", "even", "uneven", "split"],
                     help="N>1: heads per rank -- even: H/N on every rank (whole-head LPT under that constraint); uneven: the "
                          "ranks' head counts follow the layer's routes (LPT on the expert costs alone); auto (default): even "
                          "when N divides the heads (one receive layout for every layer; identical to uneven on the uniform "
-                         "mix), uneven otherwise")
+                         "mix), uneven otherwise; split: uneven, then full-attention heads give a range of their QUERIES to the "
+                         "lightest ranks until the heaviest is within 1 %% of the mean (sequences without text tokens)")
     ap.add_argument("--conservative", action="store_true",
                     help="N>1 fallback: --placement even --sp-groups 1, one all_to_all_single per tensor "
                          "(VORTA_SP_TRANSPORT=a2a), v exchanged in 16 bits -- the oldest, most exercised form of the exchange")
@@ -579,7 +580,9 @@ def main():
                                                                if emu else f"ulysses sp{P} (RCCL all-to-all over xGMI)")
                    + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else "")
                    + (f", {args.placement} head placement (heaviest rank / mean cost, worst layer: "
-                      f"{max(sp.max_over_mean):.3f})" if P > 1 else ""),
+                      f"{max(sp.max_over_mean):.3f}"
+                      + (f"; heads split by query range: {sum(len(x) - H for x in sp.orders)} extra parts over {L} layers"
+                         if args.placement == "split" else "") + ")" if P > 1 else ""),
                    "experts": {"fused": "one fused grid per layer", "serial": "one launch per expert",
                                "concurrent": "experts on side streams"}[args.experts],
                    **({"fp8": "e4m3 q,k,v and probabilities on the fp8 MFMA; conversion (per-head scales, key centring "

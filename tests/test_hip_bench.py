@@ -123,6 +123,31 @@ def test_bench_fp8pv_lines():
     assert fps[0] == fps[1] != 0, fps
 
 
+def test_bench_two_rank_rehearsal_with_heads_split_by_query_range():
+    """--placement split: a full-attention head computes one range of its queries on each of two ranks
+    (both receive its K and V); the layer must be the one whole heads give, bit for bit -- 16-bit, e4m3 and int8-score
+    (the per-head scales are taken over the whole head on both ranks)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    base = [sys.executable, "bench.py", "--gpus", "2", "--config", "wan-tiny", "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-gemm-ceiling"]
+    for dtype in ("bf16", "fp8", "i8pv"):
+        fps = {}
+        for placement in ("uneven", "split"):
+            r = subprocess.run(base + ["--dtype", dtype, "--placement", placement], cwd=ROOT, env=env, capture_output=True,
+                               text=True, timeout=900)
+            assert r.returncode == 0, (dtype, placement, r.stdout[-1500:], r.stderr[-3000:])
+            j = _line(r.stdout)
+            assert j["exchange_selfcheck"]["ok"] is True
+            fps[placement] = j["output_fingerprint"]
+            if placement == "split":
+                par = j["config"]["parallelism"]
+                assert "split head placement" in par and "extra parts" in par and "split by query range: 0 extra" not in par, par
+                ratio = float(par.split("worst layer: ")[1].split(";")[0])
+                assert ratio <= 1.02, par
+        assert fps["uneven"] == fps["split"] != 0, (dtype, fps)
+
+
 def test_bench_three_rank_rehearsal_heads_not_divisible():
     """3 ranks sharing the GPU (gloo, host-staged): 8 heads do not divide by 3 -- the reference's reshard and the equal-count
     placement both refuse that -- but head counts that follow the routes place them (3 + 3 + 2 and the like).  One collective

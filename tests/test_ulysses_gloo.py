@@ -232,6 +232,81 @@ def _selfcheck_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
+def _split_worker(rank, world, port, ret):
+    """heads split by QUERY RANGE over two ranks (split_placement): both ranks receive the head, each returns its range
+    (zeros elsewhere: the identity attention of exchange_selfcheck honours the range), and every token shard must come
+    back whole -- one group and two slot groups, both transports; a wrong range table must fail"""
+    _init(rank, world, port)
+    import vorta_amd.ulysses.engine as E
+    from vorta_amd.ulysses import UlyssesLayout, exchange_selfcheck, slot_groups, split_placement, placement_loads
+    P = world
+    S, T, D = 64 * world, 0, 8
+    H = 2 * world + 1
+    experts = ([0, 0, 0, 2, 1, 2, 2, 1, 2] * H)[:H]  # three full-attention heads: whole heads cannot balance 2 or 4 ranks
+    cost = [9.0, 2.0, 1.0]
+    res = {}
+    for groups in (1, 2):
+        order, counts, parts = split_placement(experts, cost, P, S, groups, align=4, tol=0.005)
+        n_extra = sum(counts) - H
+        loads = placement_loads(experts, cost, order, counts, parts, S)
+        res[("extra", groups)] = n_extra
+        res[("ratio", groups)] = max(loads) * P / sum(loads)
+        lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.bfloat16, counts=counts)
+        sg = slot_groups(lay.Hl, min(groups, min(lay.counts)))
+        for transport in ("a2a", "p2p"):
+            E.TRANSPORT = transport
+            bufs = [lay.new_buffer() for _ in range(4)]
+            r = exchange_selfcheck(lay, order, sg, bufs, parts=parts)
+            res[(groups, transport, "ok")] = r["ok"]
+            # the same exchange told that every slot is whole must lose the rows only the other part returned
+            wrong = [None if p is None else (p[0], max(p[0] + 4, p[1] - 4)) for p in parts]
+            bufs = [lay.new_buffer() for _ in range(4)]
+            r = exchange_selfcheck(lay, order, sg, bufs, parts=wrong)
+            res[(groups, transport, "wrong ranges")] = r["ok"]
+    E.TRANSPORT = "a2a"
+    ret[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_heads_split_by_query_range_round_trip(world):
+    ret = mp.Manager().dict()
+    mp.spawn(_split_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        res = ret[r]
+        for groups in (1, 2):
+            assert res[("extra", groups)] >= 1, res            # the mix needs at least one split
+            assert res[("ratio", groups)] <= 1.03, res  # (4-token steps of a 64-token shard are coarse)
+            for transport in ("a2a", "p2p"):
+                assert res[(groups, transport, "ok")] is True, (r, groups, transport)
+                assert res[(groups, transport, "wrong ranges")] is False, (r, groups, transport)
+
+
+def test_split_placement_reaches_one_percent_on_wan14b_at_eight_ranks():
+    """Wan-14B-81f, 40 heads on 8 ranks: whole heads leave the heaviest rank at 1.037 of the mean, query
+    ranges of full-attention heads bring every layer to <= 1.01 (costs: algorithmic FLOPs per head as bench.py counts them)"""
+    from vorta_amd.ulysses import balanced_placement, placement_loads, split_placement
+    S = 21 * 45 * 80
+    cost = [2926264320000.0, 731566080000.0, 526727577600.0]  # full / coreset / sliding-tile, Wan-14B-81f
+    for n0, n1, n2 in ((14, 13, 13), (7, 13, 20)):  # bench.py's uniform and sparse-heavy mixes at 40 heads
+        for layer in range(40):
+            e = np.random.default_rng(1234 + layer).permutation([0] * n0 + [1] * n1 + [2] * n2)
+            o, c = balanced_placement(e, cost, 8)
+            whole = placement_loads(e, cost, o, c)
+            order, counts, parts = split_placement(e, cost, 8, S)
+            loads = placement_loads(e, cost, order, counts, parts, S)
+            assert abs(sum(loads) - sum(whole)) < 1e-6 * sum(whole)          # nothing computed twice
+            assert max(loads) * 8 / sum(loads) <= 1.01 < max(whole) * 8 / sum(whole)
+            st = np.cumsum([0] + counts)
+            for j in range(8):  # at most two partial heads per rank (segments of its fused launch), full-attention heads only
+                mine = [i for i in range(st[j], st[j + 1]) if parts[i] is not None]
+                assert len(mine) <= 2 and all(e[order[i]] == 0 for i in mine)
+            for h in set(order):  # the parts of a head tile its tokens exactly once
+                rng = sorted(parts[i] or (0, S) for i in range(len(order)) if order[i] == h)
+                assert rng[0][0] == 0 and rng[-1][1] == S and all(a[1] == b[0] for a, b in zip(rng, rng[1:]))
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_exchange_selfcheck_passes_and_catches_a_misordered_placement(world):
     ret = mp.Manager().dict()

@@ -278,6 +278,9 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     # `ws` may be released now: the caching allocator is stream ordered and the launch is on this stream
 
 
+MAX_FUSED = 6  # csrc/attn_common.h MAX_SEGMENTS (the library refuses more with VORTA_EINVAL)
+
+
 def attn_fwd_batch(calls) -> None:
     """vorta_attn_fwd_batch: `calls` is a list of dicts of attn_fwd arguments (q,k,v,out + keywords, optional tag /
     flops).  Launches that all resolve to the 256-row pipelined kernel are fused into one grid, in list order
@@ -311,8 +314,8 @@ def attn_fwd_batch(calls) -> None:
         return _plan(a)[0] == 256 and a.variant != 1 and not (a._ext is not None and not a._i8 and a._ext.flags & 1)
 
     ok = [fusable_one(a) for a, _, _, _ in built]
-    fuse_all = 1 < len(built) <= 4 and all(ok)
-    fuse_some = not fuse_all and 2 <= sum(ok) <= 4 and sum(ok) < len(built)
+    fuse_all = 1 < len(built) <= MAX_FUSED and all(ok)
+    fuse_some = not fuse_all and 2 <= sum(ok) <= MAX_FUSED and sum(ok) < len(built)
     in_grid = [o and (fuse_all or fuse_some) for o in ok]
     for i, (hinted, _, c) in enumerate(hints):
         if hinted and not in_grid[i]:  # stand-alone after all: the caller's own split count

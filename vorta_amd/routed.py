@@ -26,18 +26,30 @@ class HeadRouting:
     lists: torch.Tensor                 # (3, H) int32 device, ascending heads per expert
     counts_host: Optional[List[int]]    # [n0,n1,n2] or None when only the device knows
     counts_dev: Optional[torch.Tensor]  # (3,) int32 device
+    # full-attention heads that compute only a RANGE of their queries here (sequence parallelism below whole heads,
+    # ulysses/engine.py split_placement): (one-entry int32 device list with the head, first query token, end); such a
+    # head is not in lists[0]
+    partials: Optional[List[Tuple[torch.Tensor, int, int]]] = None
 
     @staticmethod
-    def from_expert_ids(expert_of_head: Sequence[int], device) -> "HeadRouting":
+    def from_expert_ids(expert_of_head: Sequence[int], device, q_ranges: Optional[dict] = None) -> "HeadRouting":
+        """`q_ranges`: {head: (t0, t1)} for full-attention heads (expert 0) that attend only for query tokens [t0, t1)"""
         H = len(expert_of_head)
+        q_ranges = q_ranges or {}
         lists = torch.zeros((3, H), dtype=torch.int32)
         counts = []
         for e in range(3):
-            hs = [h for h, x in enumerate(expert_of_head) if int(x) == e]
+            hs = [h for h, x in enumerate(expert_of_head) if int(x) == e and not (e == 0 and h in q_ranges)]
             counts.append(len(hs))
             if hs:
                 lists[e, : len(hs)] = torch.tensor(hs, dtype=torch.int32)
-        return HeadRouting(lists.to(device), counts, None)
+        partials = None
+        if q_ranges:
+            if any(int(expert_of_head[h]) != 0 for h in q_ranges):
+                raise ValueError("only full-attention heads (expert 0) can be split by query range")
+            partials = [(torch.tensor([h], dtype=torch.int32).to(device), int(t0), int(t1))
+                        for h, (t0, t1) in sorted(q_ranges.items())]
+        return HeadRouting(lists.to(device), counts, None, partials)
 
     @staticmethod
     def from_device(lists: torch.Tensor, counts: torch.Tensor) -> "HeadRouting":
@@ -235,7 +247,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         o_e = [out[0] if out.dim() == 4 else out] * 3
 
     def live(e):
-        return routing.counts_host is None or routing.counts_host[e] > 0
+        return routing.counts_host is None or routing.counts_host[e] > 0 or (e == 0 and bool(routing.partials))
 
     def nheads(e):  # for the algorithmic-work tags only
         return routing.counts_host[e] if routing.counts_host is not None else 0
@@ -264,9 +276,24 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     def expert_full():
-        return [dict(base, out=o_e[0], n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full",
-                     q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
-                     flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H))]
+        calls = []
+        if routing.counts_host is None or routing.counts_host[0] > 0:
+            calls.append(dict(base, out=o_e[0], n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full",
+                              q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
+                              flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H)))
+        for hl, t0, t1 in routing.partials or ():
+            # a head whose other query tokens another rank computes: every key, the query rows [t0, t1)
+            if T > 0 or not (0 <= t0 < t1 <= S):
+                raise ValueError("a query range needs a sequence without text tokens and 0 <= t0 < t1 <= S")
+            part = dict(base, out=o_e[0], n_q=t1 - t0, n_kv=S, q_valid=t1 - t0, tag="full_part",
+                        kv_rows=None if rm is None else rm[:S], flops=4.0 * (t1 - t0) * S * D,
+                        head_list=hl, n_heads=1, n_heads_dev=None)
+            if rm is None:
+                part.update(q_row_offset=t0)
+            else:
+                part.update(q_rows=rm[t0:t1])
+            calls.append(part)
+        return calls
 
     # ---- expert 1: coreset attention (hunyuan.py:410-457 / wan.py:243-270) ----
     def expert_lowres():

@@ -3,9 +3,9 @@ zero-copy engine).  Training-only helpers of the reference (the autograd `all_to
 `TrainingLog`) are out of scope."""
 from .comm import all_gather, all_to_all_4D, broadcast_sp_group, dist_prefix, set_seed, shrink_dim
 from .engine import (UlyssesLayout, UlyssesRoutedAttention, balanced_head_order, balanced_placement, exchange_and_attend,
-                     exchange_selfcheck, make_row_map, slot_groups, tag_rows)
+                     exchange_selfcheck, make_row_map, placement_loads, slot_groups, split_placement, tag_rows)
 from .state import SP_STATE, SequenceParallelState
 
 __all__ = ["SP_STATE", "SequenceParallelState", "all_to_all_4D", "all_gather", "shrink_dim", "broadcast_sp_group",
            "dist_prefix", "set_seed", "UlyssesLayout", "UlyssesRoutedAttention", "balanced_head_order", "balanced_placement", "make_row_map", "exchange_and_attend", "slot_groups",
-           "exchange_selfcheck", "tag_rows"]
+           "exchange_selfcheck", "tag_rows", "split_placement", "placement_loads"]

@@ -112,6 +112,93 @@ def balanced_placement(experts: Sequence[int], cost_of_expert: Sequence[float], 
     return order, counts
 
 
+def split_placement(experts: Sequence[int], cost_of_expert: Sequence[float], P: int, n_tokens: int, groups: int = 1,
+                    max_heads: Optional[int] = None, tol: float = 0.01, align: int = 256, max_parts: int = 2):
+    """`balanced_placement`, then BELOW whole heads: while the heaviest rank carries more than (1 + tol) x the mean, one of
+    its full-attention heads gives the tail of its QUERIES to the lightest rank -- both ranks receive the head's K and V
+    (and q: the exchange stays one message per peer), each computes its own query range and returns the whole head; the
+    token shards pick their rows from the rank that computed them.  Full attention costs the same per query, so a
+    range moves load continuously (`align`-token steps): water-filling towards the mean, heaviest rank first.  Wan-14B at
+    P = 8 (five heads per rank, costs 5.6 : 1.4 : 1) goes from 1.037 of the mean to <= 1.01.  A rank holds at most
+    `max_parts` partial heads (each is one more segment of its fused launch).  Returns (order, counts, parts): the head
+    order lists a split head once per part -- rank j owns order[sum(counts[:j]) : sum(counts[:j + 1])], sum(counts) =
+    H + number of extra parts -- and parts[i] = None for a whole head or (t0, t1), the query tokens slot i computes.
+    Deterministic."""
+    order, counts = balanced_placement(experts, cost_of_expert, P, 1, max_heads)
+    starts = [sum(counts[:j]) for j in range(P + 1)]
+    bins = [list(order[starts[j]:starts[j + 1]]) for j in range(P)]
+    cost = lambda h: cost_of_expert[int(experts[h])]
+    full = max(range(len(cost_of_expert)), key=lambda e: cost_of_expert[e])
+    c_full = cost_of_expert[full]
+    load = [sum(cost(h) for h in b) for b in bins]
+    mean = sum(load) / P
+    rng = {}                      # (rank, head) -> [t0, t1): the query range of a partial head
+    n_parts = [0] * P             # partial heads per rank
+    step = c_full * align / n_tokens
+    for _ in range(4 * P):
+        R = max(range(P), key=lambda j: (load[j], -j))
+        if load[R] <= (1.0 + tol) * mean:
+            break
+        # a full-attention head of R that can still give: one it already holds in part, else (room permitting) a whole one
+        cand = [h for h in bins[R] if int(experts[h]) == full and (((R, h) in rng) or n_parts[R] < max_parts)]
+        cand = [h for h in cand if rng.get((R, h), (0, n_tokens))[1] - rng.get((R, h), (0, n_tokens))[0] > 2 * align]
+        light = [j for j in range(P) if j != R and n_parts[j] < max_parts and load[j] < mean - step
+                 and not any((j, h) in rng for h in cand)]
+        if not cand or not light:
+            break
+        r = min(light, key=lambda j: (load[j], j))
+        h = max(cand, key=lambda x: (rng.get((R, x), (0, n_tokens))[1] - rng.get((R, x), (0, n_tokens))[0], x))
+        t0, t1 = rng.get((R, h), (0, n_tokens))
+        move = min(load[R] - mean, mean - load[r])
+        n = min(int(round(move / step)) * align, (t1 - t0) - align)
+        if n < align:
+            break
+        if (R, h) not in rng:
+            n_parts[R] += 1
+        rng[(R, h)] = (t0, t1 - n)
+        rng[(r, h)] = (t1 - n, t1)
+        n_parts[r] += 1
+        bins[r].append(h)
+        load[R] -= n / align * step
+        load[r] += n / align * step
+    eff = lambda j, h: cost(h) * ((rng[(j, h)][1] - rng[(j, h)][0]) / n_tokens if (j, h) in rng else 1.0)
+    counts = [len(b) for b in bins]
+    n_groups = max(1, min(int(groups), min(counts)))
+    out_order: List[int] = []
+    parts: List[Optional[tuple]] = []
+    for j, b in enumerate(bins):
+        if n_groups == 1:
+            slots = sorted(b)
+        else:
+            sizes = group_sizes(len(b), n_groups)
+            gl = [0.0] * n_groups
+            gb: List[List[int]] = [[] for _ in sizes]
+            for h in sorted(b, key=lambda i: (-eff(j, i), i)):
+                g = min((x for x in range(n_groups) if len(gb[x]) < sizes[x]), key=lambda x: (gl[x] / sizes[x], x))
+                gb[g].append(h)
+                gl[g] += eff(j, h)
+            slots = [h for g in gb for h in sorted(g)]
+        out_order += slots
+        parts += [rng.get((j, h)) for h in slots]
+    return out_order, counts, parts
+
+
+def placement_loads(experts: Sequence[int], cost_of_expert: Sequence[float], order: Sequence[int], counts: Sequence[int],
+                    parts: Optional[Sequence[Optional[tuple]]] = None, n_tokens: int = 1) -> List[float]:
+    """cost per rank of a placement (a partial full-attention head counts by its share of the queries)"""
+    starts = [sum(counts[:j]) for j in range(len(counts) + 1)]
+    loads = []
+    for j in range(len(counts)):
+        tot = 0.0
+        for i in range(starts[j], starts[j + 1]):
+            c = cost_of_expert[int(experts[order[i]])]
+            if parts is not None and parts[i] is not None:
+                c *= (parts[i][1] - parts[i][0]) / n_tokens
+            tot += c
+        loads.append(tot)
+    return loads
+
+
 def slot_groups(Hl: int, groups: int) -> List[tuple]:
     out, g0 = [], 0
     for n in group_sizes(Hl, groups):
@@ -121,7 +208,7 @@ def slot_groups(Hl: int, groups: int) -> List[tuple]:
 
 
 def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, groups, attend, out_shard, out_text,
-                        vwire: Optional["VWire"] = None, prepare=None):
+                        vwire: Optional["VWire"] = None, prepare=None, parts=None):
     """One layer under sequence parallelism.  `groups` = slot ranges of the local heads; `attend(g0, g1, index)`
     enqueues the attention over local head slots [g0, g1) of the layout buffers.  With one group this is
     scatter -> attention -> gather.  With several, the exchange of group g+1 and the return of group g-1 are in
@@ -133,7 +220,7 @@ def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, g
     if prepare is not None:
         prepare()
     handles = lay.scatter_heads_start(shards, bufs[:3], head_order, texts, groups, vwire=vwire)
-    state = lay.gather_heads_begin(out_shard, head_order)
+    state = lay.gather_heads_begin(out_shard, head_order, parts)
     back = []
     side = None
     if len(groups) > 1 and GROUP_STREAMS and out_shard.is_cuda:
@@ -186,7 +273,7 @@ def tag_rows(t: int, heads: Sequence[int], tokens: torch.Tensor, kind: int, D: i
 
 
 def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, bufs, vwire: Optional["VWire"] = None,
-                       break_order: bool = False) -> dict:
+                       break_order: bool = False, parts=None) -> dict:
     """Push integer-tagged q, k, v (`tag_rows`: value = f(tensor, head, token, channel)) through THIS layout's own exchange
     -- the staging pass, the all_to_all_single (even or per-rank splits) or the grouped send / recv of every slot group,
     the text rows, v as e4m3 when it travels that way, the return trip of the output and the all-gather of the text
@@ -197,7 +284,8 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
       * the returned sequence shard of every head and the gathered text rows against the q rows sent.
     Replaces nothing in the reference (vorta/ulysses/utils.py:42-56,68-89 has no check); it is what makes the first run
     on a new transport trustworthy.  `break_order` (tests only): the last rank swaps two heads of ITS copy of the order,
-    which must fail the check.  Returns {"ok", "failed": [names], "bytes": sent + received by this rank, "ms"}."""
+    which must fail the check.  `parts` (`split_placement`): a slot that computes only a range of its head's queries
+    returns ZEROS for the other rows, so the shard is whole only if every row was taken from the right slot.  Returns {"ok", "failed": [names], "bytes": sent + received by this rank, "ms"}."""
     import time
     dev, dt = lay.device, lay.dtype
     H, S, T, D, P, Sl, me, Hl = lay.H, lay.S, lay.T, lay.D, lay.P, lay.Sl, lay.rank, lay.Hl
@@ -212,15 +300,24 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
     out_text = torch.zeros((H, T, D), dtype=dt, device=dev) if T else None
     rv = lay.rows_video
 
+    my_parts = None if parts is None else list(parts)[lay.starts[me]:lay.starts[me + 1]]
+
     def attend(g0, g1, gi):  # identity attention: the output rows of a head slot are its query rows
         bufs[3][:rv].view(P, Hl, Sl, D)[:, g0:g1].copy_(bufs[0][:rv].view(P, Hl, Sl, D)[:, g0:g1])
         if T:
             bufs[3][rv:].view(Hl, Sl, D)[g0:g1, :T].copy_(bufs[0][rv:].view(Hl, Sl, D)[g0:g1, :T])
+        for i in range(g0, g1):  # a partial slot: only the query tokens of its range
+            if my_parts is not None and my_parts[i] is not None:
+                t0, t1 = my_parts[i]
+                o_i = lay.head_view(bufs[3])[i]
+                keep = torch.zeros(S, dtype=torch.bool, device=dev)
+                keep[t0:t1] = True
+                o_i[lay.row_map[:S].long()[~keep]] = 0
 
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    exchange_and_attend(lay, shards, bufs, order, texts, groups, attend, out_shard, out_text, vwire=vwire)
+    exchange_and_attend(lay, shards, bufs, order, texts, groups, attend, out_shard, out_text, vwire=vwire, parts=parts)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) * 1e3
@@ -263,7 +360,7 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
     if P > 1 and not lay.loopback:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=lay.group)
     esz = torch.empty((), dtype=dt).element_size()
-    away = (H - Hl) * Sl * D  # elements of one tensor this rank sends to its peers
+    away = (lay.Hv - Hl) * Sl * D  # elements of one tensor this rank sends to its peers
     back = Hl * (S - Sl) * D  # ... and receives from them
     nbytes = (n16 * esz + (1 if vwire is not None else 0)) * (away + back) + esz * (away + back)  # q, k, v in; o back
     nbytes += esz * (P - 1) * max(lay.counts) * T * D * 2 if T else 0  # text all-gather (padded to the largest count)
@@ -294,8 +391,8 @@ class VWire:
         dev = lay.device
         self.buf = buf  # (rows_total, D) uint8 receive buffer = the v8 operand of the attention kernels
         self.amax = torch.zeros((lay.H, lay.D), dtype=torch.float32, device=dev)
-        self.descale_all = torch.zeros((lay.H, lay.D), dtype=torch.float32, device=dev)  # in head_order
-        self.stage = torch.empty((lay.H, lay.Sl, lay.D), dtype=torch.uint8, device=dev)
+        self.descale_all = torch.zeros((lay.Hv, lay.D), dtype=torch.float32, device=dev)  # in head_order
+        self.stage = torch.empty((lay.Hv, lay.Sl, lay.D), dtype=torch.uint8, device=dev)
         self.lay = lay
 
     def descale(self, g0: int, g1: int) -> torch.Tensor:
@@ -329,9 +426,11 @@ class UlyssesLayout:
                 raise ValueError(f"heads {H} and sequence {S} must be divisible by the sequence-parallel size {P}")
             counts = [H // P] * P
         counts = [int(c) for c in counts]
-        if len(counts) != P or sum(counts) != H or min(counts) < 1:
-            raise ValueError(f"head counts {counts} do not place {H} heads on {P} ranks (at least one each)")
+        if len(counts) != P or sum(counts) < H or min(counts) < 1 or (sum(counts) > H and T > 0):
+            raise ValueError(f"head counts {counts} do not place {H} heads on {P} ranks (at least one each; more slots than "
+                             "heads = heads split by query range, `split_placement`: sequences without text only)")
         self.H, self.S, self.T, self.D, self.P, self.rank = H, S, T, D, P, rank
+        self.Hv = sum(counts)  # head slots over all ranks: H, + one per extra part of a head split by query range
         self.counts = counts
         self.starts = [sum(counts[:j]) for j in range(P + 1)]
         self.even = all(c == counts[0] for c in counts)
@@ -497,7 +596,7 @@ class UlyssesLayout:
         """(H, Sl, D) staging buffers in head_order (one per tensor slot), allocated once per layout."""
         st = self.__dict__.setdefault("_stages", {})
         if key not in st:
-            st[key] = torch.empty((self.H, self.Sl, self.D), dtype=self.dtype, device=self.device)
+            st[key] = torch.empty((self.Hv, self.Sl, self.D), dtype=self.dtype, device=self.device)
         return st[key]
 
     @staticmethod
@@ -550,7 +649,8 @@ class UlyssesLayout:
         srcs = []
         staged = []
         for t, (x, buf) in enumerate(zip(shards, bufs)):
-            direct = self.even and x.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
+            direct = (self.even and self.Hv == self.H and x.is_contiguous()
+                      and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P)))
             if direct:
                 src = x
                 first = [self._run_of(head_order, j * Hl, Hl) for j in range(P)]
@@ -591,10 +691,10 @@ class UlyssesLayout:
             # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides (rows per
             # chunk follow the ranks' head counts on the send side; every peer sends this rank's Hl heads)
             splits = (None, None) if self.even else ([c * Sl for c in counts], [blk] * P)
-            h = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs], *splits)
+            h = self._start_a2a([(src.view(self.Hv * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs], *splits)
             if vwire is not None:  # converted while q and k are on the links
                 src, _, buf = convert_v()
-                hv = self._start_a2a([(src.view(self.H * Sl, self.D), buf[:P * blk])], *splits)
+                hv = self._start_a2a([(src.view(self.Hv * Sl, self.D), buf[:P * blk])], *splits)
                 h = None if h is None and hv is None else ("works", (h[1] if h else []) + (hv[1] if hv else []))
             return [h]
         if vwire is not None:
@@ -625,12 +725,41 @@ class UlyssesLayout:
         self._finish(self.gather_heads_start(buf, state))
         self.gather_heads_end(buf, state, out_text)
 
-    def gather_heads_begin(self, out_shard: torch.Tensor, head_order: Sequence[int]):
+    def gather_heads_begin(self, out_shard: torch.Tensor, head_order: Sequence[int],
+                           parts: Optional[Sequence[Optional[tuple]]] = None):
+        """`parts` (`split_placement`): parts[i] = (t0, t1) when slot i of the head order computed only those query tokens
+        of its head; this rank's token shard then takes each row of the head from the slot whose range holds it"""
         Hl, P = self.Hl, self.P
-        direct = self.even and out_shard.is_contiguous() and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P))
+        if parts is not None and not any(x is not None for x in parts):
+            parts = None
+        if (parts is None) != (self.Hv == self.H):
+            raise ValueError("a head order with split heads needs `parts`, and only such an order takes them")
+        direct = (parts is None and self.even and out_shard.is_contiguous()
+                  and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P)))
         dst = out_shard if direct else self._stage(("g", 0))
         first = [self._run_of(head_order, j * Hl, Hl) if direct else self.starts[j] for j in range(P)]
-        return dict(out_shard=out_shard, order=list(head_order), direct=direct, dst=dst, first=first)
+        state = dict(out_shard=out_shard, order=list(head_order), direct=direct, dst=dst, first=first, parts=None)
+        if parts is not None:
+            lo, hi = self.rank * self.Sl, (self.rank + 1) * self.Sl  # this rank's tokens
+            slot_of = [-1] * self.H
+            extra = []  # (slot, head, first row, end row) of the shard: rows another part of the head computed
+            best = {}
+            for i, (h, pr) in enumerate(zip(head_order, parts)):
+                t0, t1 = (0, self.S) if pr is None else pr
+                r0, r1 = max(t0, lo) - lo, min(t1, hi) - lo
+                if r1 <= r0:
+                    continue
+                if r1 - r0 > best.get(h, (0, 0))[0]:
+                    if h in best:
+                        extra.append(best[h][1])
+                    best[h] = (r1 - r0, (i, h, r0, r1))
+                    slot_of[h] = i
+                else:
+                    extra.append((i, h, r0, r1))
+            if min(slot_of) < 0:
+                raise ValueError("the parts of a split head do not cover this rank's tokens")
+            state.update(parts=list(parts), slot_of=slot_of, extra=extra)
+        return state
 
     def gather_heads_start(self, buf: torch.Tensor, state, slots: Optional[Sequence[int]] = None, gi: int = 0,
                            n_groups: int = 1):
@@ -642,7 +771,7 @@ class UlyssesLayout:
         dst, first = state["dst"], state["first"]
         if TRANSPORT == "a2a" and (g0, g1) == (0, Hl) and first == list(self.starts[:P]) and P > 1:
             splits = (None, None) if self.even else ([blk] * P, [c * Sl for c in self.counts])
-            return self._start_a2a([(buf[:P * blk], dst.view(self.H * Sl, self.D))], *splits)
+            return self._start_a2a([(buf[:P * blk], dst.view(self.Hv * Sl, self.D))], *splits)
         dst[first[me] + g0:first[me] + g1].copy_(buf[me * blk + g0 * Sl:me * blk + g1 * Sl].view(g1 - g0, Sl, self.D))
         p2p = []
         for j in range(P):
@@ -658,7 +787,15 @@ class UlyssesLayout:
         """after every slot group's handle was finished: un-permute (if staged) and all-gather the text rows"""
         Hl, Sl = self.Hl, self.Sl
         out_shard, head_order = state["out_shard"], state["order"]
-        if not state["direct"]:
+        if state["parts"] is not None:
+            # every head from the slot that computed most of this shard's rows, then the rows another part computed
+            if out_shard.is_cuda and HIP_STAGING:
+                ops.permute_heads([state["dst"]], [out_shard], src_map=self._head_map(state["slot_of"]))
+            else:
+                out_shard.copy_(state["dst"][torch.as_tensor(state["slot_of"], device=out_shard.device)])
+            for i, h, r0, r1 in state["extra"]:
+                out_shard[h, r0:r1].copy_(state["dst"][i, r0:r1])
+        elif not state["direct"]:
             if out_shard.is_cuda and HIP_STAGING:
                 ops.permute_heads([state["dst"]], [out_shard], dst_map=self._head_map(head_order))
             else:
@@ -735,8 +872,10 @@ class UlyssesRoutedAttention:
         """heaviest_rank (with loopback): every layer is run as the rank that carries the largest cost in THAT layer -- a
         P-GPU step waits for its slowest rank layer by layer, so this (not a fixed rank) is the compute side of it."""
         from ..routed import HeadRouting
-        if placement not in ("even", "uneven"):
-            raise ValueError("placement is 'even' or 'uneven'")
+        if placement not in ("even", "uneven", "split"):
+            raise ValueError("placement is 'even', 'uneven' or 'split'")
+        if placement == "split" and cfg["text"]:
+            raise ValueError("placement 'split' (heads split by query range) is for sequences without text tokens")
         if heaviest_rank and not loopback:
             raise ValueError("heaviest_rank is an emulation mode (loopback)")
         self.fp8 = fp8
@@ -746,16 +885,22 @@ class UlyssesRoutedAttention:
         self.concurrent, self.fused, self.sliding_block_rows = concurrent, fused, sliding_block_rows
         self.te = cfg["text_valid"]
         costs = [cost_of_expert["full"], cost_of_expert["lowres"], cost_of_expert["sliding"]]
-        self.orders, self.routes, self.lays, self.groups = [], [], [], []
+        self.orders, self.routes, self.lays, self.groups, self.parts = [], [], [], [], []
         layouts, self.states = {}, {}
         self.max_over_mean = []  # per layer: heaviest rank's cost / mean cost (1.0 = perfectly balanced)
         for e in layer_experts:
+            parts = None
             if placement == "even":
                 order, counts = balanced_head_order(e, costs, P, groups), [H // P] * P
-            else:
+            elif placement == "uneven":
                 order, counts = balanced_placement(e, costs, P, groups)
+            else:
+                # whole 256-row workgroups at full size; small rehearsal sequences need finer steps to move anything
+                order, counts, parts = split_placement(e, costs, P, S, groups, align=256 if S >= 32768 else 32)
+                if not any(x is not None for x in parts):
+                    parts = None
             starts = [sum(counts[:j]) for j in range(P + 1)]
-            loads = [sum(costs[int(e[h])] for h in order[starts[j]:starts[j + 1]]) for j in range(P)]
+            loads = placement_loads(e, costs, order, counts, parts, S)
             self.max_over_mean.append(max(loads) * P / sum(loads))
             r = max(range(P), key=lambda j: (loads[j], -j)) if heaviest_rank else rank
             key = (tuple(counts), r)
@@ -768,10 +913,14 @@ class UlyssesRoutedAttention:
             lay = layouts[key]
             sg = slot_groups(lay.Hl, min(groups, min(counts)))
             local = [int(e[h]) for h in order[lay.starts[r]:lay.starts[r + 1]]]
+            local_parts = [None] * len(local) if parts is None else parts[lay.starts[r]:lay.starts[r + 1]]
             self.orders.append(order)
             self.lays.append(lay)
             self.groups.append(sg)
-            self.routes.append([HeadRouting.from_expert_ids(local[g0:g1], device) for g0, g1 in sg])
+            self.parts.append(parts)
+            self.routes.append([HeadRouting.from_expert_ids(
+                local[g0:g1], device, q_ranges={i - g0: local_parts[i] for i in range(g0, g1) if local_parts[i] is not None})
+                for g0, g1 in sg])
         self.Sl = S // P
         self.sets = []
         for i in range(n_sets):
@@ -789,7 +938,8 @@ class UlyssesRoutedAttention:
         st = self.states[lay.Hl]
         if st.vwire is not None:
             st.vwire.lay = lay
-        return exchange_selfcheck(lay, self.orders[l], self.groups[l], st.bufs, vwire=st.vwire, break_order=break_order)
+        return exchange_selfcheck(lay, self.orders[l], self.groups[l], st.bufs, vwire=st.vwire, break_order=break_order,
+                                  parts=self.parts[l])
 
     def layer(self, l: int):
         from ..routed import routed_attention
@@ -818,4 +968,5 @@ class UlyssesRoutedAttention:
         # every cached table of this layer exists before the slot groups fork onto their streams (the routing lists were
         # copied to the device in __init__)
         exchange_and_attend(lay, shards, st.bufs, self.orders[l], texts, self.groups[l], attend, self.out_shard,
-                            self.out_text, vwire=st.vwire, prepare=lambda: st.geom.prebuild(self.te if self.cfg["model"] == "hunyuan" else 0))
+                            self.out_text, vwire=st.vwire, parts=self.parts[l],
+                            prepare=lambda: st.geom.prebuild(self.te if self.cfg["model"] == "hunyuan" else 0))
