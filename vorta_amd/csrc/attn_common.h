@@ -66,7 +66,10 @@ __device__ __forceinline__ int live_order(const Params& p, int b, int n, bool re
   return (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (b >> 3);
 }
 
-constexpr int MAX_SEGMENTS = 6;  // launches fused into one grid (vorta_attn_fwd_batch): three experts, the text queries or up to
+#ifndef VORTA_MAX_SEGMENTS
+#define VORTA_MAX_SEGMENTS 6
+#endif
+constexpr int MAX_SEGMENTS = VORTA_MAX_SEGMENTS;  // launches fused into one grid (vorta_attn_fwd_batch): three experts, the text queries or up to
                                  // two partial full-attention heads of a sequence-parallel rank (ulysses/engine.py split_placement)
 struct MultiParams {
   Params seg[MAX_SEGMENTS];

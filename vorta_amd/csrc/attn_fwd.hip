@@ -378,6 +378,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     v_col[i] = ((lane & 15) ^ ((row & 3) << 2)) << 4;
   }
   int rowK[CH], rowV[CH];  // rows of the next K block / next V block to fetch
+  int posK[CH];            // key positions behind rowK (the loop's running value)
 #define ROWS_OF(dst_, blk_)                                                       \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
     const int pos_ = min((blk_) * KVB + 4 * (CH * wave + i_) + (lane >> 4), n_kv - 1); \
@@ -514,11 +515,22 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   // top of step j: K(j+NS) -> the slot K(j) left, V(j+NS-1) -> the slot V(j-1) left.  They are read in step
   // j+NS-1, so the barrier that ends step j only waits for the requests of step j-NS+2 and older: with NS = 3
   // the 2*CH requests of the current step stay in flight across it (two steps of latency cover, one with NS = 2)
+  // (the key positions of the loop are running values, one add per step: written as (block index) * 64 + lane term every
+  // unrolled step keeps its own hoisted copy of the sum in a register -- CH x 2 here, CH x 6 with the ring of 3)
 #define STAGE_DMA(kfree_, vfree_, j_)                                             \
   DMA_K(kfree_)                                                                   \
   DMA_V(vfree_)                                                                   \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
-  ROWS_OF(rowK, (j_) + NS + 1)                                                    \
+  if constexpr (NW == 8) {                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                           \
+      posK[i_] += KVB;                                                            \
+      const int pos_ = min(posK[i_], n_kv - 1);                                   \
+      if constexpr (KVTAB) rowK[i_] = kv_rows[pos_];                              \
+      else rowK[i_] = p.kv_row_offset + pos_;                                     \
+    }                                                                             \
+  } else { /* (four pieces per wave: the running values cost more registers than the hoisted sums) */ \
+    ROWS_OF(rowK, (j_) + NS + 1)                                                  \
+  }                                                                               \
   __builtin_amdgcn_sched_barrier(0);
   // end of a step: own DMA requests older than the current step have landed, then the workgroup barrier (which
   // also orders every wave's LDS reads of this step before the next step's overwrites)
@@ -574,12 +586,20 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
   // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
   // all visible to the scheduler together.
+  // -DVORTA_REQ_STAGGER=1 (ring of 3 only; experiment): the second wave of every SIMD (waves NW/2 ...) issues its tile
+  // requests BEHIND its step instead of at the top, so that the two waves of a SIMD are not both held by their requests
+  // (~90 cycles each, four per step) right after the barrier; the ring of 3 gives those requests the next step to land
+#ifndef VORTA_REQ_STAGGER
+#define VORTA_REQ_STAGGER 0
+#endif
 #define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, vfree_, j_)                       \
   { /* kcur_ = j % NS: slot of K(j) (free) and of V(j); knext_ = (j+1) % NS; vfree_ = (j-1) % NS */ \
-    STAGE_DMA(kcur_, vfree_, j_)                                                  \
+    if (!late_req) { STAGE_DMA(kcur_, vfree_, j_) }                               \
     STEP_BODY(c0_, c1_, n0_, n1_, kcur_, knext_, j_)                              \
+    if (late_req) { STAGE_DMA(kcur_, vfree_, j_) }                                \
     STEP_SYNC()                                                                   \
   }
+  const bool late_req = VORTA_REQ_STAGGER && NS == 3 && NW == 8 && wave >= NW / 2;  // wave-uniform
 #define STEP_BODY(c0_, c1_, n0_, n1_, kcur_, knext_, j_)                          \
   {                                                                               \
     if (wave_active) {                                                            \
@@ -663,6 +683,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     }
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     ROWS_OF(rowK, blk0 + NS)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) posK[i_] = (blk0 + NS) * KVB + 4 * (CH * wave + i_) + (lane >> 4);
     }
     __syncthreads();
     if (wave_active) {
