@@ -13,7 +13,7 @@ NB="--no-cpu-baseline --no-gemm-ceiling"
 hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -enable-post-misched=0 -w $R/tools/probe_mfma_shape.hip -o /tmp/probe_shape
 ( while true; do echo "t $(date +%s.%N)"; rocm-smi --showpower --showclocks --json 2>/dev/null | head -c 2000; echo; sleep 0.25; done ) > $O/smi_samples.txt 2>&1 &
 SAMPLER=$!
-timeout -k 10 200 /tmp/probe_shape 16 2 > $O/probe_e.txt 2>&1 || true
+timeout -k 10 200 /tmp/probe_shape 0 1 > $O/probe_e.txt 2>&1 || true
 kill $SAMPLER || true
 python3 $R/tools/smi_phases.py $O/probe_e.txt $O/smi_samples.txt > $O/probe_e_with_power.txt || true
 cat $O/probe_e_with_power.txt

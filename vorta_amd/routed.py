@@ -167,7 +167,7 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
 STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
 # process-wide default of `routed_attention(fp8=None)`: the processors of vorta.attention call it that way, so the
 # unchanged inference scripts pick the e4m3 path up from the environment or from `set_attention_precision("fp8")`
-# False (native), True (all e4m3), "fp8pv" (16-bit scores, e4m3 P V) or "i8pv" (int8 scores with a scale per row, e4m3 P V)
+# False (native), True (all e4m3), "fp8pv" (16-bit scores, e4m3 P V) or "i8pv" (int8 scores: one key scale per head, one query scale per wave; e4m3 P V)
 _PREC_ENV = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower()
 DEFAULT_FP8 = True if _PREC_ENV == "fp8" else (_PREC_ENV if _PREC_ENV in ("fp8pv", "i8pv") else False)
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
