@@ -497,3 +497,73 @@ def test_fp8_headline_sizes_sampled_waves_vs_oracle_emulator(config, precision):
         F._check(torch.from_numpy(o[h][sel]), ref[h][sel], dtype, amb[h][sel], vmax)
     if T:
         assert torch.all(out[0, :, S + te:] == 0)
+
+
+@pytest.mark.parametrize("config", ["wan14b-81f", "hunyuan-129f"])
+def test_i8pv_headline_sizes_sampled_waves_vs_oracle_emulator(config):
+    """precision "i8pv" (int8 scores, e4m3 P V) at the sizes that matter against the ORACLE: one head per
+    expert over the whole sequence of BASELINE configs[4] (S = 75 600) and of the headline geometry (S = 118 800 + 256 text
+    rows, 96 valid), the routed op as the processors call it (fused grid: the kernel with wave roles), then sampled waves of
+    every launch restated by oracle.fp8_attn_launch on the kernel's own operands -- the wave's query conversion, the int8
+    keys and their seeds (O.i8_wave_operands), the probabilities' bytes written as the kernel writes them."""
+    import test_hip_fp8 as F
+    import test_hip_i8 as I
+    from vorta_amd import ops
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    if config == "wan14b-81f":
+        model, latent, tile, group, T, te, dtype = "wan", (21, 45, 80), (7, 9, 8), (3, 3, 2), 0, 0, torch.bfloat16
+    else:
+        model, latent, tile, group, T, te, dtype = "hunyuan", (33, 45, 80), (11, 9, 8), (3, 3, 2), 256, 96, torch.float16
+    S = latent[0] * latent[1] * latent[2]
+    q, k, v = (_rand((1, 3, S + T, 128), 910 + i, dtype) for i in range(3))
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
+    v8_, vd_, _ = ops.fp8_quantize_v(v[0])
+    i8 = ops.i8_quantize_k(q[0], k[0])
+    out = routed_attention(q, k, v, HeadRouting.from_expert_ids([0, 1, 2], dev()), geom, model=model, text_len=T,
+                           text_valid=te, fp8="i8pv", fp8_operands=((v8_, vd_, _), i8))
+    torch.cuda.synchronize()
+    hooks = I._hooks(q[0], i8)
+    ve, vde = I._vdec(v8_, vd_)
+    N = S + T
+    ref, amb = np.zeros((3, N, 128)), np.full((3, N), np.nan)
+    gen = np.random.default_rng(9)
+
+    def some(lens, n):
+        picks = set()
+        while len(picks) < n:
+            g = int(gen.integers(len(lens)))
+            picks.add((g, 32 * int(gen.integers(-(-lens[g] // 32)))))
+        return lambda g, w0: (g, w0) in picks
+
+    kw = dict(p_mode="direct")
+    nq = S + T
+    picks = some([nq], 4)
+    last = ((S + te - 1) // 32) * 32
+    O.fp8_attn_launch(None, None, ve[0], ref[0], vde[0], n_q=nq, n_kv=S + te, q_valid=S + te, ambiguous=amb[0],
+                      wave_filter=lambda g, w0: picks(g, w0) or w0 == last, wave_operands=hooks[0], **kw)
+    hl = torch.tensor([1], dtype=torch.int32, device=dev())
+    keep_q, drop_q = ops.coreset_select(q[0], geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T, head_list=hl)
+    keep_k = keep_q if model == "wan" else ops.coreset_select(k[0], geom.latent, geom.group, geom.n_keep, tail_first=S,
+                                                              n_tail=te, head_list=hl, want_drop=False)[0]
+    nql = geom.S_low + T
+    picks = some([nql], 4)
+    O.fp8_attn_launch(None, None, ve[1], ref[1], vde[1], n_q=nql, n_kv=geom.S_low + te, q_valid=geom.S_low + te,
+                      q_rows=keep_q[0].cpu().numpy(), kv_rows=keep_k[0].cpu().numpy(), dup_rows=drop_q[0].cpu().numpy(),
+                      n_dup_pos=geom.G, ambiguous=amb[1], wave_filter=lambda g, w0: picks(g, w0) or w0 == 0,
+                      wave_operands=hooks[1], **kw)
+    q_rows, kv_rows, n_kv, table, n_lists = geom.sta_launch_tables(te, 256)
+    qr, kr, tb = q_rows.cpu().numpy(), kv_rows.cpu().numpy(), table.cpu().numpy()
+    bounds = [(int(tb[tb[:, 0] == g, 1].min()), int(tb[tb[:, 0] == g, 2].max())) for g in range(n_lists)]
+    O.fp8_attn_launch(None, None, ve[2], ref[2], vde[2], n_q=S, n_kv=n_kv, q_rows=qr, kv_rows=kr, q_group_bounds=bounds,
+                      ambiguous=amb[2], wave_filter=some([b[1] - b[0] for b in bounds], 10), wave_operands=hooks[2], **kw)
+    if T:
+        O.fp8_attn_launch(None, None, ve[2], ref[2], vde[2], n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te, n_splits=1,
+                          ambiguous=amb[2], wave_filter=lambda g, w0: w0 in (0, 64), wave_operands=hooks[2], **kw)
+    o = out[0].float().cpu().numpy()
+    vmax = F._vmax(ve, vde)
+    for h in range(3):
+        sel = ~np.isnan(amb[h])
+        assert sel.sum() >= 32 * 4, (h, sel.sum())
+        F._check(torch.from_numpy(o[h][sel]), ref[h][sel], dtype, amb[h][sel], vmax)
+    if T:
+        assert torch.all(out[0, :, S + te:] == 0)
