@@ -391,9 +391,20 @@ class VWire:
         dev = lay.device
         self.buf = buf  # (rows_total, D) uint8 receive buffer = the v8 operand of the attention kernels
         self.amax = torch.zeros((lay.H, lay.D), dtype=torch.float32, device=dev)
-        self.descale_all = torch.zeros((lay.Hv, lay.D), dtype=torch.float32, device=dev)  # in head_order
-        self.stage = torch.empty((lay.Hv, lay.Sl, lay.D), dtype=torch.uint8, device=dev)
+        # layouts of one slot count share this state, and with heads split by query range their total slot counts differ
+        # from layer to layer: room for two extra parts per rank (`split_placement` max_parts), views sized by the layer's
+        cap = lay.H + 2 * lay.P
+        self._descale_all = torch.zeros((cap, lay.D), dtype=torch.float32, device=dev)
+        self._stage = torch.empty((cap, lay.Sl, lay.D), dtype=torch.uint8, device=dev)
         self.lay = lay
+
+    @property
+    def descale_all(self) -> torch.Tensor:  # (slots of the current layout, D), in head_order
+        return self._descale_all[:self.lay.Hv]
+
+    @property
+    def stage(self) -> torch.Tensor:
+        return self._stage[:self.lay.Hv]
 
     def descale(self, g0: int, g1: int) -> torch.Tensor:
         """v_descale rows of the local head slots [g0, g1)"""
