@@ -791,3 +791,38 @@ def test_routed_vs_native_attention_operator_psnr(mix):
           f"whole op {psnr(out, ref):.2f} dB; per expert {dict((n, round(p, 2)) for n, p in per.items())}")
     assert per["full"] > 100.0  # the same kernel on the same heads
     assert 5.0 < per["coreset"] < 60.0 and 5.0 < per["sliding-tile"] < 60.0
+
+
+@pytest.mark.parametrize("precision", [False, "i8pv", True])
+def test_full_attention_head_split_by_query_range(precision):
+    """HeadRouting.partials (sequence parallelism below whole heads, ulysses/engine.py split_placement): a full-attention
+    head that computes only the query tokens [t0, t1) here -- an extra dense segment of the fused launch -- writes exactly
+    the rows the whole head writes there, bit for bit (ranges on 32-token boundaries keep every wave's rows together), and
+    leaves the head's other rows alone; with and without a row map (the zero-copy Ulysses layout), 16-bit, int8-score, e4m3."""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.bfloat16
+    latent, tile, window, group = (8, 12, 16), (2, 6, 8), (3, 3, 3), (2, 3, 2)
+    S = latent[0] * latent[1] * latent[2]
+    H = 5
+    experts = [0, 2, 0, 1, 0]
+    rng = np.random.default_rng(31)
+    q, k, v = (to_dev(rng.standard_normal((1, H, S, 128)), dtype) for _ in range(3))
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    kw = dict(model="wan", fp8=precision)
+    whole = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, **kw)
+    ranges = {2: (0, 416), 4: (1120, S)}
+    out = torch.full_like(whole, 7.0)
+    route = HeadRouting.from_expert_ids(experts, dev(), q_ranges=ranges)
+    assert route.counts_host == [1, 1, 1] and len(route.partials) == 2
+    routed_attention(q, k, v, route, geom, out=out, **kw)
+    torch.cuda.synchronize()
+    for h in range(H):
+        t0, t1 = ranges.get(h, (0, S))
+        assert torch.equal(out[0, h, t0:t1], whole[0, h, t0:t1]), (precision, h)
+        rest = torch.cat([out[0, h, :t0], out[0, h, t1:]])
+        assert torch.all(rest == 7.0), (precision, h)
+    with pytest.raises(ValueError):  # only full-attention heads split
+        HeadRouting.from_expert_ids(experts, dev(), q_ranges={1: (0, 64)})
+    with pytest.raises(ValueError):  # and only where the sequence has no text tokens
+        routed_attention(torch.cat([q, q[:, :, :64]], 2), torch.cat([k, k[:, :, :64]], 2), torch.cat([v, v[:, :, :64]], 2),
+                         route, geom, model="hunyuan", text_len=64, text_valid=40, fp8=precision)

@@ -240,13 +240,13 @@ def _split_worker(rank, world, port, ret):
     import vorta_amd.ulysses.engine as E
     from vorta_amd.ulysses import UlyssesLayout, exchange_selfcheck, slot_groups, split_placement, placement_loads
     P = world
-    S, T, D = 64 * world, 0, 8
+    S, T, D = 512 * world, 0, 8
     H = 2 * world + 1
     experts = ([0, 0, 0, 2, 1, 2, 2, 1, 2] * H)[:H]  # three full-attention heads: whole heads cannot balance 2 or 4 ranks
     cost = [9.0, 2.0, 1.0]
     res = {}
     for groups in (1, 2):
-        order, counts, parts = split_placement(experts, cost, P, S, groups, align=4, tol=0.005)
+        order, counts, parts = split_placement(experts, cost, P, S, groups, align=32, tol=0.005)
         n_extra = sum(counts) - H
         loads = placement_loads(experts, cost, order, counts, parts, S)
         res[("extra", groups)] = n_extra
@@ -259,7 +259,7 @@ def _split_worker(rank, world, port, ret):
             r = exchange_selfcheck(lay, order, sg, bufs, parts=parts)
             res[(groups, transport, "ok")] = r["ok"]
             # the same exchange told that every slot is whole must lose the rows only the other part returned
-            wrong = [None if p is None else (p[0], max(p[0] + 4, p[1] - 4)) for p in parts]
+            wrong = [None if p is None else (p[0], max(p[0] + 32, p[1] - 32)) for p in parts]
             bufs = [lay.new_buffer() for _ in range(4)]
             r = exchange_selfcheck(lay, order, sg, bufs, parts=wrong)
             res[(groups, transport, "wrong ranges")] = r["ok"]
@@ -277,7 +277,7 @@ def test_heads_split_by_query_range_round_trip(world):
         res = ret[r]
         for groups in (1, 2):
             assert res[("extra", groups)] >= 1, res            # the mix needs at least one split
-            assert res[("ratio", groups)] <= 1.03, res  # (4-token steps of a 64-token shard are coarse)
+            assert res[("ratio", groups)] <= 1.03, res  # (32-token steps of a 512-token shard are coarse)
             for transport in ("a2a", "p2p"):
                 assert res[(groups, transport, "ok")] is True, (r, groups, transport)
                 assert res[(groups, transport, "wrong ranges")] is False, (r, groups, transport)

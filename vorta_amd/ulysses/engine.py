@@ -124,6 +124,10 @@ def split_placement(experts: Sequence[int], cost_of_expert: Sequence[float], P: 
     order lists a split head once per part -- rank j owns order[sum(counts[:j]) : sum(counts[:j + 1])], sum(counts) =
     H + number of extra parts -- and parts[i] = None for a whole head or (t0, t1), the query tokens slot i computes.
     Deterministic."""
+    if align % 32 or not 1 <= max_parts <= 2:
+        # a wave = 32 consecutive query positions shares reference-point decisions (and, with int8 scores, its query scale):
+        # ranges on 32-token boundaries keep every wave's rows together, so a split head is the whole head bit for bit
+        raise ValueError("split_placement: `align` must be a multiple of 32 tokens, `max_parts` 1 or 2")
     order, counts = balanced_placement(experts, cost_of_expert, P, 1, max_heads)
     starts = [sum(counts[:j]) for j in range(P + 1)]
     bins = [list(order[starts[j]:starts[j + 1]]) for j in range(P)]
