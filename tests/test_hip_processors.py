@@ -449,16 +449,28 @@ def _sp_worker(rank, world, port, ret):
             part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
             err = max(err, float((part.float() - ref[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item()))
             counts |= {k[-1] for k in _sp._LAYOUTS if isinstance(k[-1], tuple)}
+    # below whole heads: a full-attention head computes a range of its queries on each rank (VORTA_SP_PLACEMENT=split); the
+    # shard must still be the single-process one bit for bit
+    splits = 0
+    for sc, ref in ((score, full), (score2, full2)):
+        for groups in (1, 2):
+            _sp.SP_PLACEMENT, _sp.SP_GROUPS = "split", groups
+            _sp._LAYOUTS.clear(); _sp._BUFFERS.clear(); _sp._ROUTINGS.clear()
+            part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
+            err = max(err, float((part.float() - ref[:, rank * Sl:(rank + 1) * Sl].float()).abs().max().item()))
+            splits += sum(1 for k in _sp._LAYOUTS if isinstance(k[-1], tuple) and sum(k[-1]) > k[0])
     _sp.SP_PLACEMENT, _sp.SP_GROUPS = "uneven", 1
-    ret[rank] = err if (2, 4) in counts else -1.0  # (-1: the skewed route did not give unequal head counts)
+    ok = (2, 4) in counts and splits > 0  # (the skewed route gave unequal head counts; some route gave a split head)
+    ret[rank] = err if ok else -1.0
     dist.barrier()
     SP_STATE.cleanup()
 
 
 def test_processor_under_sequence_parallel_rehearsal():
     """2 ranks sharing this GPU (gloo, host-staged messages): the SP branch of the processor returns exactly
-    the sequence shard of the single-process result -- with H/P heads on every rank and with head counts that follow the
-    routes (`balanced_placement`), one and two slot groups."""
+    the sequence shard of the single-process result -- with H/P heads on every rank, with head counts that follow the
+    routes (`balanced_placement`) and with full-attention heads split by query range (`split_placement`), one and two
+    slot groups."""
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

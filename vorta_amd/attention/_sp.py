@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..routed import HeadRouting, geometry_for, routed_attention
 from ..ulysses import SP_STATE
-from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balanced_placement, exchange_and_attend,
+from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balanced_placement, exchange_and_attend, split_placement,
                               slot_groups)
 
 _LAYOUTS = {}
@@ -26,7 +26,9 @@ SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
 # head placement: "uneven" (default) = the ranks' head counts follow the layer's routes (ulysses/engine.py
 # balanced_placement: whole heads are a coarse unit when H/P is small and the mix is skewed -- 24 heads with 4 full-attention
 # ones on 8 ranks: heaviest rank 1.33 of the mean cost with 3 heads each, 1.02 with 1 + ... + 5; identical to "even" when
-# the routes are balanced); "even" = H/P heads on every rank (A/B)
+# the routes are balanced); "even" = H/P heads on every rank (A/B); "split" = uneven, then full-attention heads give a range
+# of their queries to the lightest ranks until the heaviest is within 1 % of the mean (`split_placement`; sequences without
+# text tokens, i.e. Wan: Hunyuan layers fall back to "uneven")
 SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "uneven")
 
 
@@ -79,15 +81,17 @@ def _layout(H, S, T, D, device, dtype, counts=None):
     return lay, _BUFFERS[bkey]
 
 
-def _routing(local_experts: tuple, device) -> HeadRouting:
+def _routing(local_experts: tuple, device, q_ranges: tuple = ()) -> HeadRouting:
     """HeadRouting.from_expert_ids builds a CPU tensor and copies it to the device (a host stall per layer on the
-    sequence-parallel path): cached per distinct local expert tuple (at most 3^(H/P) of them, a handful in practice)."""
-    key = (local_experts, str(device))
+    sequence-parallel path): cached per distinct local expert tuple (at most 3^(H/P) of them, a handful in practice).
+    `q_ranges`: ((slot, t0, t1), ...) for full-attention heads that compute a range of their queries here (placement 'split')"""
+    key = (local_experts, str(device), q_ranges)
     r = _ROUTINGS.get(key)
     if r is None:
         if len(_ROUTINGS) > 4096:
             _ROUTINGS.clear()
-        r = _ROUTINGS[key] = HeadRouting.from_expert_ids(list(local_experts), device)
+        r = _ROUTINGS[key] = HeadRouting.from_expert_ids(list(local_experts), device,
+                                                         q_ranges={i: (t0, t1) for i, t0, t1 in q_ranges} or None)
     return r
 
 
@@ -127,7 +131,14 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
         cost = [float(S + te) ** 2, float(s_low + te) ** 2, float(S) * n_kv]
     # VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot
     # groups (as equal as Hl allows), so the exchange of one group overlaps the attention of another
-    if SP_PLACEMENT == "uneven" and H >= P:
+    parts = None
+    if SP_PLACEMENT == "split" and H >= P and T == 0 and not dense_only:
+        # below whole heads: full-attention heads give a range of their queries to the lightest ranks (sequences without
+        # text tokens; ulysses/engine.py split_placement)
+        order, counts, parts = split_placement(experts, cost, P, S, SP_GROUPS, align=256 if S >= 32768 else 32)
+        if not any(x is not None for x in parts):
+            parts = None
+    elif SP_PLACEMENT in ("uneven", "split") and H >= P:
         order, counts = balanced_placement(experts, cost, P, SP_GROUPS)
     else:
         order, counts = balanced_head_order(experts, cost, P, min(SP_GROUPS, H // P)), [H // P] * P
@@ -141,6 +152,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     qv, kv, vv, ov = (lay.head_view(b) for b in bufs)
     me = SP_STATE.group_local_rank
     local = [experts[h] for h in order[lay.starts[me]:lay.starts[me + 1]]]
+    local_parts = [None] * len(local) if parts is None else parts[lay.starts[me]:lay.starts[me + 1]]
+    ranges_of = lambda g0, g1: tuple((i - g0,) + tuple(local_parts[i]) for i in range(g0, g1) if local_parts[i] is not None)
     rm = lay.row_map
 
     # the precision switch (set_attention_precision / VORTA_ATTENTION_PRECISION) is about the ROUTED operator; dense
@@ -165,7 +178,7 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
             ops.attn_fwd(qv[g0:g1], kv[g0:g1], vv[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
                          q_rows=rm[:S + T], kv_rows=rm[:S + te])
         else:
-            routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], _routing(tuple(local[g0:g1]), q.device), geom,
+            routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], _routing(tuple(local[g0:g1]), q.device, ranges_of(g0, g1)), geom,
                              model=model, text_len=T, text_valid=te, out=ov[g0:g1], fp8=False, fp8_views=views)
 
     sg = slot_groups(lay.Hl, groups)
@@ -175,13 +188,13 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
         if not dense_only:
             geom.prebuild(te if model == "hunyuan" else 0)
             for g0, g1 in sg:
-                _routing(tuple(local[g0:g1]), q.device)
+                _routing(tuple(local[g0:g1]), q.device, ranges_of(g0, g1))
 
     # the received heads are written straight into the (1, N, H, D) result the output projection reads
     buf = torch.empty((1, N, H, D), dtype=q.dtype, device=q.device)
     exchange_and_attend(lay, shards, bufs, order, texts, sg, attend,
                         buf[0, :Sl].transpose(0, 1), buf[0, Sl:].transpose(0, 1) if T else None, vwire=vwire,
-                        prepare=prepare)
+                        prepare=prepare, parts=parts)
     return buf
 
 
