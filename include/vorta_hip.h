@@ -126,7 +126,10 @@ typedef struct vorta_attn_args {
 } vorta_attn_args;
 
 int vorta_attn_fwd(const vorta_attn_args* args, void* hip_stream);
-/* Up to 4 launches fused into ONE grid (the experts of a routed layer, hunyuan.py:564-591): workgroups are
+#define VORTA_MAX_FUSED_LAUNCHES 6 /* (was 4 before round 4; more -> VORTA_EINVAL) */
+/* Up to VORTA_MAX_FUSED_LAUNCHES launches fused into ONE grid (the experts of a routed layer, hunyuan.py:564-591, the text
+ * queries of the sliding-tile expert, and -- under sequence parallelism -- up to two full-attention heads that compute
+ * only a range of their queries on this rank: q_rows = a slice of the row map, n_heads = 1): workgroups are
  * dispatched in argument order -- pass the longest key loops first -- so one expert's tail is filled by the next
  * expert instead of idling until a kernel boundary.  Every entry must resolve to the 256-row pipelined kernel
  * (VORTA_EUNSUPPORTED otherwise: launch those separately); split-key entries get their merge kernels after. */

@@ -67,7 +67,7 @@ __device__ __forceinline__ int live_order(const Params& p, int b, int n, bool re
 }
 
 #ifndef VORTA_MAX_SEGMENTS
-#define VORTA_MAX_SEGMENTS 6
+#define VORTA_MAX_SEGMENTS VORTA_MAX_FUSED_LAUNCHES /* include/vorta_hip.h */
 #endif
 constexpr int MAX_SEGMENTS = VORTA_MAX_SEGMENTS;  // launches fused into one grid (vorta_attn_fwd_batch): three experts, the text queries or up to
                                  // two partial full-attention heads of a sequence-parallel rank (ulysses/engine.py split_placement)

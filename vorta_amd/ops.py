@@ -278,7 +278,7 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tenso
     # `ws` may be released now: the caching allocator is stream ordered and the launch is on this stream
 
 
-MAX_FUSED = 6  # csrc/attn_common.h MAX_SEGMENTS (the library refuses more with VORTA_EINVAL)
+MAX_FUSED = 6  # include/vorta_hip.h VORTA_MAX_FUSED_LAUNCHES (the library refuses more with VORTA_EINVAL)
 
 
 def attn_fwd_batch(calls) -> None:
