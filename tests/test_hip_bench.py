@@ -129,13 +129,14 @@ def test_bench_two_rank_rehearsal_with_heads_split_by_query_range():
     (the per-head scales are taken over the whole head on both ranks)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    base = [sys.executable, "bench.py", "--gpus", "2", "--config", "wan-tiny", "--steps", "1", "--warmup", "1",
-            "--no-cpu-baseline", "--no-gemm-ceiling"]
-    for dtype in ("bf16", "fp8", "i8pv"):
+    base = [sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-gemm-ceiling"]
+    # wan-tiny: no text tokens; tiny: the Hunyuan form (64 text rows behind the video: the part of a split head that ends at
+    # the last video token answers its text queries)
+    for config, dtype in (("wan-tiny", "bf16"), ("wan-tiny", "fp8"), ("wan-tiny", "i8pv"), ("tiny", "bf16"), ("tiny", "i8pv")):
         fps = {}
         for placement in ("uneven", "split"):
-            r = subprocess.run(base + ["--dtype", dtype, "--placement", placement], cwd=ROOT, env=env, capture_output=True,
-                               text=True, timeout=900)
+            r = subprocess.run(base + ["--config", config, "--dtype", dtype, "--placement", placement], cwd=ROOT, env=env,
+                               capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, (dtype, placement, r.stdout[-1500:], r.stderr[-3000:])
             j = _line(r.stdout)
             assert j["exchange_selfcheck"]["ok"] is True
@@ -145,7 +146,7 @@ def test_bench_two_rank_rehearsal_with_heads_split_by_query_range():
                 assert "split head placement" in par and "extra parts" in par and "split by query range: 0 extra" not in par, par
                 ratio = float(par.split("worst layer: ")[1].split(";")[0])
                 assert ratio <= 1.02, par
-        assert fps["uneven"] == fps["split"] != 0, (dtype, fps)
+        assert fps["uneven"] == fps["split"] != 0, (config, dtype, fps)
 
 
 def test_bench_three_rank_rehearsal_heads_not_divisible():

@@ -823,6 +823,17 @@ def test_full_attention_head_split_by_query_range(precision):
         assert torch.all(rest == 7.0), (precision, h)
     with pytest.raises(ValueError):  # only full-attention heads split
         HeadRouting.from_expert_ids(experts, dev(), q_ranges={1: (0, 64)})
-    with pytest.raises(ValueError):  # and only where the sequence has no text tokens
-        routed_attention(torch.cat([q, q[:, :, :64]], 2), torch.cat([k, k[:, :, :64]], 2), torch.cat([v, v[:, :, :64]], 2),
-                         route, geom, model="hunyuan", text_len=64, text_valid=40, fp8=precision)
+    # with text tokens behind the video (Hunyuan): the part that ends at the last video token also answers the text queries
+    T, te = 64, 40
+    qt, kt, vt = (torch.cat([x, x[:, :, :T].flip(2)], 2).contiguous() for x in (q, k, v))
+    kw = dict(model="hunyuan", text_len=T, text_valid=te, fp8=precision)
+    whole = routed_attention(qt, kt, vt, HeadRouting.from_expert_ids(experts, dev()), geom, **kw)
+    out = torch.full_like(whole, 7.0)
+    routed_attention(qt, kt, vt, route, geom, out=out, **kw)
+    torch.cuda.synchronize()
+    for h in range(H):
+        t0, t1 = ranges.get(h, (0, S))
+        e1 = S + T if t1 == S else t1
+        assert torch.equal(out[0, h, t0:e1], whole[0, h, t0:e1]), (precision, h)
+        rest = torch.cat([out[0, h, :t0], out[0, h, e1:]])
+        assert torch.all(rest == 7.0), (precision, h)

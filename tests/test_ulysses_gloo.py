@@ -240,29 +240,30 @@ def _split_worker(rank, world, port, ret):
     import vorta_amd.ulysses.engine as E
     from vorta_amd.ulysses import UlyssesLayout, exchange_selfcheck, slot_groups, split_placement, placement_loads
     P = world
-    S, T, D = 512 * world, 0, 8
+    S, D = 512 * world, 8
     H = 2 * world + 1
     experts = ([0, 0, 0, 2, 1, 2, 2, 1, 2] * H)[:H]  # three full-attention heads: whole heads cannot balance 2 or 4 ranks
     cost = [9.0, 2.0, 1.0]
     res = {}
-    for groups in (1, 2):
+    for gk, T in ((1, 0), (2, 0), (11, 6), (12, 6)):  # 1x: six text rows behind every head's video rows (owner: the last part)
+        groups = gk % 10
         order, counts, parts = split_placement(experts, cost, P, S, groups, align=32, tol=0.005)
         n_extra = sum(counts) - H
         loads = placement_loads(experts, cost, order, counts, parts, S)
-        res[("extra", groups)] = n_extra
-        res[("ratio", groups)] = max(loads) * P / sum(loads)
+        res[("extra", gk)] = n_extra
+        res[("ratio", gk)] = max(loads) * P / sum(loads)
         lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.bfloat16, counts=counts)
         sg = slot_groups(lay.Hl, min(groups, min(lay.counts)))
         for transport in ("a2a", "p2p"):
             E.TRANSPORT = transport
             bufs = [lay.new_buffer() for _ in range(4)]
             r = exchange_selfcheck(lay, order, sg, bufs, parts=parts)
-            res[(groups, transport, "ok")] = r["ok"]
+            res[(gk, transport, "ok")] = r["ok"]
             # the same exchange told that every slot is whole must lose the rows only the other part returned
-            wrong = [None if p is None else (p[0], max(p[0] + 32, p[1] - 32)) for p in parts]
+            wrong = [None if p is None else (min(p[0] + 32, p[1] - 32), p[1]) for p in parts]
             bufs = [lay.new_buffer() for _ in range(4)]
             r = exchange_selfcheck(lay, order, sg, bufs, parts=wrong)
-            res[(groups, transport, "wrong ranges")] = r["ok"]
+            res[(gk, transport, "wrong ranges")] = r["ok"]
     E.TRANSPORT = "a2a"
     ret[rank] = res
     dist.barrier()
@@ -275,7 +276,7 @@ def test_heads_split_by_query_range_round_trip(world):
     mp.spawn(_split_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):
         res = ret[r]
-        for groups in (1, 2):
+        for groups in (1, 2, 11, 12):  # (1x: with 6 text rows per head)
             assert res[("extra", groups)] >= 1, res            # the mix needs at least one split
             assert res[("ratio", groups)] <= 1.03, res  # (32-token steps of a 512-token shard are coarse)
             for transport in ("a2a", "p2p"):

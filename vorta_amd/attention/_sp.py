@@ -27,8 +27,7 @@ SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
 # balanced_placement: whole heads are a coarse unit when H/P is small and the mix is skewed -- 24 heads with 4 full-attention
 # ones on 8 ranks: heaviest rank 1.33 of the mean cost with 3 heads each, 1.02 with 1 + ... + 5; identical to "even" when
 # the routes are balanced); "even" = H/P heads on every rank (A/B); "split" = uneven, then full-attention heads give a range
-# of their queries to the lightest ranks until the heaviest is within 1 % of the mean (`split_placement`; sequences without
-# text tokens, i.e. Wan: Hunyuan layers fall back to "uneven")
+# of their queries to the lightest ranks until the heaviest is within 1 % of the mean (`split_placement`)
 SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "uneven")
 
 
@@ -132,9 +131,9 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     # VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot
     # groups (as equal as Hl allows), so the exchange of one group overlaps the attention of another
     parts = None
-    if SP_PLACEMENT == "split" and H >= P and T == 0 and not dense_only:
-        # below whole heads: full-attention heads give a range of their queries to the lightest ranks (sequences without
-        # text tokens; ulysses/engine.py split_placement)
+    if SP_PLACEMENT == "split" and H >= P and not dense_only:
+        # below whole heads: full-attention heads give a range of their queries to the lightest ranks (ulysses/engine.py
+        # split_placement; the part that ends at the last video token keeps the head's text queries)
         order, counts, parts = split_placement(experts, cost, P, S, SP_GROUPS, align=256 if S >= 32768 else 32)
         if not any(x is not None for x in parts):
             parts = None

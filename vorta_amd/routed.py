@@ -282,16 +282,18 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                               q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
                               flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H)))
         for hl, t0, t1 in routing.partials or ():
-            # a head whose other query tokens another rank computes: every key, the query rows [t0, t1)
-            if T > 0 or not (0 <= t0 < t1 <= S):
-                raise ValueError("a query range needs a sequence without text tokens and 0 <= t0 < t1 <= S")
-            part = dict(base, out=o_e[0], n_q=t1 - t0, n_kv=S, q_valid=t1 - t0, tag="full_part",
-                        kv_rows=None if rm is None else rm[:S], flops=4.0 * (t1 - t0) * S * D,
+            # a head whose other query tokens another rank computes: every key, the query rows [t0, t1) of the VIDEO tokens;
+            # the part that ends at the last video token also owns the head's text queries (they follow it in token order)
+            if not (0 <= t0 < t1 <= S):
+                raise ValueError(f"query range [{t0}, {t1}) outside the {S} video tokens")
+            e1, v1 = (S + T, S + te) if (t1 == S and T > 0) else (t1, t1)
+            part = dict(base, out=o_e[0], n_q=e1 - t0, n_kv=S + te, q_valid=v1 - t0, tag="full_part",
+                        kv_rows=None if rm is None else rm[:S + te], flops=4.0 * (v1 - t0) * (S + te) * D,
                         head_list=hl, n_heads=1, n_heads_dev=None)
             if rm is None:
                 part.update(q_row_offset=t0)
             else:
-                part.update(q_rows=rm[t0:t1])
+                part.update(q_rows=rm[t0:e1])
             calls.append(part)
         return calls
 

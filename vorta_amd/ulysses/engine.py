@@ -122,8 +122,9 @@ def split_placement(experts: Sequence[int], cost_of_expert: Sequence[float], P: 
     P = 8 (five heads per rank, costs 5.6 : 1.4 : 1) goes from 1.037 of the mean to <= 1.01.  A rank holds at most
     `max_parts` partial heads (each is one more segment of its fused launch).  Returns (order, counts, parts): the head
     order lists a split head once per part -- rank j owns order[sum(counts[:j]) : sum(counts[:j + 1])], sum(counts) =
-    H + number of extra parts -- and parts[i] = None for a whole head or (t0, t1), the query tokens slot i computes.
-    Deterministic."""
+    H + number of extra parts -- and parts[i] = None for a whole head or (t0, t1), the VIDEO query tokens slot i computes;
+    the part that ends at the last video token (t1 == n_tokens) also answers the head's text queries, which follow the
+    video in token order.  Deterministic."""
     if align % 32 or not 1 <= max_parts <= 2:
         # a wave = 32 consecutive query positions shares reference-point decisions (and, with int8 scores, its query scale):
         # ranges on 32-token boundaries keep every wave's rows together, so a split head is the whole head bit for bit
@@ -317,6 +318,8 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
                 keep = torch.zeros(S, dtype=torch.bool, device=dev)
                 keep[t0:t1] = True
                 o_i[lay.row_map[:S].long()[~keep]] = 0
+                if T and t1 != S:  # only the part that ends at the last video token answers the text queries
+                    o_i[lay.row_map[S:S + T].long()] = 0
 
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
@@ -441,9 +444,9 @@ class UlyssesLayout:
                 raise ValueError(f"heads {H} and sequence {S} must be divisible by the sequence-parallel size {P}")
             counts = [H // P] * P
         counts = [int(c) for c in counts]
-        if len(counts) != P or sum(counts) < H or min(counts) < 1 or (sum(counts) > H and T > 0):
+        if len(counts) != P or sum(counts) < H or min(counts) < 1:
             raise ValueError(f"head counts {counts} do not place {H} heads on {P} ranks (at least one each; more slots than "
-                             "heads = heads split by query range, `split_placement`: sequences without text only)")
+                             "heads = heads split by query range, `split_placement`)")
         self.H, self.S, self.T, self.D, self.P, self.rank = H, S, T, D, P, rank
         self.Hv = sum(counts)  # head slots over all ranks: H, + one per extra part of a head split by query range
         self.counts = counts
@@ -773,7 +776,14 @@ class UlyssesLayout:
                     extra.append((i, h, r0, r1))
             if min(slot_of) < 0:
                 raise ValueError("the parts of a split head do not cover this rank's tokens")
-            state.update(parts=list(parts), slot_of=slot_of, extra=extra)
+            # the text rows of a head come from the part that ends at the last video token (it owns the text queries)
+            text_slot = [-1] * self.H
+            for i, (h, pr) in enumerate(zip(head_order, parts)):
+                if pr is None or pr[1] == self.S:
+                    text_slot[h] = i
+            if self.T and min(text_slot) < 0:
+                raise ValueError("no part of a split head ends at the last video token (the owner of its text rows)")
+            state.update(parts=list(parts), slot_of=slot_of, extra=extra, text_slot=text_slot)
         return state
 
     def gather_heads_start(self, buf: torch.Tensor, state, slots: Optional[Sequence[int]] = None, gi: int = 0,
@@ -836,7 +846,12 @@ class UlyssesLayout:
                 allh = torch.cat([local[torch.arange(c, device=local.device) % Hl] for c in self.counts], dim=0)
             else:
                 allh = torch.cat([parts[j][:self.counts[j]] for j in range(self.P)], dim=0)  # (H, T, D) in head_order
-            if out_text.is_cuda and HIP_STAGING:
+            if state["parts"] is not None:  # slots -> heads by the text owner of every head
+                if out_text.is_cuda and HIP_STAGING:
+                    ops.permute_heads([allh], [out_text], src_map=self._head_map(state["text_slot"]))
+                else:
+                    out_text.copy_(allh[torch.as_tensor(state["text_slot"], device=out_text.device)])
+            elif out_text.is_cuda and HIP_STAGING:
                 ops.permute_heads([allh], [out_text], dst_map=self._head_map(head_order))
             else:
                 out_text[torch.as_tensor(list(head_order), device=out_text.device)] = allh
@@ -889,8 +904,6 @@ class UlyssesRoutedAttention:
         from ..routed import HeadRouting
         if placement not in ("even", "uneven", "split"):
             raise ValueError("placement is 'even', 'uneven' or 'split'")
-        if placement == "split" and cfg["text"]:
-            raise ValueError("placement 'split' (heads split by query range) is for sequences without text tokens")
         if heaviest_rank and not loopback:
             raise ValueError("heaviest_rank is an emulation mode (loopback)")
         self.fp8 = fp8
