@@ -322,7 +322,7 @@ def main():
                          "ranks' head counts follow the layer's routes (LPT on the expert costs alone); auto (default): even "
                          "when N divides the heads (one receive layout for every layer; identical to uneven on the uniform "
                          "mix), uneven otherwise; split: uneven, then full-attention heads give a range of their QUERIES to the "
-                         "lightest ranks until the heaviest is within 1 %% of the mean (sequences without text tokens)")
+                         "lightest ranks until the heaviest is within 1 %% of the mean")
     ap.add_argument("--conservative", action="store_true",
                     help="N>1 fallback: --placement even --sp-groups 1, one all_to_all_single per tensor "
                          "(VORTA_SP_TRANSPORT=a2a), v exchanged in 16 bits -- the oldest, most exercised form of the exchange")
