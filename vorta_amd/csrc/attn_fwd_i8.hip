@@ -610,7 +610,12 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #ifdef VORTA_I8_DIAG_ALLX  /* every wave in the first role (no ping-pong) */
 #define ROLE_Y_ false
 #else
-#define ROLE_Y_ (NW == 8 && wave >= NW / 2)
+// which half of the workgroup starts its steps with the VALU part (the e4m3 kernel measured 0-3.6 % between the two, by body:
+// attn_fwd_fp8.hip VORTA_MULTI_SWAP): -DVORTA_I8_SWAP=1 = the earlier-dispatched half
+#ifndef VORTA_I8_SWAP
+#define VORTA_I8_SWAP 0
+#endif
+#define ROLE_Y_ (NW == 8 && (VORTA_I8_SWAP ? wave < NW / 2 : wave >= NW / 2))
 #endif
   // both roles request their tile pieces inside their VALU part (role X behind its matrix part: it goes from the barrier
   // straight into its MFMAs); the 4-wave kernels (no roles) and waves past the query rows request at the top of the step
