@@ -323,6 +323,10 @@ def main():
                          "when N divides the heads (one receive layout for every layer; identical to uneven on the uniform "
                          "mix), uneven otherwise; split: uneven, then full-attention heads give a range of their QUERIES to the "
                          "lightest ranks until the heaviest is within 1 %% of the mean")
+    ap.add_argument("--kv-splits", default="1",
+                    help="N>1: 1 (default), a number, or 'auto': cut the keys of the full-attention / coreset launches of a rank "
+                         "whose heads leave the chip under one round of workgroups (small models on many ranks); changes the "
+                         "summation order, so never on by default")
     ap.add_argument("--conservative", action="store_true",
                     help="N>1 fallback: --placement even --sp-groups 1, one all_to_all_single per tensor "
                          "(VORTA_SP_TRANSPORT=a2a), v exchanged in 16 bits -- the oldest, most exercised form of the exchange")
@@ -451,7 +455,8 @@ def main():
         sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, rank, P,
                                             concurrent=concurrent, fused=fused, sliding_block_rows=args.sliding_block_rows,
                                             groups=args.sp_groups, loopback=bool(emu), fp8=fp8, v_wire=not args.no_v_wire,
-                                            placement=args.placement, heaviest_rank=bool(emu))
+                                            placement=args.placement, heaviest_rank=bool(emu),
+                                            kv_splits=args.kv_splits if args.kv_splits == "auto" else int(args.kv_splits))
 
         def one_step():
             for _ in range(cfg["fwd_per_step"]):
@@ -579,6 +584,7 @@ def main():
                    "parallelism": "single GPU" if P == 1 else (f"heaviest rank (layer by layer) of ulysses sp{P}, emulated on one GPU, no transfers"
                                                                if emu else f"ulysses sp{P} (RCCL all-to-all over xGMI)")
                    + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else "")
+                   + (f", key splits {args.kv_splits} (per layer: {sorted(set(sp.kv_splits))})" if P > 1 and args.kv_splits != "1" else "")
                    + (f", {args.placement} head placement (heaviest rank / mean cost, worst layer: "
                       f"{max(sp.max_over_mean):.3f}"
                       + (f"; heads split by query range: {sum(len(x) - H for x in sp.orders)} extra parts over {L} layers"

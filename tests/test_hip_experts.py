@@ -837,3 +837,29 @@ def test_full_attention_head_split_by_query_range(precision):
         assert torch.equal(out[0, h, t0:e1], whole[0, h, t0:e1]), (precision, h)
         rest = torch.cat([out[0, h, :t0], out[0, h, e1:]])
         assert torch.all(rest == 7.0), (precision, h)
+
+
+@pytest.mark.parametrize("precision", [False, "i8pv"])
+def test_routed_attention_with_key_splits(precision):
+    """routed_attention(kv_splits=n): the full-attention and coreset launches cut their keys into n parts + a merge kernel (for
+    sequence-parallel ranks whose few heads leave the chip under one round of workgroups): the same layer within the
+    16-bit tolerance (the summation order differs), untouched sliding-tile heads bit for bit."""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    dtype = torch.bfloat16
+    latent, tile, window, group = (8, 12, 16), (2, 6, 8), (3, 3, 3), (2, 3, 2)
+    S = latent[0] * latent[1] * latent[2]
+    experts = [0, 2, 1, 0]
+    rng = np.random.default_rng(41)
+    q, k, v = (to_dev(rng.standard_normal((1, 4, S, 128)), dtype) for _ in range(3))
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    route = HeadRouting.from_expert_ids(experts, dev(), q_ranges={3: (512, S)})
+    one, cut = torch.full_like(q, 7.0), torch.full_like(q, 7.0)
+    routed_attention(q, k, v, route, geom, model="wan", fp8=precision, out=one)
+    routed_attention(q, k, v, route, geom, model="wan", fp8=precision, kv_splits=3, out=cut)
+    torch.cuda.synchronize()
+    assert torch.equal(cut[0, 1], one[0, 1])  # the sliding-tile head is not split
+    assert torch.all(cut[0, 3, :512] == 7.0) and torch.all(one[0, 3, :512] == 7.0)  # outside the partial head's range
+    for h in (0, 2, 3):
+        sl = slice(512, S) if h == 3 else slice(0, S)
+        d = (cut[0, h, sl].float() - one[0, h, sl].float()).abs().max().item()
+        assert d <= (3e-2 if precision else 2e-2), (precision, h, d)

@@ -4,7 +4,7 @@ set -eux
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4/split_small
 rm -rf $O && mkdir -p $O
-B="python3 bench.py --config wan1.3b-81f --emulate-rank 8 --no-gemm-ceiling --steps 3 --warmup 1"
+B="python3 bench.py --config wan1.3b-81f --emulate-rank 8 --no-gemm-ceiling --steps 3 --warmup 1 ${EXTRA:-}"
 for dt in bf16 i8pv; do
   for pl in uneven split; do
     for rep in 1 2; do

@@ -210,8 +210,8 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                      concurrent: bool = False, fused: bool = True, sliding_block_rows: int = 0,
                      expert_outs: Optional[Sequence[torch.Tensor]] = None, fp8: Optional[bool] = None,
                      fp8_operands: Optional[ops.Fp8Operands] = None,
-                     fp8_views: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None
-                     ) -> torch.Tensor:
+                     fp8_views: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+                     kv_splits: int = 1) -> torch.Tensor:
     """q,k,v: (1,H,S+T,D) [hunyuan: video then text] or (1,H,S,D) [wan].  Returns (1,H,S+T,D).
 
     hunyuan: hunyuan.py:556-605 (TripleEval.__call__ steps 5.1-5.4);  wan: wan.py:351-383.
@@ -227,7 +227,10 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     copies; the coreset ranking still reads the 16-bit q/k (coreset_select.py:98-105 ranks in the input dtype).
     fp8=None follows the process-wide default (`set_attention_precision`, VORTA_ATTENTION_PRECISION=fp8).
     fp8_views = (q8, k8, v8, v_descale): e4m3 views with the geometry of q,k,v that were converted elsewhere (the
-    sequence-parallel path converts the receive buffers once, vorta_amd/ulysses/engine.py)."""
+    sequence-parallel path converts the receive buffers once, vorta_amd/ulysses/engine.py).
+    kv_splits > 1: the full-attention and coreset launches cut their KEYS into that many parts (+ a merge kernel) -- for
+    a sequence-parallel rank whose one or two heads leave the chip under one round of workgroups, where a layer lasts as
+    long as one workgroup's key loop; changes the summation order, so it is never chosen silently."""
     if q.dim() == 4 and q.shape[0] != 1:
         # hunyuan.py:168 asserts batch 1; Wan's CFG runs two batch-1 forwards (pipeline_wan.py:322-344)
         raise AssertionError(f"Batch size {q.shape[0]} is not supported by routed_attention.")
@@ -274,11 +277,13 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
                                   video_tokens=S if rm is None and T > 0 else 0)
         base = dict(q=f8.q, k=f8.k, v=f8.v, scale=scale, v_descale=f8.v_descale)
 
+    split_kw = dict(n_splits=int(kv_splits)) if kv_splits and int(kv_splits) > 1 else {}
+
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     def expert_full():
         calls = []
         if routing.counts_host is None or routing.counts_host[0] > 0:
-            calls.append(dict(base, out=o_e[0], n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full",
+            calls.append(dict(base, out=o_e[0], n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full", **split_kw,
                               q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
                               flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H)))
         for hl, t0, t1 in routing.partials or ():
@@ -287,7 +292,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
             if not (0 <= t0 < t1 <= S):
                 raise ValueError(f"query range [{t0}, {t1}) outside the {S} video tokens")
             e1, v1 = (S + T, S + te) if (t1 == S and T > 0) else (t1, t1)
-            part = dict(base, out=o_e[0], n_q=e1 - t0, n_kv=S + te, q_valid=v1 - t0, tag="full_part",
+            part = dict(base, out=o_e[0], n_q=e1 - t0, n_kv=S + te, q_valid=v1 - t0, tag="full_part", **split_kw,
                         kv_rows=None if rm is None else rm[:S + te], flops=4.0 * (v1 - t0) * (S + te) * D,
                         head_list=hl, n_heads=1, n_heads_dev=None)
             if rm is None:
@@ -315,7 +320,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
             keep_q, drop_q = kq[0], kq[1]
             keep_k = kq[2] if gm else keep_q
         return [dict(base, out=o_e[1], n_q=geom.S_low + T, n_kv=geom.S_low + te, q_valid=geom.S_low + te, q_rows=keep_q,
-                     kv_rows=keep_k, dup_rows=drop_q, n_dup_pos=geom.G, tag="lowres",
+                     kv_rows=keep_k, dup_rows=drop_q, n_dup_pos=geom.G, tag="lowres", **split_kw,
                      flops=nheads(1) * 4.0 * (geom.S_low + te) ** 2 * D, **sl)]
 
     # ---- expert 2: sliding-tile attention (hunyuan.py:459-507 / wan.py:272-294) ----

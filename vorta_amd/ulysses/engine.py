@@ -898,7 +898,7 @@ class UlyssesRoutedAttention:
     def __init__(self, cfg: dict, layer_experts: Sequence[np.ndarray], cost_of_expert: dict, device, dtype,
                  rank: int, P: int, group=None, n_sets: int = 2, concurrent: bool = False, fused: bool = True,
                  sliding_block_rows: int = 0, groups: int = 1, loopback: bool = False, fp8: bool = False,
-                 v_wire: bool = True, placement: str = "even", heaviest_rank: bool = False):
+                 v_wire: bool = True, placement: str = "even", heaviest_rank: bool = False, kv_splits=1):
         """heaviest_rank (with loopback): every layer is run as the rank that carries the largest cost in THAT layer -- a
         P-GPU step waits for its slowest rank layer by layer, so this (not a fixed rank) is the compute side of it."""
         from ..routed import HeadRouting
@@ -913,6 +913,9 @@ class UlyssesRoutedAttention:
         self.concurrent, self.fused, self.sliding_block_rows = concurrent, fused, sliding_block_rows
         self.te = cfg["text_valid"]
         costs = [cost_of_expert["full"], cost_of_expert["lowres"], cost_of_expert["sliding"]]
+        # kv_splits: 1 (default), a number, or "auto": per layer, from this rank's count of workgroups -- a rank with one or
+        # two heads runs under one round of workgroups on 256 CUs, where key splits shorten the layer and query splits do not
+        self.kv_splits_arg, self.kv_splits = kv_splits, []
         self.orders, self.routes, self.lays, self.groups, self.parts = [], [], [], [], []
         layouts, self.states = {}, {}
         self.max_over_mean = []  # per layer: heaviest rank's cost / mean cost (1.0 = perfectly balanced)
@@ -942,6 +945,14 @@ class UlyssesRoutedAttention:
             sg = slot_groups(lay.Hl, min(groups, min(counts)))
             local = [int(e[h]) for h in order[lay.starts[r]:lay.starts[r + 1]]]
             local_parts = [None] * len(local) if parts is None else parts[lay.starts[r]:lay.starts[r + 1]]
+            if kv_splits == "auto":
+                s_low = (S // (cfg["group"][0] * cfg["group"][1] * cfg["group"][2])) * int(
+                    cfg["group"][0] * cfg["group"][1] * cfg["group"][2] * (1 - cfg["rate"]))
+                rows = {0: S + T, 1: s_low + T, 2: S}
+                wgs = sum(-(-rows[x] // 256) for x in local)
+                self.kv_splits.append(max(1, min(8, round(768 / max(wgs, 1)))) if wgs < 384 else 1)
+            else:
+                self.kv_splits.append(max(1, int(kv_splits)))
             self.orders.append(order)
             self.lays.append(lay)
             self.groups.append(sg)
@@ -991,7 +1002,8 @@ class UlyssesRoutedAttention:
                 views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
             routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], st.geom, model=self.cfg["model"],
                              text_len=self.cfg["text"], text_valid=self.te, out=o[g0:g1], concurrent=self.concurrent,
-                             fused=self.fused, sliding_block_rows=self.sliding_block_rows, fp8=False, fp8_views=views)
+                             fused=self.fused, sliding_block_rows=self.sliding_block_rows, fp8=False, fp8_views=views,
+                             kv_splits=self.kv_splits[l])
 
         # every cached table of this layer exists before the slot groups fork onto their streams (the routing lists were
         # copied to the device in __init__)
