@@ -29,6 +29,10 @@ SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
 # the routes are balanced); "even" = H/P heads on every rank (A/B); "split" = uneven, then full-attention heads give a range
 # of their queries to the lightest ranks until the heaviest is within 1 % of the mean (`split_placement`)
 SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "uneven")
+# key splits of the full-attention / coreset launches: "1" (default), a number, or "auto" = per layer from this rank's count
+# of workgroups (a rank whose one or two heads leave the chip under one round of workgroups: small models on many ranks;
+# changes the summation order -- ulysses/engine.py, bench.py --kv-splits)
+SP_KV_SPLITS = __import__("os").environ.get("VORTA_SP_KV_SPLITS", "1")
 
 
 class _SpBuffers:
@@ -154,6 +158,14 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     local_parts = [None] * len(local) if parts is None else parts[lay.starts[me]:lay.starts[me + 1]]
     ranges_of = lambda g0, g1: tuple((i - g0,) + tuple(local_parts[i]) for i in range(g0, g1) if local_parts[i] is not None)
     rm = lay.row_map
+    kv_splits = 1
+    if not dense_only and SP_KV_SPLITS != "1":
+        if SP_KV_SPLITS == "auto":
+            rows = {0: S + T, 1: s_low + T, 2: S}
+            wgs = sum(-(-rows[int(x)] // 256) for x in local)
+            kv_splits = max(1, min(8, round(768 / max(wgs, 1)))) if wgs < 384 else 1
+        else:
+            kv_splits = max(1, int(SP_KV_SPLITS))
 
     # the precision switch (set_attention_precision / VORTA_ATTENTION_PRECISION) is about the ROUTED operator; dense
     # attention -- --native_attention, the PSNR reference -- stays in the dtype of q,k,v on one GPU and under SP alike
@@ -178,7 +190,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
                          q_rows=rm[:S + T], kv_rows=rm[:S + te])
         else:
             routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], _routing(tuple(local[g0:g1]), q.device, ranges_of(g0, g1)), geom,
-                             model=model, text_len=T, text_valid=te, out=ov[g0:g1], fp8=False, fp8_views=views)
+                             model=model, text_len=T, text_valid=te, out=ov[g0:g1], fp8=False, fp8_views=views,
+                             kv_splits=kv_splits)
 
     sg = slot_groups(lay.Hl, groups)
 
