@@ -7,6 +7,8 @@ sampled rows against the oracle (the oracle cannot hold an S x S score matrix at
   configs[4]  Wan-2.1 14B 81x720x1280  (21,45,80)  S =  75 600  routed, tile (7,9,8), coreset (3,3,2), 40 heads (bf16, and
               one rank of eight through the e4m3 kernels: test_config4_one_rank_of_eight_fp8_at_full_size)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -536,8 +538,9 @@ def test_i8pv_headline_sizes_sampled_waves_vs_oracle_emulator(config):
         return lambda g, w0: (g, w0) in picks
 
     kw = dict(p_mode="direct")
+    more = int(os.environ.get("VORTA_TEST_MORE_WAVES", "1"))  # an extended run samples this many times more waves
     nq = S + T
-    picks = some([nq], 4)
+    picks = some([nq], 4 * more)
     last = ((S + te - 1) // 32) * 32
     O.fp8_attn_launch(None, None, ve[0], ref[0], vde[0], n_q=nq, n_kv=S + te, q_valid=S + te, ambiguous=amb[0],
                       wave_filter=lambda g, w0: picks(g, w0) or w0 == last, wave_operands=hooks[0], **kw)
@@ -546,7 +549,7 @@ def test_i8pv_headline_sizes_sampled_waves_vs_oracle_emulator(config):
     keep_k = keep_q if model == "wan" else ops.coreset_select(k[0], geom.latent, geom.group, geom.n_keep, tail_first=S,
                                                               n_tail=te, head_list=hl, want_drop=False)[0]
     nql = geom.S_low + T
-    picks = some([nql], 4)
+    picks = some([nql], 4 * more)
     O.fp8_attn_launch(None, None, ve[1], ref[1], vde[1], n_q=nql, n_kv=geom.S_low + te, q_valid=geom.S_low + te,
                       q_rows=keep_q[0].cpu().numpy(), kv_rows=keep_k[0].cpu().numpy(), dup_rows=drop_q[0].cpu().numpy(),
                       n_dup_pos=geom.G, ambiguous=amb[1], wave_filter=lambda g, w0: picks(g, w0) or w0 == 0,
@@ -555,7 +558,7 @@ def test_i8pv_headline_sizes_sampled_waves_vs_oracle_emulator(config):
     qr, kr, tb = q_rows.cpu().numpy(), kv_rows.cpu().numpy(), table.cpu().numpy()
     bounds = [(int(tb[tb[:, 0] == g, 1].min()), int(tb[tb[:, 0] == g, 2].max())) for g in range(n_lists)]
     O.fp8_attn_launch(None, None, ve[2], ref[2], vde[2], n_q=S, n_kv=n_kv, q_rows=qr, kv_rows=kr, q_group_bounds=bounds,
-                      ambiguous=amb[2], wave_filter=some([b[1] - b[0] for b in bounds], 10), wave_operands=hooks[2], **kw)
+                      ambiguous=amb[2], wave_filter=some([b[1] - b[0] for b in bounds], 10 * more), wave_operands=hooks[2], **kw)
     if T:
         O.fp8_attn_launch(None, None, ve[2], ref[2], vde[2], n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te, n_splits=1,
                           ambiguous=amb[2], wave_filter=lambda g, w0: w0 in (0, 64), wave_operands=hooks[2], **kw)
