@@ -10,7 +10,7 @@ for o in $ALL; do [ "$o" = "$SRC" ] || OTHERS="$OTHERS $o.o"; done
 while [ $# -gt 1 ]; do
   n=$1; f=$2; shift 2
   /opt/rocm/bin/hipcc $FLAGS $f -c $SRC.hip -o ${SRC}_v$n.o
-  /opt/rocm/bin/hipcc $FLAGS $f -c api.hip -o api_v$n.o
+  /opt/rocm/bin/hipcc $FLAGS $f "-DVORTA_VARIANT_FLAGS=\"$f\"" -c api.hip -o api_v$n.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libvorta_hip_$n.so ${SRC}_v$n.o api_v$n.o $OTHERS
   echo built libvorta_hip_$n.so "$f"
 done

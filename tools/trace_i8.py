@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Diagnostic: where the waves of the int8-score attention loop spend their cycles.  Needs the -DVORTA_TRACE_I8=i builds
 (i = 1 ... 7; one interval per build), e.g.
-    bash tools/dbg/build_i8_variants.sh tri1 -DVORTA_TRACE_I8=1 tri2 -DVORTA_TRACE_I8=2 ... tri7 -DVORTA_TRACE_I8=7
+    bash tools/dbg/build_i8_variants.sh tri1 "-DVORTA_I8_DIAG -DVORTA_TRACE_I8=1" ... tri7 "-DVORTA_I8_DIAG -DVORTA_TRACE_I8=7"
     python tools/trace_i8.py            # runs itself once per library (child processes)
 Interval i = shader cycles per step between stamps i-1 and i:
   0 step start | 1 after the tile requests at the top (role Y's) | 2 before the matrix part | 3 after it | 4 after the requests

@@ -38,7 +38,9 @@ def build(force: bool = False, verbose: bool = True, extra_flags=None, suffix: s
                          "libvorta_hip.so itself")
     lib = LIB if not suffix else os.path.join(CSRC, f"libvorta_hip{suffix}.so")
     deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "attn_common.h"), os.path.join(CSRC, "attn_fwd_fp8_diag.inc"),
-            os.path.join(INCLUDE, "vorta_hip.h")]
+            os.path.join(CSRC, "attn_fwd_i8_diag.inc"), os.path.join(CSRC, "attn_fwd_diag.inc"), os.path.join(INCLUDE, "vorta_hip.h")]
+    if extra:  # vorta_build_info() of a variant library names its flags
+        extra = extra + ['-DVORTA_VARIANT_FLAGS="%s"' % " ".join(extra).replace('"', "'")]
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

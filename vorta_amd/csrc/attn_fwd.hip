@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include "attn_common.h"
+#include "attn_fwd_diag.inc"
 
 namespace {
 using namespace vorta_attn;
@@ -271,30 +272,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const Params p) {
 
 // The default kernel: scores computed one key block ahead (software pipeline across blocks), K/V tiles staged
 // global -> LDS by DMA, softmax folded into the score MFMA.  See the notes inside and DESIGN.md (d).
-#ifndef VORTA_RING
-// K/V ring depth of the 8-wave kernels: 2 = one step of DMA latency cover (64 KiB LDS), 3 = two steps (96 KiB).
-// Measured equal (1216 vs 1217 TFLOP/s, S=32 760 H=12 bf16, same box): the end-of-step vmcnt wait is not where
-// the loop stalls.  4 = PAIRED steps (128 KiB): the tile requests of TWO key blocks leave in one burst at the top of every
-// second step and one vmcnt(0) + barrier closes the pair -- the stream's cost is per burst, not per request or byte
-// (profiles/r04_probe_mfma_shape_energy.txt part E).
-#define VORTA_RING 2
-#endif
-
-// lane 16 g + n of `v` to every lane of row g (v_mov_b32_dpp row_newbcast:n)
-template <int N>
-__device__ __forceinline__ int row_bcast(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + N, 0xf, 0xf, false);
-}
+// K/V ring depth: 2 = one step of DMA latency cover (64 KiB LDS).  A ring of 3 (two steps of cover), paired steps on a ring of
+// 4 (one request burst + one barrier per two key blocks) and staggered requests all measured within -1.5 ... +0.3 % of it:
+// the end-of-step wait is not where this loop stalls (profiles/r04_probe_mfma_shape_energy.txt; the code is in the history
+// of round 4).
+constexpr int RING = 2;
 
 template <typename T, int NW, bool KVTAB, int NS>
 __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __restrict__ smem, const int wg) {
   // NS = depth of the K and of the V tile rings (NS * 32 KiB of LDS): K(j+NS) / V(j+NS-1) are requested at the
   // top of step j, NS-1 steps before the step that reads them
-  static_assert(NS == 2 || NS == 3 || NS == 4, "ring depth");
-  constexpr bool PAIR = NS == 4;
-#ifdef VORTA_TRACE
-  const long long tr_e0_ = wall_clock64();  // workgroup entry, absolute (100 MHz)
-#endif
+  static_assert(NS == 2, "ring depth");
+  TRACE_ENTRY_()
   using V8 = typename MF<T>::v8;
   using V4 = typename MF<T>::v4;
   constexpr int NT = NW * 64;
@@ -391,36 +380,6 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #define DMA_V(par_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(   \
       v_rsrc, (LDS_AS void*)(smem + (NS + (par_)) * TILE_BYTES + (CH * wave + i_) * 1024), 16,                     \
       (int)__umul24((unsigned)rowV[i_], (unsigned)v_ss32) + v_col[i_], 0, 0, 0);
-  // Paired steps keep the rows of up to four key blocks in ONE register: lane 16 g + n, n = CH b + i, holds the row of key
-  // position 64 (blk + b) + 4 (CH wave + i) + g -- what piece i of block blk + b fetches for its sub-row g -- and a request
-  // reads its row with a row broadcast (one table load per pair instead of CH per step, and CH*2 - 1 registers fewer).
-  int pack = 0;
-  const int pk_off = ((lane & 15) / CH) * KVB + 4 * (CH * wave + ((lane & 15) % CH)) + (lane >> 4);
-#define PACK_OF(blk_)                                                             \
-  {                                                                               \
-    const int pos_ = min((blk_) * KVB + pk_off, n_kv - 1);                        \
-    if constexpr (KVTAB) pack = kv_rows[pos_];                                    \
-    else pack = p.kv_row_offset + pos_;                                           \
-  }
-#define DMA_PIECE(rsrc_, lds_, ss_, col_, b_, i_)                                 \
-  if constexpr ((i_) < CH) __builtin_amdgcn_raw_ptr_buffer_load_lds(              \
-      rsrc_, (LDS_AS void*)((lds_) + (CH * wave + (i_)) * 1024), 16,              \
-      (int)__umul24((unsigned)row_bcast<(CH * (b_) + (i_)) & 15>(pack), (unsigned)(ss_)) + col_[(i_) < CH ? (i_) : 0], 0, 0, 0);
-#define DMA_TILE(rsrc_, lds_, ss_, col_, b_)                                      \
-  DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 0) DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 1) \
-  DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 2) DMA_PIECE(rsrc_, lds_, ss_, col_, b_, 3)
-#define DMA_K_P(slot_, b_) DMA_TILE(k_rsrc, smem + (slot_) * TILE_BYTES, k_ss32, k_col, b_)
-#define DMA_V_P(slot_, b_) DMA_TILE(v_rsrc, smem + (NS + (slot_)) * TILE_BYTES, v_ss32, v_col, b_)
-  // top of a pair whose first block j has ring slot s_ (0 or 2): `pack` holds the rows of blocks j+2, j+3, j+4.  V(j+2),
-  // K(j+3), V(j+3), K(j+4) go to the slots V(j-2), K(j-1), V(j-1), K(j) left during the previous pair; they are read in
-  // the NEXT pair, after the barrier that closes this one.  Then the pack of the next pair (blocks j+4 ...) is requested.
-#define STAGE_PAIR(s_, j_)                                                        \
-  DMA_V_P(((s_) + 2) & 3, 0)                                                      \
-  DMA_K_P(((s_) + 3) & 3, 1)                                                      \
-  DMA_V_P(((s_) + 3) & 3, 1)                                                      \
-  DMA_K_P((s_), 2)                                                                \
-  PACK_OF((j_) + 4)                                                               \
-  __builtin_amdgcn_sched_barrier(0);
 
   // ---- LDS read addresses ----
   int k_rd[8];
@@ -512,11 +471,10 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= (g_); c1_[i_] -= (g_); minit[i_] = -m_run; } \
     asm volatile("" : "+v"(minit));                                               \
   }
-  // top of step j: K(j+NS) -> the slot K(j) left, V(j+NS-1) -> the slot V(j-1) left.  They are read in step
-  // j+NS-1, so the barrier that ends step j only waits for the requests of step j-NS+2 and older: with NS = 3
-  // the 2*CH requests of the current step stay in flight across it (two steps of latency cover, one with NS = 2)
+  // top of step j: K(j+2) -> the slot K(j) left, V(j+1) -> the slot V(j-1) left.  They are read in step j+1, after the
+  // barrier that ends step j (one step of latency cover)
   // (the key positions of the loop are running values, one add per step: written as (block index) * 64 + lane term every
-  // unrolled step keeps its own hoisted copy of the sum in a register -- CH x 2 here, CH x 6 with the ring of 3)
+  // unrolled step keeps its own hoisted copy of the sum in a register)
 #define STAGE_DMA(kfree_, vfree_, j_)                                             \
   DMA_K(kfree_)                                                                   \
   DMA_V(vfree_)                                                                   \
@@ -534,27 +492,9 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   __builtin_amdgcn_sched_barrier(0);
   // end of a step: own DMA requests older than the current step have landed, then the workgroup barrier (which
   // also orders every wave's LDS reads of this step before the next step's overwrites)
-#ifdef VORTA_TRACE  // diagnostic build only (tools/trace_barrier.py): cycles spent in the wait and in the barrier
-  long long tr_wait_ = 0, tr_bar_ = 0;
-  const long long tr_t0_ = clock64();
-  const long long tr_w0_ = wall_clock64();  // constant 100 MHz: the shader clock over the loop follows from the two
-#define STEP_SYNC()                                                               \
-  {                                                                               \
-    const long long a_ = clock64();                                               \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
-    const long long b_ = clock64();                                               \
-    asm volatile("s_barrier" ::: "memory");                                       \
-    const long long c_ = clock64();                                               \
-    tr_wait_ += b_ - a_;                                                          \
-    tr_bar_ += c_ - b_;                                                           \
-  }
-#else
-#define STEP_SYNC()                                                               \
-  {                                                                               \
-    if constexpr (NS == 2 || NS == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-    else if constexpr (CH == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-  }
+  TRACE_VARS_()
+#ifndef STEP_SYNC
+#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
 
   // Issue-order recipe for the step's basic block (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x400 transcendental,
@@ -586,20 +526,12 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
   // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
   // all visible to the scheduler together.
-  // -DVORTA_REQ_STAGGER=1 (ring of 3 only; experiment): the second wave of every SIMD (waves NW/2 ...) issues its tile
-  // requests BEHIND its step instead of at the top, so that the two waves of a SIMD are not both held by their requests
-  // (~90 cycles each, four per step) right after the barrier; the ring of 3 gives those requests the next step to land
-#ifndef VORTA_REQ_STAGGER
-#define VORTA_REQ_STAGGER 0
-#endif
 #define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, vfree_, j_)                       \
   { /* kcur_ = j % NS: slot of K(j) (free) and of V(j); knext_ = (j+1) % NS; vfree_ = (j-1) % NS */ \
-    if (!late_req) { STAGE_DMA(kcur_, vfree_, j_) }                               \
+    STAGE_DMA(kcur_, vfree_, j_)                                                  \
     STEP_BODY(c0_, c1_, n0_, n1_, kcur_, knext_, j_)                              \
-    if (late_req) { STAGE_DMA(kcur_, vfree_, j_) }                                \
     STEP_SYNC()                                                                   \
   }
-  const bool late_req = VORTA_REQ_STAGGER && NS == 3 && NW == 8 && wave >= NW / 2;  // wave-uniform
 #define STEP_BODY(c0_, c1_, n0_, n1_, kcur_, knext_, j_)                          \
   {                                                                               \
     if (wave_active) {                                                            \
@@ -657,34 +589,16 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
   }
 
   if (blk0 < blk1) {
-    if constexpr (PAIR) {
-      // prologue: K(0), K(1), K(2), V(0), V(1) -> their ring slots; then the pack of the first pair (blocks 2, 3, 4)
-      PACK_OF(blk0)
-      DMA_K_P(0, 0)
-      DMA_V_P(0, 0)
-      DMA_K_P(1, 1)
-      DMA_V_P(1, 1)
-      DMA_K_P(2, 2)
-      __builtin_amdgcn_sched_barrier(0);
-      PACK_OF(blk0 + 2)
-    } else {
-    // prologue: K(0..NS-1) and V(0..NS-2) -> their ring slots; then rowK = rows(NS), rowV = rows(NS-1)
+    // prologue: K(0), K(1) and V(0) -> their ring slots; then rowK = rows(2), rowV = rows(1)
     ROWS_OF(rowK, blk0)
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     DMA_K(0)
     DMA_V(0)
     ROWS_OF(rowK, blk0 + 1)
     DMA_K(1)
-    if constexpr (NS == 3) {
-      _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
-      DMA_V(1)
-      ROWS_OF(rowK, blk0 + 2)
-      DMA_K(2)
-    }
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     ROWS_OF(rowK, blk0 + NS)
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) posK[i_] = (blk0 + NS) * KVB + 4 * (CH * wave + i_) + (lane >> 4);
-    }
     __syncthreads();
     if (wave_active) {
       QK(sA0, sA1, 0)  // seed 0: plain scores of the first block
@@ -707,42 +621,10 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
     }
     __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
   }
-  if constexpr (PAIR) {
-    // ring slots cycle with period 4; the requests of two blocks per burst, one vmcnt(0) + barrier per pair
-    for (int blk = blk0; blk < blk1; blk += 4) {
-      STAGE_PAIR(0, blk)
-      STEP_BODY(sA0, sA1, sB0, sB1, 0, 1, blk)
-      if (blk + 1 >= blk1) break;
-      STEP_BODY(sB0, sB1, sA0, sA1, 1, 2, blk + 1)
-      STEP_SYNC()
-      if (blk + 2 >= blk1) break;
-      STAGE_PAIR(2, blk + 2)
-      STEP_BODY(sA0, sA1, sB0, sB1, 2, 3, blk + 2)
-      if (blk + 3 >= blk1) break;
-      STEP_BODY(sB0, sB1, sA0, sA1, 3, 0, blk + 3)
-      STEP_SYNC()
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a loop left in mid-pair still has its burst in flight
-  } else if constexpr (NS == 2) {
-    for (int blk = blk0; blk < blk1; blk += 2) {
-      STEP(sA0, sA1, sB0, sB1, 0, 1, 1, blk)
-      if (blk + 1 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 1, 0, 0, blk + 1)
-    }
-  } else {  // ring slots cycle with period 3, score roles with period 2: unrolled by 6
-    for (int blk = blk0; blk < blk1; blk += 6) {
-      STEP(sA0, sA1, sB0, sB1, 0, 1, 2, blk)
-      if (blk + 1 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 1, 2, 0, blk + 1)
-      if (blk + 2 >= blk1) break;
-      STEP(sA0, sA1, sB0, sB1, 2, 0, 1, blk + 2)
-      if (blk + 3 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 0, 1, 2, blk + 3)
-      if (blk + 4 >= blk1) break;
-      STEP(sA0, sA1, sB0, sB1, 1, 2, 0, blk + 4)
-      if (blk + 5 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 2, 0, 1, blk + 5)
-    }
+  for (int blk = blk0; blk < blk1; blk += 2) {
+    STEP(sA0, sA1, sB0, sB1, 0, 1, 1, blk)
+    if (blk + 1 >= blk1) break;
+    STEP(sB0, sB1, sA0, sA1, 1, 0, 0, blk + 1)
   }
 #undef QK
 #undef QK_PRE
@@ -752,27 +634,12 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 #undef STEP
 #undef STEP_BODY
 #undef STAGE_DMA
-#undef STAGE_PAIR
 #undef STEP_SYNC
 #undef ROWS_OF
-#undef PACK_OF
 #undef DMA_K
 #undef DMA_V
-#undef DMA_PIECE
-#undef DMA_TILE
-#undef DMA_K_P
-#undef DMA_V_P
 
-#ifdef VORTA_TRACE
-  if (p.n_splits == 1 && p.ws_ml && lane == 0) {
-    long long* tr = (long long*)p.ws_ml + ((int64_t)wg * NW + wave) * 8;
-    tr[0] = clock64() - tr_t0_; tr[1] = tr_wait_; tr[2] = tr_bar_; tr[3] = blk1 - blk0;
-    tr[4] = wall_clock64() - tr_w0_;
-    tr[5] = tr_e0_; tr[6] = wall_clock64();  // absolute entry / end-of-loop times
-    tr[7] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_ID
-            ((long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // XCC_ID
-  }
-#endif
+  TRACE_FLUSH_()
   if (!wave_active) return;
   // ---------------- epilogue ----------------
   const float l_tot = half_sum(l_run);
@@ -826,7 +693,7 @@ __device__ __forceinline__ void attn_pipe_dma_body(const Params& p, char* __rest
 template <typename T, int NW, bool KVTAB>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
-  constexpr int NS = NW == 8 ? VORTA_RING : 2;  // 8 waves = the CU's whole wave budget at this VGPR count: 96 of its 160 KiB
+  constexpr int NS = RING;
   __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE_BYTES];
   // XCD-aware work order: consecutive logical ids (same head, neighbouring query blocks) share an XCD's L2
   const int wg = live_order(p, blockIdx.x, gridDim.x, p.xcd_remap);
@@ -842,7 +709,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const Params 
 template <typename T>
 __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParams mp) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
-  __shared__ __attribute__((aligned(16))) char smem[2 * VORTA_RING * TILE_BYTES];  // K and V rings
+  __shared__ __attribute__((aligned(16))) char smem[2 * RING * TILE_BYTES];  // K and V rings
   const int b = blockIdx.x;
   int s = 0;
 #pragma unroll
@@ -853,8 +720,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_multi_kernel(const MultiParam
   // neighbouring query blocks -> one L2 serves the K/V stream instead of eight).  Every XCD still gets 1/8 of
   // every segment, which keeps the chip balanced across segments of different cost.
   const int wg = live_order(p, b - mp.start[s], mp.start[s + 1] - mp.start[s], true);
-  if (p.kv_rows) attn_pipe_dma_body<T, 8, true, VORTA_RING>(p, smem, wg);
-  else attn_pipe_dma_body<T, 8, false, VORTA_RING>(p, smem, wg);
+  if (p.kv_rows) attn_pipe_dma_body<T, 8, true, RING>(p, smem, wg);
+  else attn_pipe_dma_body<T, 8, false, RING>(p, smem, wg);
 #endif
 }
 

@@ -528,94 +528,16 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     SCHED_S()                                                                     \
     PRIO_LO()                                                                     \
   }
-  // Timing ablations (suffixed diagnostic libraries only; each removes one ingredient of the step and gives WRONG RESULTS;
-  // tools/measure/r4_i8_ablation.sh, profiles/r04_i8_ablation.txt)
-#ifdef VORTA_I8_DIAG_NOSYNC
-#undef STEP_SYNC
-#define STEP_SYNC() asm volatile("" ::: "memory");
-#endif
-#ifdef VORTA_I8_DIAG_NOBAR
-#undef STEP_SYNC
-#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-#ifdef VORTA_I8_DIAG_NODMA
-#undef STAGE_DMA
-#define STAGE_DMA(kw_, vw_, bw_, jabs_)
-#undef DMA_K
-#define DMA_K(slot_)
-#undef DMA_V
-#define DMA_V(slot_)
-#undef REQ_TAIL
-#undef ROWS_UPDATE
-#define REQ_TAIL(bw_)
-#endif
-#ifdef VORTA_I8_DIAG_NOSEED
-#undef MAKE_SEEDS
-#define MAKE_SEEDS(bslot_, sslot_)
-#endif
-#ifdef VORTA_I8_DIAG_NOVALU
-#undef VALU_PART
-#undef REQ_TAIL
-#undef ROWS_UPDATE
-#define VALU_PART(bs_, ss_, qa_, qb_, qc_) qa_ qb_ qc_ asm volatile("" : "+v"(y0), "+v"(y1) : "v"(n0), "v"(n1));
-#undef PACK_Y
-#define PACK_Y(pb_) asm volatile("" : "+v"(pb_) : "v"(y0), "v"(y1));
-#endif
-#ifdef VORTA_I8_DIAG_NOLDS
-#undef SEEDS_IN
-#define SEEDS_IN(d_, sslot_, t_) _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) d_[e_] = MAGIC_I;
-#undef KFRAGS
-#define KFRAGS(dst_, slot_, t_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) dst_[ks_] = qf[ks_ ^ (t_)];
-#undef VFRAG
-#define VFRAG(dt_, slot_) vf_[dt_] = pbA_;
-#endif
-#ifdef VORTA_I8_DIAG_NOMFMA
-#define mfma_i8(a_, b_, c_) ([&]() { i32x16 r_ = (c_); asm volatile("" : "+v"(r_) : "v"(a_), "v"(b_)); return r_; }())
-#define mfma8(a_, b_, c_) ([&]() { f32x16 r_ = (c_); asm volatile("" : "+v"(r_) : "v"(a_), "v"(b_)); return r_; }())
-#endif
-  // -DVORTA_TRACE_I8=i (diagnostic libraries, tools/trace_i8.py; one interval per build): shader cycles between stamps i-1
-  // and i of every step, summed per wave, go to ws_ml of an unsplit launch; results stay correct.
-  //   0 step start | 1 after the requests at the top (role Y's) | 2 before the matrix part | 3 after it | 4 after the requests
-  //   behind it (role X's) | 5 before the end-of-step wait | 6 before the barrier | 7 after
-#ifdef VORTA_TRACE_I8
-  unsigned tr_sum_ = 0, tr_t0_ = 0;
-#define TR_(i_)                                                                   \
-  if constexpr ((i_) == VORTA_TRACE_I8 - 1) {                                     \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    tr_t0_ = (unsigned)__builtin_readcyclecounter();                              \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-  } else if constexpr ((i_) == VORTA_TRACE_I8) {                                  \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-    tr_sum_ += (unsigned)__builtin_readcyclecounter() - tr_t0_;                   \
-    __builtin_amdgcn_sched_barrier(0);                                            \
-  }
-#undef STEP_SYNC
-#define STEP_SYNC()                                                               \
-  {                                                                               \
-    TR_(5)                                                                        \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                   \
-    TR_(6)                                                                        \
-    asm volatile("s_barrier" ::: "memory");                                       \
-    TR_(7)                                                                        \
-  }
-#define TR_FLUSH_()                                                               \
-  if (p.n_splits == 1 && p.ws_ml && lane == 0) {                                  \
-    unsigned* tr = (unsigned*)p.ws_ml + ((int64_t)wg * NW + wave) * 2;            \
-    tr[0] = tr_sum_; tr[1] = (unsigned)(nsteps - 1);                              \
-  }
-#else
+  // Diagnostic builds only (suffixed libraries: vorta_amd/build.py refuses extra flags for the product): -DVORTA_I8_DIAG pulls
+  // in the in-loop cycle stamps (-DVORTA_TRACE_I8=i, tools/trace_i8.py) and the wrong-result timing ablations
+  // (-DVORTA_I8_DIAG_*), which re-define the macros above.
+// which half of the workgroup starts its steps with the VALU part (the e4m3 kernel measured 0-3.6 % between the two, by body;
+// here the later-dispatched half: 26.5 against 26.8-27.2 ms, profiles/r04_i8_ablation.txt part 6)
+#define ROLE_Y_ (NW == 8 && wave >= NW / 2)
 #define TR_(i_)
 #define TR_FLUSH_()
-#endif
-#ifdef VORTA_I8_DIAG_ALLX  /* every wave in the first role (no ping-pong) */
-#define ROLE_Y_ false
-#else
-// which half of the workgroup starts its steps with the VALU part (the e4m3 kernel measured 0-3.6 % between the two, by body:
-// attn_fwd_fp8.hip VORTA_MULTI_SWAP): -DVORTA_I8_SWAP=1 = the earlier-dispatched half
-#ifndef VORTA_I8_SWAP
-#define VORTA_I8_SWAP 0
-#endif
-#define ROLE_Y_ (NW == 8 && (VORTA_I8_SWAP ? wave < NW / 2 : wave >= NW / 2))
+#ifdef VORTA_I8_DIAG
+#include "attn_fwd_i8_diag.inc"
 #endif
   // both roles request their tile pieces inside their VALU part (role X behind its matrix part: it goes from the barrier
   // straight into its MFMAs); the 4-wave kernels (no roles) and waves past the query rows request at the top of the step
