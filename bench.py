@@ -357,10 +357,10 @@ def main():
     if args.dtype:
         cfg["dtype"] = args.dtype
     if args.conservative:  # before vorta_amd.ulysses.engine reads the transport switch, and inherited by the child ranks
-        args.placement, args.sp_groups, args.no_v_wire = "even", 1, True
+        args.placement, args.sp_groups, args.no_v_wire = "auto", 1, True  # (auto = even wherever even exists)
         os.environ["VORTA_SP_TRANSPORT"] = "a2a"
-    if args.placement == "auto":
-        args.placement = "even" if cfg["heads"] % max(args.emulate_rank or args.gpus, 1) == 0 else "uneven"
+    from vorta_amd.ulysses.state import resolve_placement  # the processors' rule (vorta_amd/attention/_sp.py)
+    args.placement = resolve_placement(args.placement, cfg["heads"], max(args.emulate_rank or args.gpus, 1))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_rank:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (never exec: nothing in this
         # process has touched the GPU yet, and nothing will), relay its output and exit with its code
@@ -534,15 +534,21 @@ def main():
                 "share_of_step": round(dom["ms"] / (ms_per_step * args.steps), 3)}
     # bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself), keyed by
     # workload: `traffic` = bytes leaving the L2s (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md 'HBM'); the Infinity
-    # Cache sits behind that interface, the memory controllers' own activity (tools/umc_activity.py) gives the DRAM side
+    # Cache sits behind that interface.  The NEWEST table that holds this workload is used (r05b > r05 > r04b > ...) and named,
+    # with the git head of the tree it was taken on when the table records it: the line says which binary its traffic describes.
+    # (A DRAM-side estimate from the memory controllers' activity is quoted only from a pass of the SAME round as the table.)
     try:
-        wl, pmc_file = None, None
-        for pmc_file in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):  # the newest table that holds this workload
-            if os.path.exists(os.path.join(ROOT, "profiles", pmc_file)):
-                wl = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["workloads"].get(
-                    f"{args.config} {args.mix} {cfg['dtype']}")
-                if wl is not None:
-                    break
+        import glob
+        import re
+        tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_pmc_traffic.json")),
+                        key=lambda f: re.match(r"r(\d+)([a-z]*)_", os.path.basename(f)).groups(), reverse=True)
+        wl, pmc_file, table = None, None, None
+        for f in tables:
+            table = json.load(open(f))
+            wl = table["workloads"].get(f"{args.config} {args.mix} {cfg['dtype']}")
+            if wl is not None:
+                pmc_file = os.path.basename(f)
+                break
         if wl is not None and world == 1 and not emu and proc_info is None:
             base = dom_sym.split("<")[0]
             hit = [v for k_, v in wl["kernels"].items() if base in k_]
@@ -550,14 +556,17 @@ def main():
                 roofline["traffic"] = hit[0]["l2_miss_bytes_per_launch"]
                 roofline["traffic_unit"] = ("bytes per launch leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE, "
                                             f"profiles/{pmc_file})")
+                roofline["traffic_source"] = f"profiles/{pmc_file}"
+                roofline["traffic_source_head"] = table.get("head")  # git head of the profiled tree (None: older tables)
                 roofline["traffic_over_minimum"] = round(hit[0]["l2_miss_bytes_per_launch"] /
                                                          wl["algorithmic_min_bytes_per_fused_launch"], 2)
-        umc = os.path.join(ROOT, "profiles", f"r03_umc_activity_{args.config}_{cfg['dtype']}.json")
-        if os.path.exists(umc) and args.mix == "uniform" and world == 1 and not emu and proc_info is None:
-            u = json.load(open(umc))
-            roofline["traffic_dram_estimate"] = u["from_percent"]["bytes_per_layer"]
-            roofline["traffic_dram_unit"] = ("HBM bytes per launch from the memory controllers' activity (coarse: integer "
-                                             "percent; tools/umc_activity.py)")
+                rnd = re.match(r"(r\d+)", pmc_file).group(1)
+                umc = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{rnd}*_umc_activity_{args.config}_{cfg['dtype']}.json")))
+                if umc and args.mix == "uniform":
+                    u = json.load(open(umc[-1]))
+                    roofline["traffic_dram_estimate"] = u["from_percent"]["bytes_per_layer"]
+                    roofline["traffic_dram_unit"] = ("HBM bytes per launch from the memory controllers' activity (coarse: "
+                                                     f"integer percent; tools/umc_activity.py, profiles/{os.path.basename(umc[-1])})")
     except Exception:
         pass
     per_tag = {f"{tag}: {sym}": {"launches": v["launches"], "avg_ms": round(v["ms"] / v["launches"], 4),
@@ -640,12 +649,66 @@ def main():
         except Exception as exc:  # context only: never let it cost the bench line
             roofline["library_gemm_tflops"] = None
             roofline["library_gemm_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    if world == 1 and not args.no_gemm_ceiling and not emu and proc_info is None:
+        borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not emu and proc_info is None:
             res["cpu_baseline"] = cpu_baseline(cfg, layer_ids)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, budget_s: float = 20.0):
+    """Context beside `library_gemm_tflops`, measured after the timed region and never part of `value`: the kernel the
+    REFERENCE borrows for its dense expert on this box -- torch.nn.functional.scaled_dot_product_attention, the call at
+    /root/reference/vorta/attention/hunyuan.py:169-176 (wan.py:142-145) -- on a sample of 8 heads x (S + T_eff)^2 in 16 bits,
+    and this build's own dense launch (ops.attn_fwd) on the same tensors.  torch-ROCm is not the reference (nothing of the
+    reference travels); it is the attention kernel the reference's code would have called here.  `step_ms_if_borrowed_dense` =
+    the all-full (--native_attention) step through that kernel, EXTRAPOLATED from the sample: heads x layers x forwards."""
+    import torch.nn.functional as F
+    from vorta_amd import ops
+    t_start = time.perf_counter()
+    try:
+        dt16 = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16
+        N, hs = S + te, 8
+        gen = torch.Generator(device=dev).manual_seed(99)
+        q, k, v = (torch.randn((1, hs, N, 128), generator=gen, device=dev, dtype=dt16) for _ in range(3))
+        flops = 4.0 * N * N * 128
+
+        def timed(fn, heads, reps):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps / heads  # ms per head
+
+        # one head first: if the library kernel is very slow here the 8-head sample would eat the budget
+        t0 = time.perf_counter()
+        ms1 = timed(lambda: F.scaled_dot_product_attention(q[:, :1], k[:, :1], v[:, :1]), 1, 1)
+        heads = hs if (time.perf_counter() - t0) * hs * 1.5 < budget_s - (time.perf_counter() - t_start) else 1
+        ms_sdpa = timed(lambda: F.scaled_dot_product_attention(q[:, :heads], k[:, :heads], v[:, :heads]), heads, 2) if heads > 1 else ms1
+        o = torch.empty((1, hs, N, 128), device=dev, dtype=dt16)
+        ms_own = timed(lambda: ops.attn_fwd(q[0, :heads], k[0, :heads], v[0, :heads], o[0, :heads], n_q=N, n_kv=N), heads, 2)
+        sdpa_tf, own_tf = flops / (ms_sdpa * 1e-3) / 1e12, flops / (ms_own * 1e-3) / 1e12
+        roofline["library_sdpa_tflops"] = round(sdpa_tf, 1)
+        roofline["library_sdpa_sample"] = (f"F.scaled_dot_product_attention, {heads} heads x ({N})^2 x 128, {cfg['dtype'] if cfg['dtype'] in ('fp16', 'bf16') else 'bf16'}, "
+                                           f"torch {torch.__version__}")
+        roofline["frac_of_library_sdpa"] = round(achieved / sdpa_tf, 4) if sdpa_tf > 0 else None
+        roofline["own_dense_tflops_same_sample"] = round(own_tf, 1)
+        roofline["own_dense_over_library_sdpa"] = round(own_tf / sdpa_tf, 3) if sdpa_tf > 0 else None
+        fwd = cfg["fwd_per_step"]
+        res["config"]["step_ms_if_borrowed_dense"] = round(ms_sdpa * H * L * fwd, 1)
+        res["config"]["step_ms_own_dense"] = round(ms_own * H * L * fwd, 1)
+        res["config"]["borrowed_dense_note"] = ("all-full mix (--native_attention) extrapolated from the sample: ms per head x "
+                                                f"{H} heads x {L} layers x {fwd} forwards; SDPA = the kernel the reference calls "
+                                                "(hunyuan.py:169-176), torch-ROCm build on this box")
+    except Exception as exc:  # context only: never let it cost the bench line
+        roofline["library_sdpa_tflops"] = None
+        roofline["library_sdpa_error"] = f"{type(exc).__name__}: {exc}"[:200]
 
 
 def guarded():

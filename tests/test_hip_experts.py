@@ -839,6 +839,38 @@ def test_full_attention_head_split_by_query_range(precision):
         assert torch.all(rest == 7.0), (precision, h)
 
 
+@pytest.mark.parametrize("cfg", ["wan1.3b-81f", "wan14b-81f"])
+@pytest.mark.parametrize("precision", [False, "i8pv"])
+def test_split_head_is_the_whole_head_at_sizes_that_are_no_multiple_of_32(cfg, precision):
+    """S = 32 760 and 75 600 are 24 and 16 mod 32.  split_placement counts a boundary from the FRONT in 256-token
+    steps (only the part that ends at S is ragged), so each part's waves and workgroups are those of the whole-head launch:
+    torch.equal at the production sizes, with the ranges split_placement itself produces."""
+    import bench
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    from vorta_amd.ulysses.engine import split_align, split_placement
+    c = bench.CONFIGS[cfg]
+    latent, S = tuple(c["latent"]), c["latent"][0] * c["latent"][1] * c["latent"][2]
+    assert S % 32 != 0
+    experts_all = ([0, 0, 1, 1, 2, 2, 2, 1] * 5)[:c["heads"]]
+    order, counts, parts = split_placement(experts_all, [5.6, 1.4, 1.0], 8, S, 1, align=split_align(S))
+    cuts = sorted({t for pr in parts if pr for t in pr} - {0, S})
+    assert cuts and all(t % 256 == 0 for t in cuts), cuts
+    experts = [0, 2, 0]
+    ranges = {0: (0, cuts[0]), 2: (cuts[-1], S)}
+    gen = torch.Generator(device=dev()).manual_seed(5)
+    q, k, v = (torch.randn((1, 3, S, 128), generator=gen, device=dev(), dtype=torch.bfloat16) for _ in range(3))
+    geom = RoutedGeometry(latent, tuple(c["tile"]), WINDOW, tuple(c["group"]), 0.5, dev())
+    kw = dict(model="wan", fp8=precision)
+    whole = routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev()), geom, **kw)
+    out = torch.full_like(whole, 7.0)
+    routed_attention(q, k, v, HeadRouting.from_expert_ids(experts, dev(), q_ranges=ranges), geom, out=out, **kw)
+    torch.cuda.synchronize()
+    for h, (t0, t1) in ranges.items():
+        assert torch.equal(out[0, h, t0:t1], whole[0, h, t0:t1]), (cfg, precision, h, t0, t1)
+        assert torch.all(torch.cat([out[0, h, :t0], out[0, h, t1:]]) == 7.0)
+    assert torch.equal(out[0, 1], whole[0, 1])
+
+
 @pytest.mark.parametrize("precision", [False, "i8pv"])
 def test_routed_attention_with_key_splits(precision):
     """routed_attention(kv_splits=n): the full-attention and coreset launches cut their keys into n parts + a merge kernel (for

@@ -308,6 +308,69 @@ def test_split_placement_reaches_one_percent_on_wan14b_at_eight_ranks():
                 assert rng[0][0] == 0 and rng[-1][1] == S and all(a[1] == b[0] for a, b in zip(rng, rng[1:]))
 
 
+def _default_placement_worker(rank, world, port, ret):
+    """no VORTA_SP_* in the environment: the processors' placement rule (vorta_amd/attention/_sp.py place_heads) takes `even`
+    where P divides the heads and `uneven` where it does not, and the placement it returns passes the exchange's self-check"""
+    for k in [k for k in os.environ if k.startswith("VORTA_SP_")]:
+        del os.environ[k]
+    _init(rank, world, port)
+    import vorta_amd.attention._sp as sp
+    from vorta_amd.ulysses import UlyssesLayout, exchange_selfcheck, slot_groups
+    P, S, T, D = world, 40 * world, 6, 8
+    res = {"default": sp.SP_PLACEMENT}
+    for H in (2 * world, 3 * world + 1):
+        experts = ([0, 2, 2, 1, 2, 2, 1] * H)[:H]
+        placement, order, counts, parts = sp.place_heads(experts, [7.0, 2.0, 1.0], P, S)
+        lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.bfloat16, counts=counts)
+        r = exchange_selfcheck(lay, order, slot_groups(lay.Hl, 1), [lay.new_buffer() for _ in range(4)])
+        res[H] = (placement, list(counts), parts is None, r["ok"])
+    ret[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_default_placement_is_auto_even_when_ranks_divide_heads(world):
+    ret = mp.Manager().dict()
+    mp.spawn(_default_placement_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        res = ret[r]
+        assert res["default"] == "auto"
+        placement, counts, whole, ok = res[2 * world]
+        assert placement == "even" and counts == [2] * world and whole and ok, (r, res)
+        placement, counts, whole, ok = res[3 * world + 1]
+        assert placement == "uneven" and sum(counts) == 3 * world + 1 and whole and ok, (r, res)
+
+
+def test_placement_rule_names():
+    from vorta_amd.ulysses.state import resolve_placement
+    assert resolve_placement("auto", 24, 8) == "even" and resolve_placement("auto", 12, 8) == "uneven"
+    assert resolve_placement("uneven", 24, 8) == "uneven" and resolve_placement("split", 40, 8) == "split"
+    with pytest.raises(ValueError):
+        resolve_placement("even", 12, 8)
+    with pytest.raises(ValueError):
+        resolve_placement("balanced", 24, 8)
+
+
+def test_split_placement_boundaries_are_workgroup_aligned_at_production_sizes():
+    """boundaries are counted from the front in `align` steps, so every boundary except S itself is a multiple
+    of `align` also where S is not (32 760 = 24 mod 32, 75 600 = 16 mod 32); parts tile each head exactly once"""
+    from vorta_amd.ulysses.engine import split_align, split_placement
+    rng = np.random.default_rng(3)
+    for S in (32760, 75600, 118800, 8320, 1000):
+        a = split_align(S)
+        assert a == (256 if S >= 4096 else 32)
+        for P in (2, 3, 4, 8):
+            for _ in range(20):
+                H = int(rng.choice([12, 24, 40]))
+                e = [int(x) for x in rng.integers(0, 3, H)]
+                order, counts, parts = split_placement(e, [5.6, 1.4, 1.0], P, S, 1, align=a)
+                for h in set(order):
+                    rs = sorted(parts[i] or (0, S) for i in range(len(order)) if order[i] == h)
+                    assert rs[0][0] == 0 and rs[-1][1] == S and all(x[1] == y[0] for x, y in zip(rs, rs[1:]))
+                    assert all(t0 % a == 0 and (t1 == S or t1 % a == 0) and t1 - t0 >= a for t0, t1 in rs), (S, P, rs)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_exchange_selfcheck_passes_and_catches_a_misordered_placement(world):
     ret = mp.Manager().dict()

@@ -35,6 +35,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("root")
     ap.add_argument("--json", required=True)
+    ap.add_argument("--head", default=os.environ.get("VORTA_TREE_HEAD"), help="git head of the profiled tree (the GPU box has no .git: "
+                    "the caller passes it, e.g. VORTA_TREE_HEAD=$(git rev-parse --short=12 HEAD) in the gpurun command)")
+    ap.add_argument("--source", default="tools/measure/r5_round.sh")
     a = ap.parse_args()
     import bench as B
     table = {}
@@ -62,7 +65,8 @@ def main():
     out = {"what": "bytes leaving the L2s (TCC -> EA requests: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024) per launch of the "
                    "attention kernels; the Infinity Cache sits BEHIND this interface (its hits are counted here), the "
                    "DRAM-side estimate is profiles/r0N_umc_activity_*.json",
-           "source": "tools/measure/r4_round.sh (round 3: measure_r3_pmc.sh): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, no trace "
+           "head": a.head,
+           "source": a.source + ": rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, no trace "
                      "domains, python3 bench.py --config C --mix M --dtype D --steps 1 --warmup 0",
            "workloads": table}
     json.dump(out, open(a.json, "w"), indent=1)

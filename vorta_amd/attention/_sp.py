@@ -13,7 +13,8 @@ import torch
 from .. import ops
 from ..routed import HeadRouting, geometry_for, routed_attention
 from ..ulysses import SP_STATE
-from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balanced_placement, exchange_and_attend, split_placement,
+from ..ulysses.state import PLACEMENTS, resolve_placement  # noqa: F401  (one rule for the processors and bench.py)
+from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balanced_placement, exchange_and_attend, split_align, split_placement,
                               slot_groups)
 
 _LAYOUTS = {}
@@ -23,12 +24,16 @@ SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
 # fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
 # 16-bit exchange with the receive-side conversion (A/B; same bytes in the operand buffers either way)
 SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
-# head placement: "uneven" (default) = the ranks' head counts follow the layer's routes (ulysses/engine.py
-# balanced_placement: whole heads are a coarse unit when H/P is small and the mix is skewed -- 24 heads with 4 full-attention
-# ones on 8 ranks: heaviest rank 1.33 of the mean cost with 3 heads each, 1.02 with 1 + ... + 5; identical to "even" when
-# the routes are balanced); "even" = H/P heads on every rank (A/B); "split" = uneven, then full-attention heads give a range
-# of their queries to the lightest ranks until the heaviest is within 1 % of the mean (`split_placement`)
-SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "uneven")
+# head placement (VORTA_SP_PLACEMENT; bench.py --placement follows the same rule through `resolve_placement`):
+#   "auto" (default) = "even" when P divides the heads, "uneven" otherwise: the exchange with equal splits is the one every
+#       test and rehearsal exercises most, and on balanced routes the two are the same placement;
+#   "even"   = H/P heads on every rank, LPT order inside (ulysses/engine.py balanced_head_order);
+#   "uneven" = the ranks' head COUNTS follow the layer's routes (balanced_placement: whole heads are a coarse unit when H/P is
+#       small and the mix is skewed -- 24 heads with 4 full-attention ones on 8 ranks: heaviest rank 1.33 of the mean cost with
+#       3 heads each, 1.02 with 1 + ... + 5); variable-split all_to_all_single, padded text all-gather;
+#   "split"  = uneven, then full-attention heads give a range of their queries to the lightest ranks until the heaviest is
+#       within 1 % of the mean (`split_placement`).  Opt-in, like the key splits below.
+SP_PLACEMENT = __import__("os").environ.get("VORTA_SP_PLACEMENT", "auto")
 # key splits of the full-attention / coreset launches: "1" (default), a number, or "auto" = per layer from this rank's count
 # of workgroups (a rank whose one or two heads leave the chip under one round of workgroups: small models on many ranks;
 # changes the summation order -- ulysses/engine.py, bench.py --kv-splits)
@@ -98,6 +103,28 @@ def _routing(local_experts: tuple, device, q_ranges: tuple = ()) -> HeadRouting:
     return r
 
 
+def place_heads(experts, cost, P: int, S: int, dense_only: bool = False, placement: Optional[str] = None, groups: Optional[int] = None):
+    """(placement taken, head order, heads per rank, query ranges or None) of one layer: VORTA_SP_PLACEMENT (default `auto`)
+    resolved by `resolve_placement`, then the engine's placement of that name.
+    VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot groups (as
+    equal as the slot count allows), so the exchange of one group overlaps the attention of another."""
+    H = len(experts)
+    groups = SP_GROUPS if groups is None else groups
+    placement = resolve_placement(SP_PLACEMENT if placement is None else placement, H, P)
+    parts = None
+    if placement == "split" and H >= P and not dense_only:
+        # below whole heads: full-attention heads give a range of their queries to the lightest ranks (ulysses/engine.py
+        # split_placement; the part that ends at the last video token keeps the head's text queries)
+        order, counts, parts = split_placement(experts, cost, P, S, groups, align=split_align(S))
+        if not any(x is not None for x in parts):
+            parts = None
+    elif placement in ("uneven", "split") and H >= P:
+        order, counts = balanced_placement(experts, cost, P, groups)
+    else:
+        order, counts = balanced_head_order(experts, cost, P, min(groups, H // P)), [H // P] * P
+    return placement, order, counts, parts
+
+
 def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_sparse: Optional[float], *, model: str,
                  text_valid: int = 0, attention_mask=None, lowres_group_info=None, window_size=(3, 3, 3),
                  tile_size=(6, 8, 8), latent_shape=None, experts_host=None) -> torch.Tensor:
@@ -132,19 +159,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
         s_low = (S // g) * int(g * (1 - lowres_group_info.reduction_rate))
         _, _, n_kv = ops.sta_table_sizes(latent_shape, tile_size, window_size, te)
         cost = [float(S + te) ** 2, float(s_low + te) ** 2, float(S) * n_kv]
-    # VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot
-    # groups (as equal as Hl allows), so the exchange of one group overlaps the attention of another
-    parts = None
-    if SP_PLACEMENT == "split" and H >= P and not dense_only:
-        # below whole heads: full-attention heads give a range of their queries to the lightest ranks (ulysses/engine.py
-        # split_placement; the part that ends at the last video token keeps the head's text queries)
-        order, counts, parts = split_placement(experts, cost, P, S, SP_GROUPS, align=256 if S >= 32768 else 32)
-        if not any(x is not None for x in parts):
-            parts = None
-    elif SP_PLACEMENT in ("uneven", "split") and H >= P:
-        order, counts = balanced_placement(experts, cost, P, SP_GROUPS)
-    else:
-        order, counts = balanced_head_order(experts, cost, P, min(SP_GROUPS, H // P)), [H // P] * P
+    placement, order, counts, parts = place_heads(experts, cost, P, S, dense_only)
+    sp_attention.last_placement = placement  # (what a test or a curious caller reads back)
     lay, sb = _layout(H, S, T, D, q.device, q.dtype, counts)
     bufs = sb.bufs
     groups = min(SP_GROUPS, min(counts))

@@ -112,6 +112,12 @@ def balanced_placement(experts: Sequence[int], cost_of_expert: Sequence[float], 
     return order, counts
 
 
+def split_align(n_tokens: int) -> int:
+    """granularity of a query-range boundary: the 256 query rows of a workgroup (a part then starts on a workgroup of the
+    whole-head launch); 32 = one wave only where a head has a handful of workgroups (tests, tiny shapes)"""
+    return 256 if n_tokens >= 16 * 256 else 32
+
+
 def split_placement(experts: Sequence[int], cost_of_expert: Sequence[float], P: int, n_tokens: int, groups: int = 1,
                     max_heads: Optional[int] = None, tol: float = 0.01, align: int = 256, max_parts: int = 2):
     """`balanced_placement`, then BELOW whole heads: while the heaviest rank carries more than (1 + tol) x the mean, one of
@@ -156,12 +162,17 @@ def split_placement(experts: Sequence[int], cost_of_expert: Sequence[float], P: 
         t0, t1 = rng.get((R, h), (0, n_tokens))
         move = min(load[R] - mean, mean - load[r])
         n = min(int(round(move / step)) * align, (t1 - t0) - align)
-        if n < align:
+        # the boundary is counted from the FRONT of the sequence in `align` steps: only the part that ends at the last
+        # token may be ragged (n_tokens itself need not be a multiple of 32: 32 760, 75 600), so every wave and every
+        # 256-row workgroup of a part is a wave / workgroup of the whole-head launch
+        cut = ((t1 - n) // align) * align
+        if cut * 1 <= t0 or t1 - cut < align or cut - t0 < align:
             break
+        n = t1 - cut
         if (R, h) not in rng:
             n_parts[R] += 1
-        rng[(R, h)] = (t0, t1 - n)
-        rng[(r, h)] = (t1 - n, t1)
+        rng[(R, h)] = (t0, cut)
+        rng[(r, h)] = (cut, t1)
         n_parts[r] += 1
         bins[r].append(h)
         load[R] -= n / align * step
@@ -927,7 +938,7 @@ class UlyssesRoutedAttention:
                 order, counts = balanced_placement(e, costs, P, groups)
             else:
                 # whole 256-row workgroups at full size; small rehearsal sequences need finer steps to move anything
-                order, counts, parts = split_placement(e, costs, P, S, groups, align=256 if S >= 32768 else 32)
+                order, counts, parts = split_placement(e, costs, P, S, groups, align=split_align(S))
                 if not any(x is not None for x in parts):
                     parts = None
             starts = [sum(counts[:j]) for j in range(P + 1)]

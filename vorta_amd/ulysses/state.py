@@ -50,3 +50,19 @@ class SequenceParallelState:
 
 
 SP_STATE = SequenceParallelState()
+
+
+# head -> rank placements of the zero-copy exchange (vorta_amd/attention/_sp.py says what each is)
+PLACEMENTS = ("auto", "even", "uneven", "split")
+
+
+def resolve_placement(name: str, H: int, P: int) -> str:
+    """The placement a layer of H heads takes on P ranks: `auto` -> even when P divides H, uneven otherwise; even with
+    P not dividing H is refused (there is no such exchange), anything unknown too."""
+    if name not in PLACEMENTS:
+        raise ValueError(f"VORTA_SP_PLACEMENT / --placement must be one of {PLACEMENTS}, got {name!r}")
+    if name == "auto":
+        return "even" if H % max(P, 1) == 0 else "uneven"
+    if name == "even" and H % max(P, 1) != 0:
+        raise ValueError(f"placement 'even' needs the rank count ({P}) to divide the heads ({H}); use 'auto' or 'uneven'")
+    return name
