@@ -528,90 +528,12 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     SCHED_S()                                                                     \
     PRIO_LO()                                                                     \
   }
-  // VORTA_I8_MERGE (8-wave kernels): ONE dataflow for every wave -- step j = [P V of block j-1 with the multiply-adds, the row
-  // max of block j and the seeds of block j+1 in the shadows of its five 64-cycle MFMAs] -> rare branches -> [scores of block
-  // j+1 with the byte conversions of block j in their shadows] -- instead of a matrix part and a VALU part that the two waves of
-  // a SIMD swap.  A wave issues in order: with a VALU part of its own a wave's step is the SUM of its two parts (~660 + ~800
-  // cycles); here the vector work rides under the wave's own MFMAs and the two waves of a SIMD interleave MFMA by MFMA.  The
-  // halves of the workgroup are staggered by where they place their tile requests (REQ_A: waves 0-3, REQ_B: waves 4-7;
-  // 0 top of the step, 1 between the two halves, 2 end of the step).
-#ifndef VORTA_I8_MERGE
-#define VORTA_I8_MERGE 0
-#endif
-#ifndef VORTA_I8_REQ_A
-#define VORTA_I8_REQ_A 1
-#endif
-#ifndef VORTA_I8_REQ_B
-#define VORTA_I8_REQ_B 0
-#endif
-#if VORTA_I8_SCHED == 1
-#define SCHED_MY()                                                                \
-  SG_(0x100, 9)                                                                   \
-  SG_(0x008, 1) SG_(0x100, 8) SG_(0x002, 10) SG_(0x200, 1)                        \
-  SG_(0x008, 1) SG_(0x002, 11)                                                    \
-  SG_(0x008, 1) SG_(0x002, 11) SG_(0x100, 4)                                      \
-  SG_(0x008, 1) SG_(0x002, 11) SG_(0x100, 4)                                      \
-  SG_(0x008, 1) SG_(0x002, 16)
-#else
-#define SCHED_MY()
-#endif
-#define REQ_ALL(kw_, vw_, bw_)                                                    \
-  DMA_K(kw_)                                                                      \
-  DMA_V(vw_)                                                                      \
-  REQ_TAIL(bw_)                                                                   \
-  __builtin_amdgcn_sched_barrier(0);
-#define MATRIX_PART_Y(kr_, vr_, sr_, pbr_, pbw_, jabs_, bs_, ss_, mid_)           \
-  {                                                                               \
-    PRIO_HI()                                                                     \
-    i32x4 kfa_[4], kfb_[4];                                                       \
-    i32x8 vf_[4];                                                                 \
-    const float sb_ = *(const float*)(smem + bias_rd + (bs_) * SC_BYTES);         \
-    VFRAG(0, vr_) VFRAG(1, vr_) VFRAG(2, vr_) VFRAG(3, vr_)                       \
-    lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pbr_, lacc, 4, 0, 0, 0, 0, 0); \
-    TIE_(lacc, vf_[0])                                                            \
-    {                                                                             \
-      const float s_ = __builtin_amdgcn_fmed3f(sb_ * inv_q, -SEED_LIMIT, SEED_LIMIT); \
-      *(int*)(smem + seed_wr + (ss_) * SC_BYTES) = MAGIC_I + (int)__builtin_rintf(s_); \
-    }                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, off8); \
-    o[0] = mfma8(vf_[0], pbr_, o[0]);                                             \
-    TIE_(o[0], vf_[1])                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, off8); \
-    o[1] = mfma8(vf_[1], pbr_, o[1]);                                             \
-    TIE_(o[1], vf_[2])                                                            \
-    SEEDS_IN(n0, sr_, 0)                                                          \
-    KFRAGS(kfa_, kr_, 0)                                                          \
-    ROW_MAX_POS(mx_cur, y0, y1)                                                   \
-    o[2] = mfma8(vf_[2], pbr_, o[2]);                                             \
-    TIE_(o[2], vf_[3])                                                            \
-    o[3] = mfma8(vf_[3], pbr_, o[3]);                                             \
-    SCHED_MY()                                                                    \
-    if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(jabs_) ROW_MAX(mx_cur, y0, y1) }  \
-    if (!__all(mx_cur <= ythr)) {                                                 \
-      const float g8_ = fmaxf(mx_cur - ybias, 0.f);                               \
-      RAISE_REF(g8_)                                                              \
-    }                                                                             \
-    mid_                                                                          \
-    SEEDS_IN(n1, sr_, 1)                                                          \
-    KFRAGS(kfb_, kr_, 1)                                                          \
-    QK_TILE(n0, kfa_)                                                             \
-    TIE_(n0, n1)                                                                  \
-    QK_TILE(n1, kfb_)                                                             \
-    PACK_Y(pbw_)                                                                  \
-    TIE_(n1, pbw_)                                                                \
-    SCHED_S()                                                                     \
-    PRIO_LO()                                                                     \
-  }
   // Diagnostic builds only (suffixed libraries: vorta_amd/build.py refuses extra flags for the product): -DVORTA_I8_DIAG pulls
   // in the in-loop cycle stamps (-DVORTA_TRACE_I8=i, tools/trace_i8.py) and the wrong-result timing ablations
   // (-DVORTA_I8_DIAG_*), which re-define the macros above.
 // which half of the workgroup starts its steps with the VALU part (the e4m3 kernel measured 0-3.6 % between the two, by body;
 // here the later-dispatched half: 26.5 against 26.8-27.2 ms, profiles/r04_i8_ablation.txt part 6)
-#if VORTA_I8_MERGE
-#define ROLE_Y_ (NW == 8)  /* one dataflow: the prologue and the drain are role Y's */
-#else
 #define ROLE_Y_ (NW == 8 && wave >= NW / 2)
-#endif
 #define TR_(i_)
 #define TR_FLUSH_()
 #ifdef VORTA_I8_DIAG
@@ -619,32 +541,6 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #endif
   // both roles request their tile pieces inside their VALU part (role X behind its matrix part: it goes from the barrier
   // straight into its MFMAs); the 4-wave kernels (no roles) and waves past the query rows request at the top of the step
-#if VORTA_I8_MERGE
-#define STEP(kw_, kr_, vw_, vr_, bw_, sr_, bsx_, ssx_, bsy_, ssy_, pbr_, pbw_, jabs_) \
-  {                                                                               \
-    TR_(0)                                                                        \
-    if (!wave_active || NW != 8) { STAGE_DMA(kw_, vw_, bw_, jabs_) }              \
-    TR_(1)                                                                        \
-    if (wave_active) {                                                            \
-      if constexpr (NW == 8) {                                                    \
-        if (req_at == 0) { REQ_ALL(kw_, vw_, bw_) }                               \
-        __builtin_amdgcn_sched_barrier(0);                                        \
-        TR_(2)                                                                    \
-        MATRIX_PART_Y(kr_, vr_, sr_, pbr_, pbw_, jabs_, bsy_, ssy_, if (req_at == 1) { REQ_ALL(kw_, vw_, bw_) }) \
-        __builtin_amdgcn_sched_barrier(0);                                        \
-        TR_(3)                                                                    \
-        if (req_at == 2) { REQ_ALL(kw_, vw_, bw_) }                               \
-        TR_(4)                                                                    \
-      } else {                                                                    \
-        MATRIX_PART(kr_, vr_, sr_, pbr_, pbw_, jabs_, , )                         \
-        __builtin_amdgcn_sched_barrier(0);                                        \
-        VALU_PART(bsx_, ssx_, , , )                                               \
-      }                                                                           \
-    }                                                                             \
-    STEP_SYNC()                                                                   \
-  }
-  const int req_at = wave < NW / 2 ? VORTA_I8_REQ_A : VORTA_I8_REQ_B;  // wave-uniform
-#else
 #define STEP(kw_, kr_, vw_, vr_, bw_, sr_, bsx_, ssx_, bsy_, ssy_, pbr_, pbw_, jabs_) \
   {                                                                               \
     TR_(0)                                                                        \
@@ -672,7 +568,6 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     STEP_SYNC()                                                                   \
   }
 
-#endif
   const int nsteps = blk1 - blk0;
   const bool role_y = ROLE_Y_;  // wave-uniform
   if (nsteps > 0) {
