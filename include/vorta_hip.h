@@ -31,12 +31,14 @@ extern "C" {
 #define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
 #define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
 
-#define VORTA_ABI_VERSION 6 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
+#define VORTA_ABI_VERSION 7 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
                                 4: vorta_fp8_quant_args gains slot_first / slot_count and flags bit2, adds vorta_fp8_v_absmax /
                                 vorta_fp8_v_convert; every earlier call means what it meant
                                 5: vorta_fp8_quant_args gains video_tokens / token_offset / total_tokens / src_map and flags
                                 bit3 / bit4 (sequence shards), adds vorta_fp8_quant_ws_partials
-                                6: adds the int8-score entry points (vorta_i8_quantize_k, vorta_attn_fwd_i8, vorta_attn_fwd_batch_i8) */
+                                6: adds the int8-score entry points (vorta_i8_quantize_k, vorta_attn_fwd_i8, vorta_attn_fwd_batch_i8);
+                                7: the int8-score kernel writes its probabilities with one power-of-two scale per query row
+                                   and 32 keys (vorta_attn_i8_ext.defer becomes the reference-point trigger in binades, default 24) */
 
 typedef enum vorta_dtype {
   VORTA_BF16 = 0,
@@ -321,11 +323,15 @@ int vorta_i8_quantize_k(const vorta_i8_quant_args* args, void* hip_stream);
  *   args->o: 16-bit (args->dtype).
  *   score of (query i of wave w, key j) in the exp2 domain = u (q8[i] . k8[j] + rint(k_bias[j] / sq[w])), u = scale log2(e)
  *   sq[w] sk[head] (the int32 accumulator starts from the rounded bias; |bias| is clamped to 2 000 000 units).
- *   Probabilities: P' = P 2^p_bias per 64-key block against the wave's reference point as in the mixed kernel, but written
- *   to e4m3 by ONE conversion instead of exp2 + round: the byte is rint(8 x + 56) for x = log2 P' (v_cvt_pk_u8_f32,
- *   saturating at 0), i.e. the e4m3 number whose exponent field is the integer part of x and whose mantissa is the LINEAR
- *   interpolation of its fraction (+-3 % of 2^x: costs ~0.5-0.8 dB of output PSNR, removes the transcendental and the
- *   pack from the loop).  Tables, groups, duplicates, split keys and the fused grid as vorta_attn_fwd_fp8.
+ *   Probabilities: P' = 2^(score - reference + p_bias) against the row's reference point (its first block's maximum; it moves
+ *   only when a later block lies more than `defer` binades above it), written to e4m3 by ONE conversion instead of exp2 +
+ *   round, with ONE POWER-OF-TWO SCALE PER QUERY ROW AND 32 KEYS (ABI 7): for y = 8 log2 P' + 56 and e = max(rint((max y over
+ *   the 32 consecutive keys of one half of the 64-key block - 120) / 8), -100), the byte is rint(y - 8 e) (v_cvt_pk_u8_f32, saturating at 0:
+ *   the e4m3 number whose exponent field is the integer part of log2 P' - e and whose mantissa is the LINEAR interpolation of
+ *   its fraction, +-3 % of 2^x) and 2^e is the block scale of the P V MFMA's B operand (v_mfma_scale_f32_32x32x64_f8f6f4).
+ *   The range of a probability is the scale's, not e4m3's: nothing is flushed for lying far below the ROW's maximum (up to ABI
+ *   6 everything below 2^-14 ... 2^-11
+ *   of it was).  Tables, groups, duplicates, split keys and the fused grid as vorta_attn_fwd_fp8.
  */
 typedef struct vorta_attn_i8_ext {
   uint32_t struct_size;
@@ -337,7 +343,7 @@ typedef struct vorta_attn_i8_ext {
   const float* k_head_scale;   /* [..], indexed by the head id */
   const float* v_descale;      /* [..][head_dim], indexed by the head id */
   int64_t v_descale_stride_h;
-  float p_bias, defer;         /* as vorta_attn_fp8_ext (0 = defaults 5 and 3) */
+  float p_bias, defer;         /* 0 = defaults: p_bias 5 (0 ... 16); defer 24 binades (0 ... 64: P' <= 2^(defer + 9) in fp32) */
 } vorta_attn_i8_ext;
 
 int vorta_attn_fwd_i8(const vorta_attn_args* args, const vorta_attn_i8_ext* ext, void* hip_stream);

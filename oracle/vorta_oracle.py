@@ -510,6 +510,12 @@ def _fp8_flash_rows(Q: np.ndarray, K: np.ndarray, V: np.ndarray, blk_lo: int, bl
     O = np.zeros((n, V.shape[1]))
     l = np.zeros(n)
     m = None
+    if p_mode == "mx":
+        # the kernel's byte-domain offset is ~1.5 2^23 x 8 u (u = one integer score unit in the exp2 domain, the operands' last
+        # column) rounded to fp32 twice (the row's offset, then the tile's): a probability's y may sit that far from this
+        # restatement's -- the width of the midpoint band of `ambiguous`
+        slack = max(2e-3, 2.0 ** -22 * 12582912.0 * 8.0 * abs(float(Q[0, -1])))
+        return _i8_mx_flash_rows(z_all, V, blk_lo, blk_hi, p_bias, defer, round_p, block, ambiguous, slack)
     for j in range(blk_lo, blk_hi):
         lo, hi = (j - blk_lo) * block, min((j - blk_lo + 1) * block, z_all.shape[1])
         z = z_all[:, lo:hi]
@@ -529,8 +535,8 @@ def _fp8_flash_rows(Q: np.ndarray, K: np.ndarray, V: np.ndarray, blk_lo: int, bl
                 m = m + g
         P = np.exp2(z - m[:, None] + p_bias)
         if round_p and p_mode == "direct":
-            # vorta_attn_fwd_i8: the e4m3 BYTE is rint(8 x + 56), x = log2 P' (one v_cvt_pk_u8_f32, saturating at 0): exponent
-            # field = integer part of x, mantissa = linear interpolation of its fraction
+            # the int8-score kernel up to ABI 6: the e4m3 BYTE is rint(8 x + 56), x = log2 P' (one v_cvt_pk_u8_f32, saturating at
+            # 0): exponent field = integer part of x, mantissa = linear interpolation of its fraction
             y = 8.0 * (z - m[:, None] + p_bias) + 56.0
             if ambiguous is not None:
                 near = np.rint(y + 2e-3) != np.rint(y - 2e-3)
@@ -542,6 +548,72 @@ def _fp8_flash_rows(Q: np.ndarray, K: np.ndarray, V: np.ndarray, blk_lo: int, bl
                 near = e4m3_round(P * (1 + _FP8_AMBIG)) != e4m3_round(P * (1 - _FP8_AMBIG))
                 ambiguous += (P * near).sum(1)
             P = e4m3_round(P)
+        l += P.sum(1)
+        O += P @ V[j * block:j * block + (hi - lo)]
+    return O, l, m
+
+
+I8_YMID = 120.0   # a tile's largest byte-domain value lands in [116, 124] (0x7E = 126 = 448 is the largest e4m3)
+I8_EMIN = -100.0  # block exponent >= -100 (no upper clamp: the reference point moves under a tile that lies far above it)
+# a scale block of the P V MFMA's B operand = one query row x the 32 consecutive keys of one key tile of the 64-key block
+# (8-bit operands: bytes 16 s ... 16 s + 15 of both lanes of a column; tools/probe_mx_scale.hip)
+_I8_GROUP = np.arange(64) >> 5
+
+
+def _i8_mx_flash_rows(z_all: np.ndarray, V: np.ndarray, blk_lo: int, blk_hi: int, p_bias: float, etrig: float, round_p: bool,
+                      block: int, ambiguous: Optional[np.ndarray], slack: float = 2e-3):
+    """One wave of vorta_attn_fwd_i8 (ABI 7, attn_fwd_i8.hip): MX-SCALED probabilities.  Byte domain y = 8 (z - m + p_bias) + 56
+    against the row's reference point m (the maximum of its first block).  Per 64-key block and per KEY TILE of 32 consecutive
+    keys (`_I8_GROUP`; keys past the end of the list repeat the last one: the kernel clamps its rows), for every query row: the
+    block exponent e = max(rint((max y - 120) / 8), -100), the bytes rint(y - 8 e) (saturating at 0; masked keys 0), the
+    probability = e4m3(byte) 2^e: the scale goes to the P V MFMA as the B operand's block scale.  The reference point moves
+    only when some (row, tile) of the wave has e > etrig: then every row moves by max(its larger e, 0) whole binades (bytes
+    unchanged).  `ambiguous`: as `_fp8_flash_rows`, plus -- where a tile's exponent is within noise of its neighbour -- the
+    mass of its probabilities below byte 16 (one exponent further they decode through e4m3's linear subnormals, not to the
+    same values)."""
+    assert block == 64
+    n = z_all.shape[0]
+    O = np.zeros((n, V.shape[1]))
+    l = np.zeros(n)
+    m = None
+    for j in range(blk_lo, blk_hi):
+        lo, hi = (j - blk_lo) * block, min((j - blk_lo + 1) * block, z_all.shape[1])
+        z = z_all[:, lo:hi]
+        if m is None:
+            m = z.max(1)
+        y = 8.0 * (z - m[:, None] + p_bias) + 56.0
+        ypad = np.concatenate([y, np.repeat(y[:, -1:], block - (hi - lo), 1)], 1) if hi - lo < block else y
+        ymx = np.stack([ypad[:, _I8_GROUP == g].max(1) for g in (0, 1)], 1)  # (n, 2)
+        t = (ymx - I8_YMID) / 8.0
+        with np.errstate(invalid="ignore"):
+            e = np.maximum(np.rint(np.where(np.isfinite(t), t, I8_EMIN)), I8_EMIN)
+        e_near = np.abs(np.abs(t - np.floor(t)) - 0.5) < slack / 4.0  # a correct kernel may round the other way
+        if j > blk_lo:
+            # (a trigger within noise of its threshold needs no mark: moving the reference point changes power-of-two scales on
+            # both sides of the accumulation, not one byte and not one value)
+            if (e > etrig).any():
+                g = np.maximum(e.max(1), 0.0)
+                a = np.exp2(-g)
+                O *= a[:, None]
+                l *= a
+                if ambiguous is not None:
+                    ambiguous *= a
+                m = m + g
+                e = np.maximum(e - g[:, None], I8_EMIN)
+                y = y - 8.0 * g[:, None]
+        ek = e[:, _I8_GROUP[:hi - lo]]  # (n, keys): each key's lane exponent
+        yp = y - 8.0 * ek
+        Pex = np.exp2(z - m[:, None] + p_bias)
+        if round_p:
+            with np.errstate(invalid="ignore"):
+                byte = np.clip(np.rint(np.where(np.isfinite(yp), yp, 0.0)), 0, 126).astype(np.int64)
+            P = e4m3_decode(byte) * np.exp2(ek)
+            if ambiguous is not None:
+                near = np.rint(yp + slack) != np.rint(yp - slack)
+                ambiguous += (Pex * near).sum(1)
+                ambiguous += (Pex * ((byte < 16) & e_near[:, _I8_GROUP[:hi - lo]])).sum(1)
+        else:
+            P = Pex
         l += P.sum(1)
         O += P @ V[j * block:j * block + (hi - lo)]
     return O, l, m
@@ -565,7 +637,9 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
     sizes where every wave would take hours); rows of the other waves are left untouched.
     `wave_operands(query_rows, key_rows) -> (Qw, Kw)`, optional: the score operands of ONE wave (vorta_attn_fwd_i8: the query
     scale, hence the rounded key biases, belong to the wave -- `i8_wave_operands`); q and k are then not read.
-    `p_mode="direct"`: the probabilities' bytes are rint(8 log2 P' + 56) (see `_fp8_flash_rows`)."""
+    `p_mode="direct"`: the probabilities' bytes are rint(8 log2 P' + 56) (see `_fp8_flash_rows`); `p_mode="mx"`: vorta_attn_fwd_i8
+    since ABI 7 -- one power-of-two scale per lane and block (`_i8_mx_flash_rows`; `defer` is then the trigger in binades,
+    24 in the kernel's default)."""
     q_valid = n_q if q_valid is None else q_valid
     glen = q_group_len if q_group_len > 0 else n_q
     if q_group_bounds is None:  # equal groups; else [start, end) of every group (vorta_attn_args.q_block_table)
@@ -613,11 +687,12 @@ def fp8_attn_launch(q: np.ndarray, k: np.ndarray, v: np.ndarray, out: np.ndarray
                             ambiguous[dup_rows[p_]] = amb[i]
 
 
-# ---------------------------------------------------------------------------------------------- int8 scores (ABI 6)
+# ---------------------------------------------------------------------------------------------- int8 scores (ABI 6-7)
 # No reference counterpart either: this restates include/vorta_hip.h vorta_i8_quantize_k (csrc/i8_quant.hip) and the query
 # conversion at the head of vorta_attn_fwd_i8 (csrc/attn_fwd_i8.hip) operation for operation in float32, so the kernels can be
 # held to it bit for bit; the attention itself is `fp8_attn_launch` with `wave_operands` (the scores of a wave are
-# u (q8 . k8 + seed), an exact integer dot product) and `p_mode="direct"` (the probabilities' e4m3 bytes are rint(8 x + 56)).
+# u (q8 . k8 + seed), an exact integer dot product) and `p_mode="mx"` (the probabilities' e4m3 bytes are rint(8 x + 56 - 8 e)
+# with one block exponent e per lane: `_i8_mx_flash_rows`).
 I8_MAGIC_LIMIT = 2000000.0  # |bias| in integer score units is clamped to this (the int32 accumulator is read as a float)
 
 
@@ -698,7 +773,8 @@ def i8_wave_operands(q_rows: np.ndarray, q_prep: np.ndarray, sk: float, k8: np.n
     q8 = np.clip(np.rint((qt * inv).astype(f32)), -127, 127).astype(np.float64)
     sq = (am * f32(1.0 / 127.0)) if am > 0 else f32(1.0)
     u = f32(f32(sq * c0) * f32(sk))
-    seed = np.clip(np.rint((np.asarray(k_bias, f32) * inv).astype(f32)), -I8_MAGIC_LIMIT, I8_MAGIC_LIMIT).astype(np.float64)
+    # (ABI 7: ONE rounding of the exact product -- the kernel's fused multiply-add into the binade of 1.5 2^23 -- then the clamp)
+    seed = np.clip(np.rint(np.asarray(k_bias, np.float64) * np.float64(inv)), -I8_MAGIC_LIMIT, I8_MAGIC_LIMIT)
     Q = np.concatenate([q8 * float(u), np.full((q8.shape[0], 1), float(u))], 1)
     K = np.concatenate([np.asarray(k8, np.float64), seed[:, None]], 1)
     return Q, K

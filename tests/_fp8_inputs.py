@@ -15,6 +15,18 @@ def psnr(x, ref):
     return f(rng), f(peak), math.sqrt(mse / torch.mean(ref ** 2).item())
 
 
+def robust_psnr(x, ref, q=0.999):
+    """PSNR over a ROBUST peak, the q-quantile of |ref| (a sample of <= 4M elements): on heavy-tailed inputs max |ref| sits
+    far above the bulk and a PSNR over it says little about the bulk's error"""
+    x, ref = x.float(), ref.float()
+    a = ref.abs().flatten()
+    if a.numel() > (1 << 22):
+        a = a[:: a.numel() // (1 << 22)]
+    peak = torch.quantile(a, q).item()
+    mse = torch.mean((x - ref) ** 2).item()
+    return 10.0 * math.log10(peak * peak / max(mse, 1e-30))
+
+
 def unit_rms(x):
     return x / x.pow(2).mean(-1, keepdim=True).sqrt()
 

@@ -537,7 +537,7 @@ def test_i8pv_headline_sizes_sampled_waves_vs_oracle_emulator(config):
             picks.add((g, 32 * int(gen.integers(-(-lens[g] // 32)))))
         return lambda g, w0: (g, w0) in picks
 
-    kw = dict(p_mode="direct")
+    kw = dict(p_mode="mx", defer=24.0)
     more = int(os.environ.get("VORTA_TEST_MORE_WAVES", "1"))  # an extended run samples this many times more waves
     nq = S + T
     picks = some([nq], 4 * more)

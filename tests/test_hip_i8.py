@@ -1,11 +1,11 @@
-"""GPU parity of the INT8-SCORE attention (csrc/attn_fwd_i8.hip + csrc/i8_quant.hip; include/vorta_hip.h ABI 6): scores on
+"""GPU parity of the INT8-SCORE attention (csrc/attn_fwd_i8.hip + csrc/i8_quant.hip; include/vorta_hip.h ABI 6-7): scores on
 v_mfma_i32_32x32x32_i8 with one scale per key row and per query row, P V in e4m3.  Gates:
   (q)   the quantiser against the oracle's float32 restatement: int8 bytes, row biases, query centre / balance vector, head
         scale and key centre BIT FOR BIT (plain layout); the segmented Ulysses layout and slot groups write the bytes of the
         plain call;
   (i)   kernel vs the oracle's emulator on the SAME operands -- per wave u (q8 . k8 + seed) with the wave's own query
         conversion restated (O.i8_wave_operands), v decoded from the e4m3 bytes -- with the probabilities' bytes written as the
-        kernel writes them (rint(8 log2 P' + 56)) at the kernel's reference points: the 16-bit tolerances plus the emulator's
+        kernel writes them (rint(8 log2 P' + 56 - 8 e), one block exponent e per lane) at the kernel's reference points: the 16-bit tolerances plus the emulator's
         midpoint slack (dense ragged, tables / groups / duplicates / head lists, the rescale branch, split keys);
   (i')  kernel vs exact attention on the same operands: rel. Frobenius <= 4e-2;
   (ii)  operator PSNR against the bf16 kernels on every input family of tests/_fp8_inputs.py, both geometries, every expert:
@@ -145,7 +145,7 @@ def test_i8_dense_ragged_vs_emulator(dtype, block_rows):
     ref, exact, amb = np.zeros((H, Sq, 128)), np.zeros((H, Sq, 128)), np.zeros((H, Sq))
     for h in range(H):
         O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, ambiguous=amb[h],
-                          wave_operands=hooks[h], p_mode="direct")
+                          wave_operands=hooks[h], p_mode="mx", defer=24.0)
         O.fp8_attn_launch(None, None, ve[h], exact[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, round_p=False,
                           wave_operands=hooks[h])
     _check(out, ref, dtype, amb, _vmax(ve, vde))
@@ -158,8 +158,10 @@ def test_i8_dense_ragged_vs_emulator(dtype, block_rows):
 
 
 def test_i8_rescale_branch_long_keys_and_split_keys():
-    """key norms grow along the sequence (the reference point of every wave moves several times); then the same keys cut
-    into 3 and 8 splits with the combine kernel"""
+    """key norms grow along the sequence: the blocks climb tens of binades above the first one's maximum.  With the trigger at
+    1 binade (`defer`) the reference point of every wave moves many times, with the default (24) never or once -- both against
+    the emulator at the same trigger, and against each other (a threshold sweep: the branch changes scales, not values); then
+    the same keys cut into 3 and 8 splits with the combine kernel"""
     from vorta_amd import ops
     dtype = torch.float16
     rng = np.random.default_rng(2)
@@ -172,14 +174,26 @@ def test_i8_rescale_branch_long_keys_and_split_keys():
     v8, vd, _ = ops.fp8_quantize_v(to_dev(v, dtype))
     hooks = _hooks(qd, i8)
     ve, vde = _vdec(v8, vd)
-    for n_splits in (1, 3, 8):
-        out = torch.empty((H, Sq, 128), dtype=dtype, device=dev())
-        ops.attn_fwd(qd[:, :Sq], i8.k8, v8, out, n_q=Sq, n_kv=Skv, v_descale=vd, n_splits=n_splits, i8=i8)
-        ref, amb = np.zeros((H, Sq, 128)), np.zeros((H, Sq))
-        for h in range(H):
-            O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=Sq, n_kv=Skv, n_splits=n_splits, ambiguous=amb[h],
-                              wave_operands=hooks[h], p_mode="direct")
-        _check(out, ref, dtype, amb, _vmax(ve, vde))
+    outs = {}
+    for defer in (1.0, 24.0):
+        for n_splits in (1, 3, 8):
+            out = torch.empty((H, Sq, 128), dtype=dtype, device=dev())
+            ops.attn_fwd(qd[:, :Sq], i8.k8, v8, out, n_q=Sq, n_kv=Skv, v_descale=vd, n_splits=n_splits, i8=i8,
+                         fp8_opts={"defer": defer})
+            ref, amb = np.zeros((H, Sq, 128)), np.zeros((H, Sq))
+            moved = 0
+            for h in range(H):
+                O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=Sq, n_kv=Skv, n_splits=n_splits, ambiguous=amb[h],
+                                  wave_operands=hooks[h], p_mode="mx", defer=defer)
+            _check(out, ref, dtype, amb, _vmax(ve, vde))
+            outs[(defer, n_splits)] = out.float().cpu().numpy()
+        # the emulator's own reference points: with the low trigger they end far above the first block's maximum
+    Qw, Kw = hooks[0](np.arange(32), np.arange(Skv))
+    m_lo = O._fp8_flash_rows(Qw, Kw, ve[0], 0, Skv // 64, 5.0, 1.0, True, p_mode="mx")[2]
+    m_hi = O._fp8_flash_rows(Qw, Kw, ve[0], 0, Skv // 64, 5.0, 24.0, True, p_mode="mx")[2]
+    first = (Qw @ Kw[:64].T).max(1)
+    assert (m_lo - first).min() > 4.0 and np.all(m_hi - first < m_lo - first + 1e-9)
+    assert rel_fro(outs[(1.0, 1)], outs[(24.0, 1)]) < 2e-3  # scales moved, values did not
 
 
 @pytest.mark.parametrize("block_rows", [128, 256])
@@ -211,7 +225,7 @@ def test_i8_tables_groups_duplicates_heads(block_rows):
     for h in (3, 0):
         O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=n_q, n_kv=n_kv, q_rows=q_rows, q_group_len=glen,
                           kv_rows=kv_rows, dup_rows=dup, n_dup_pos=60, ambiguous=amb[h], wave_operands=hooks[h],
-                          p_mode="direct")
+                          p_mode="mx", defer=24.0)
     _check(out, ref, dtype, amb, _vmax(ve, vde))
     assert torch.all(out[2] == 0) and torch.all(out[1] == 0)
 
@@ -260,12 +274,23 @@ def test_i8_routed_attention_vs_oracle(model, fused):
 # the targets of VERDICT r03 item 2 (dB over max|x| of the bf16 result), not the measured values
 I8_GATES = {"white": 40.0, "common3": 40.0, "student_t3": 40.0, "smooth": 40.0, "peaked": 40.0, "outlier_w": 40.0,
             "outlier_w_common": 39.0}
+# the relative Frobenius error against the bf16 kernels, which a PSNR over max|x| hides on heavy tails.  Up
+# to ABI 6 the probabilities' RANGE cost 0.09-0.13 on the common-part and smooth families and 0.14-0.21 on Student-t; with one
+# scale per (query row, 32 keys) six families sit at 0.012-0.064 (target 0.08).  Student-t(3) keeps 0.10-0.19: what is left there
+# is the int8 SCORE under one key scale per head and one query scale per 32 rows (the abs-max of 10^7 t(3) samples is ~250
+# sigma: the bulk rounds to 0 or +-1; CPU study with exact scores + the same probabilities + e4m3 v: 0.027) -- a per-row key
+# scale costs an instruction per score (round 4), so that family is gated at what the format gives
+# (profiles/r05_mx_probabilities.txt); inputs like it belong on precision "fp8pv" (16-bit scores)
+I8_REL_GATE = 0.08
+I8_REL_GATES = {"student_t3": 0.20}
 
 
 @pytest.mark.parametrize("geometry", ["wan14b-81f", "hunyuan-129f"])
 def test_i8_operator_psnr_on_every_input_family(geometry):
-    """gate (ii): every expert, every input family, precision "i8pv" against the bf16 kernels on the same bf16 inputs"""
-    from _fp8_inputs import NAMES, families, psnr
+    """gate (ii): every expert, every input family, precision "i8pv" against the bf16 kernels on the same bf16 inputs: PSNR
+    over max|x| >= 40 dB, relative Frobenius error <= 0.08 (Student-t: 0.20, see I8_REL_GATES); PSNR over the 99.9th percentile
+    of |x| is printed beside them"""
+    from _fp8_inputs import NAMES, families, psnr, robust_psnr
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
     dtype = torch.bfloat16
     if geometry == "wan14b-81f":
@@ -278,13 +303,18 @@ def test_i8_operator_psnr_on_every_input_family(geometry):
     gen = torch.Generator(device=dev()).manual_seed(1234)
     kw = dict(model=model, text_len=T, text_valid=te)
     experts = ["full", "coreset", "sliding"]
+    failures = []
     for key, q, k, v in families(latent, 3, T, gen, dev()):
         q16, k16, v16 = (x.to(dtype)[None].contiguous() for x in (q, k, v))
         ref = routed_attention(q16, k16, v16, routing, geom, **kw)
         out = routed_attention(q16, k16, v16, routing, geom, fp8="i8pv", **kw)
         torch.cuda.synchronize()
         assert torch.isfinite(out.float()).all(), key
-        table = {experts[h]: psnr(out[0, h, :S + te], ref[0, h, :S + te]) for h in range(3)}
-        print(f"i8pv vs bf16 [{geometry}] {NAMES[key]}: " + ", ".join(f"{n} {a:.1f} / {b:.1f} dB rel {c:.3f}" for n, (a, b, c) in table.items()))
-        for n, (p_range, p_peak, rel) in table.items():
-            assert p_peak >= I8_GATES[key], (geometry, key, n, p_range, p_peak, rel)
+        table = {experts[h]: psnr(out[0, h, :S + te], ref[0, h, :S + te]) + (robust_psnr(out[0, h, :S + te], ref[0, h, :S + te]),)
+                 for h in range(3)}
+        print(f"i8pv vs bf16 [{geometry}] {NAMES[key]}: " + ", ".join(f"{n} {a:.1f} / {b:.1f} / p99.9 {d:.1f} dB rel {c:.3f}"
+                                                                      for n, (a, b, c, d) in table.items()))
+        for n, (p_range, p_peak, rel, p_rob) in table.items():
+            if p_peak < I8_GATES[key] or rel > I8_REL_GATES.get(key, I8_REL_GATE):
+                failures.append((geometry, key, n, round(p_peak, 1), round(rel, 3)))
+    assert not failures, failures

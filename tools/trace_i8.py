@@ -50,6 +50,7 @@ def one(i):
     x, y = per[:, :4].mean().item(), per[:, 4:].mean().item()
     print(f"interval {i} {NAMES[i]:32s}: role X {x:7.1f}  role Y {y:7.1f} cycles/step   "
           f"({ms:.3f} ms, {4.0 * S * S * 128 * H / ms / 1e9:.0f} TFLOP/s, steps {t[0, 0, 1].item()})", flush=True)
+    print("           per wave 0..7 (wave 0 also requests the key-bias piece): " + " ".join(f"{per[:, w].mean().item():7.1f}" for w in range(8)), flush=True)
 
 
 def main():

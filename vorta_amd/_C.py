@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvo
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
 VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3, VORTA_INT8 = 0, 1, 2, 3, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _i32, _i64, _u32, _f32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
 

@@ -62,8 +62,8 @@ struct ParamsI8 {
   const float* q_prep; int64_t q_prep_sh;
   const float* k_head_scale;
   const float* v_descale; int64_t v_descale_sh;
-  float p_bias;  // log2 bias of the packed probabilities
-  float thr;     // p_bias + defer: offset scores above this move the reference point
+  float p_bias;  // log2 bias of the probabilities (P' = 2^(z - reference + p_bias))
+  float etrig;   // binades: a lane whose block exponent exceeds this moves its row's reference point (rare: the range is the scale's)
 };
 struct MultiParamsI8 {
   ParamsI8 seg[MAX_SEGMENTS];
@@ -74,8 +74,23 @@ struct MultiParamsI8 {
 __device__ __forceinline__ i32x16 mfma_i8(i32x4 a, i32x4 b, i32x16 c) {
   return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // cbsz = blgp = 0: e4m3 x e4m3, no block scale
+// O^T += V8^T P8^T with block scales on the B operand (v_mfma_scale_f32_32x32x64_f8f6f4, 8-bit operands; tools/probe_mx_scale.hip,
+// profiles/r05_probe_mx_scale.txt): scale block s (0, 1) of a column = bytes 16 s ... 16 s + 15 of BOTH lanes of that column, and
+// its E8M0 byte (2^(sb - 127), byte 0 of `sb`) is read from the lane of half s.  Here bytes 0-15 of a lane are its 16 keys of
+// key tile 0 and bytes 16-31 those of key tile 1: a scale block = one query row x the 32 consecutive keys of one key tile.
+// Same cycles as the unscaled form (profiles/r02_probe_fp8_layouts.txt).
+constexpr int SC_ONE = 127;  // E8M0 of 2^0: the V operand's scale
+#ifdef VORTA_I8_DIAG_NOSCALE
+#define ROWSUM_MFMA(a_, b_, c_, s_) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c_, 4, 0, 0, 0, 0, 0)
+#else
+#define ROWSUM_MFMA(a_, b_, c_, s_) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c_, 4, 0, 0, SC_ONE, 0, s_)  /* A: e2m1 ones */
+#endif
+__device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c, int sb) {
+#ifdef VORTA_I8_DIAG_NOSCALE  /* timing only (wrong results): what the scale operands cost the MFMA's issue */
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, SC_ONE, 0, sb);  // cbsz = blgp = 0: e4m3 x e4m3
+#endif
 }
 
 template <typename T, int NW, bool KVTAB, int NS>
@@ -211,13 +226,15 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                           \
       posK[i_] += KVB;                                                            \
       const int pos_ = min(posK[i_], n_kv - 1);                                   \
-      if constexpr (KVTAB) rowK[i_] = kv_rows[pos_];                              \
+      if constexpr (KVTAB) rowK[i_] = kv_rows[(unsigned)pos_];                    \
       else rowK[i_] = p.kv_row_offset + pos_;                                     \
     }                                                                             \
-    posB += KVB;                                                                  \
-    const int posb_ = min(posB, n_kv - 1);                                        \
-    if constexpr (KVTAB) rowB = kv_rows[posb_];                                   \
-    else rowB = p.kv_row_offset + posb_;                                          \
+    if (wave == 0) { /* only wave 0 requests the bias piece: the other waves skip its row arithmetic and table read */ \
+      posB += KVB;                                                                \
+      const int posb_ = min(posB, n_kv - 1);                                      \
+      if constexpr (KVTAB) rowB = kv_rows[(unsigned)posb_];                       \
+      else rowB = p.kv_row_offset + posb_;                                        \
+    }                                                                             \
   }
 #define DMA_K(slot_) _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(    \
       k_rsrc, (LDS_AS void*)(smem + (slot_) * TILE8 + (CH * wave + i_) * 1024), 16,                                 \
@@ -269,21 +286,40 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   i32x8 pbA_, pbB_;
 #pragma unroll
   for (int i = 0; i < 8; ++i) { pbA_[i] = 0; pbB_[i] = 0; }
+  int scA_ = SC_ONE, scB_ = SC_ONE;  // ... and their block scales (E8M0 byte of this lane's 32 probabilities)
   // Online softmax in the BYTE domain y = 8 x + 56, x = log2 P' = z - m_run + p_bias.  m_run8 = 8 x the reference point of
-  // this row (a lower bound of its running max, at most thr - p_bias below it).
+  // this row (its first block's maximum; it moves again only when a block lies more than `etrig` binades above it).
+  // MX-SCALED PROBABILITIES (round 5): the e4m3 byte of a probability is rint(y - 8 e) with e = the block exponent of its
+  // (query row, key tile of 32 keys), rint((max y of those 32 - YMID) / 8): whatever the distance of a tile from the row's
+  // reference point, its largest probability sits in the top binade of e4m3 (bytes 116 ... 124 of 126) and 2^e goes to the MFMA
+  // as the B operand's block scale -- no probability is flushed because its ROW has a larger one elsewhere.  (One exponent range for the whole
+  // row, as before round 5: everything below 2^-14 ... 2^-11 of the row's maximum was zero or a mis-decoded subnormal -- the
+  // byte domain is logarithmic, e4m3's subnormals are linear -- 0.14-0.21 relative error on heavy-tailed inputs, all of it
+  // from the probabilities' range: profiles/r05_mx_probabilities.txt.)
   float m_run8 = -1e30f;
-  const float ybias = 8.f * pp.p_bias + 56.f, ythr = 8.f * pp.thr + 56.f;
-  f32x16 y0, y1;          // byte-domain scores of one key block (keys 0-31, 32-63 of the block)
+  // The exponent lives as a BIASED float eb = 1.5 2^23 + 127 + e: in that binade a float is an integer, so ONE multiply-add
+  // (max y / 8 + CE) rounds to it, and its bit pattern's low byte IS the E8M0 scale byte 127 + e -- the register goes to the MFMA
+  // as it stands.  e has no upper clamp: a tile far above the reference point (heavy-tailed scores reach thousands of binades)
+  // trips the trigger below and the reference point moves under it BEFORE its bytes are used.
+  constexpr float YMID = 120.f;                     // a tile's largest byte-domain value lands in [YMID - 4, YMID + 4]
+  constexpr float EBIAS = MAGIC_F + 127.f;          // eb - EBIAS = e
+  constexpr float CE = EBIAS - 0.125f * YMID;       // an integer: eb = rint(max y / 8 + CE), exactly one rounding
+  constexpr float EB_MIN = EBIAS - 100.f;           // e >= -100: 2^-100 of the row's reference is nothing, and a finite scale
+  const float ybias = 8.f * pp.p_bias + 56.f, etrig_b = EBIAS + pp.etrig;
+  f32x16 y0, y1;          // byte-domain scores (minus 8 e) of one key block (keys 0-31, 32-63 of the block)
   i32x16 n0, n1;          // raw accumulators of the block after it (written by the matrix part)
   float off8 = 0.f;       // ybias - m_run8 - MAGIC_F * m8: the addend of the conversion
-  float mx_cur = -1e30f;  // row max of y
+  float ecur = EBIAS;     // biased block exponent of key tile hh (the one whose scale this lane supplies) for the block in y0, y1
 
-  // seeds of a block from its bias tile (slot bslot_) into this wave's seed slot sslot_: three VALU instructions per wave
+  // the seed of a key = rint(bias / sq) as the integer the accumulator starts from, 0x4B400000 + seed: ONE multiply-add -- in the
+  // binade of 1.5 2^23 a float is an integer, so bias * inv_q + 1.5 2^23 rounds (once, to nearest even) to the float whose BITS
+  // are that integer -- and an integer clamp of the bits (monotonic there; a product beyond the binade clamps too)
+#define SEED_BITS(b_) min(max(__float_as_int(__builtin_fmaf((b_), inv_q, MAGIC_F)), MAGIC_I - (int)SEED_LIMIT), MAGIC_I + (int)SEED_LIMIT)
+  // seeds of a block from its bias tile (slot bslot_) into this wave's seed slot sslot_: two VALU instructions per wave
 #define MAKE_SEEDS(bslot_, sslot_)                                                \
   {                                                                               \
     const float b_ = *(const float*)(smem + bias_rd + (bslot_) * SC_BYTES);       \
-    const float s_ = __builtin_amdgcn_fmed3f(b_ * inv_q, -SEED_LIMIT, SEED_LIMIT); \
-    *(int*)(smem + seed_wr + (sslot_) * SC_BYTES) = MAGIC_I + (int)__builtin_rintf(s_); \
+    *(int*)(smem + seed_wr + (sslot_) * SC_BYTES) = SEED_BITS(b_);                \
   }
   // the seeds of key tile t_ (0, 1) of a block (seed slot sslot_) as an accumulator's initial value: int32 bits = float
   // 1.5 2^23 + seed
@@ -303,7 +339,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) yd0_[i_] = __builtin_fmaf(__int_as_float(a0_[i_]), m8, off_); \
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) yd1_[i_] = __builtin_fmaf(__int_as_float(a1_[i_]), m8, off_); \
   }
-  // P' bytes straight from y: rint, saturating at 0 (-inf of masked keys -> 0); y <= 8 thr + 56 = 120 < 0x7E
+  // P' bytes straight from y - 8 e: rint, saturating at 0 (-inf of masked keys -> 0); the lane's largest is below 126.5
 #define PACK_Y(pb_)                                                               \
   _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_)                                \
     _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                            \
@@ -317,21 +353,28 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, b_[i_]);   \
     dst_ = half_max(mx_);                                                         \
   }
-  // The loop only asks two things of a block's row max: "is it above `ythr` (> 0)?" and, if so, its value.  Both are
-  // answered by a signed-integer max over the float bit patterns (order-preserving for non-negative floats, any negative
-  // result reads as "not above"; there are no NaNs).
-#define ROW_MAX_POS(dst_, a_, b_)                                                  \
+  // The block exponents from the RAW accumulators (their bits read as floats are positive and ordered like the integers):
+  // signed-integer max over each key tile's 16 registers (v_max3_i32), ONE half exchange that leaves tile 0's row max in the
+  // lanes of half 0 and tile 1's in half 1 -- where the MFMA reads the two scales -- one multiply-add to the byte domain, one
+  // to the biased exponent; a second exchange hands every lane both exponents for the offsets of its conversions.
+#define TILE_EXP(eh_, off0_, off1_, a_, b_)                                       \
   {                                                                               \
-    int m0_ = max(max(__float_as_int(a_[0]), __float_as_int(a_[1])), __float_as_int(a_[2])); \
-    int m1_ = max(max(__float_as_int(b_[0]), __float_as_int(b_[1])), __float_as_int(b_[2])); \
+    int m0_ = max(max(a_[0], a_[1]), a_[2]);                                      \
+    int m1_ = max(max(b_[0], b_[1]), b_[2]);                                      \
     _Pragma("unroll") for (int i_ = 3; i_ < 15; i_ += 2) {                        \
-      m0_ = max(max(m0_, __float_as_int(a_[i_])), __float_as_int(a_[i_ + 1]));    \
-      m1_ = max(max(m1_, __float_as_int(b_[i_])), __float_as_int(b_[i_ + 1]));    \
+      m0_ = max(max(m0_, a_[i_]), a_[i_ + 1]);                                    \
+      m1_ = max(max(m1_, b_[i_]), b_[i_ + 1]);                                    \
     }                                                                             \
-    m0_ = max(max(m0_, __float_as_int(a_[15])), __float_as_int(b_[15]));          \
-    m0_ = max(m0_, m1_);                                                          \
-    auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m0_, false, false); \
-    dst_ = __int_as_float(max((int)r_[0], (int)r_[1]));                           \
+    m0_ = max(m0_, a_[15]);                                                       \
+    m1_ = max(m1_, b_[15]);                                                       \
+    auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m1_, false, false); \
+    const int mt_ = max((int)r_[0], (int)r_[1]); /* half 0: tile 0 over both halves' keys; half 1: tile 1 */ \
+    const float ymx_ = __builtin_fmaf(__int_as_float(mt_), m8, off8);             \
+    eh_ = fmaxf(__builtin_fmaf(ymx_, 0.125f, CE), EB_MIN);                        \
+    const float ef_ = eh_ - EBIAS;                                                \
+    auto e_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(ef_), __float_as_uint(ef_), false, false); \
+    off0_ = __builtin_fmaf(__uint_as_float(e_[0]), -8.f, off8);                   \
+    off1_ = __builtin_fmaf(__uint_as_float(e_[1]), -8.f, off8);                   \
   }
   // (the empty asm makes the lane term a value of THIS step: otherwise the 16 sums lane term + register row are hoisted out
   // of the loop into 16 registers for a branch taken once per workgroup)
@@ -382,24 +425,32 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   // next rows): back to back at the top of the step they cost the wave ~100 cycles each -- every wave of the workgroup
   // asks at the same moment and the address unit takes 16 pieces per step, 16 cycles apiece -- with VALU work between
   // them the queue has drained when the next one comes (tools/trace_i8.py: 176-208 cycles per step for the requests).
+#ifdef VORTA_I8_DIAG_STALE  /* timing only (wrong results): the conversions use the PREVIOUS block's offsets -- no wait for the max chain */
+  float st0_ = 0.f, st1_ = 0.f;
+#define STALE_A_() const float so0_ = st0_, so1_ = st1_;
+#define STALE_B_() st0_ = off0_; st1_ = off1_; off0_ = so0_; off1_ = so1_;
+#else
+#define STALE_A_()
+#define STALE_B_()
+#endif
 #define VALU_PART(bs_, ss_, qa_, qb_, qc_)                                        \
   {                                                                               \
     const float sb_ = *(const float*)(smem + bias_rd + (bs_) * SC_BYTES);         \
     qa_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, off8); \
+    float off0_, off1_;                                                           \
+    STALE_A_()                                                                    \
+    TILE_EXP(ecur, off0_, off1_, n0, n1)                                          \
     __builtin_amdgcn_sched_barrier(0);                                            \
     qb_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, off8); \
+    STALE_B_()                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, off0_); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, off1_); \
     __builtin_amdgcn_sched_barrier(0);                                            \
     qc_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
-    ROW_MAX_POS(mx_cur, y0, y1)                                                   \
-    {                                                                             \
-      const float s_ = __builtin_amdgcn_fmed3f(sb_ * inv_q, -SEED_LIMIT, SEED_LIMIT); \
-      *(int*)(smem + seed_wr + (ss_) * SC_BYTES) = MAGIC_I + (int)__builtin_rintf(s_); \
-    }                                                                             \
+    *(int*)(smem + seed_wr + (ss_) * SC_BYTES) = SEED_BITS(sb_);                  \
   }
 #define ROWS_UPDATE()                                                             \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
@@ -409,12 +460,6 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   ROWS_UPDATE()
 #ifndef VORTA_I8_SCHED
 #define VORTA_I8_SCHED 1
-#endif
-// 1: the K and V tile pieces of the 8-wave kernels are requested INSIDE the matrix part, one behind the row-sum MFMA and one
-// two MFMAs later: the wave issues in order and a request holds it ~90 cycles wherever it stands -- behind an MFMA 64 of
-// them run under that MFMA, in the VALU part all of them are the wave's own (0: in the VALU part)
-#ifndef VORTA_I8_REQ_M
-#define VORTA_I8_REQ_M 0
 #endif
   // an empty, NON-volatile asm over two values: a data dependence and nothing else (reads stay free to move) -- orders the MFMAs
   // that produce / consume them where the recipe's greedy pick would not
@@ -461,69 +506,53 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #define PRIO_HI()
 #define PRIO_LO()
 #endif
-  // qa_ / qb_: a tile request behind the row-sum MFMA / behind the second P V MFMA (tied to their results, so that the
-  // recipe cannot issue both together)
-#define PV_PART(vr_, pb_, qa_, qb_, mid_)                                         \
+  // (tile requests INSIDE the matrix part, each behind an MFMA, measured 1.3 % slower than in the VALU part: round 4)
+#define PV_PART(vr_, pb_, sc_, mid_)                                              \
   i32x8 vf_[4];                                                                   \
   VFRAG(0, vr_) VFRAG(1, vr_) VFRAG(2, vr_) VFRAG(3, vr_)                         \
-  lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pb_, lacc, 4, 0, 0, 0, 0, 0); \
+  lacc = ROWSUM_MFMA(ones, pb_, lacc, sc_);                                       \
   TIE_(lacc, vf_[0]) /* the row-sum MFMA before the first that needs a fragment */ \
-  qa_                                                                             \
-  mid_ /* the score half's first reads: in the source between the two requests, whose volatile ties order memory operations */ \
-  o[0] = mfma8(vf_[0], pb_, o[0]);                                                \
+  mid_ /* the score half's first reads */                                         \
+  o[0] = mfma8(vf_[0], pb_, o[0], sc_);                                           \
   TIE_(o[0], vf_[1])                                                              \
-  o[1] = mfma8(vf_[1], pb_, o[1]);                                                \
-  qb_                                                                             \
-  o[2] = mfma8(vf_[2], pb_, o[2]);                                                \
+  o[1] = mfma8(vf_[1], pb_, o[1], sc_);                                           \
+  o[2] = mfma8(vf_[2], pb_, o[2], sc_);                                           \
   TIE_(o[2], vf_[3])                                                              \
-  o[3] = mfma8(vf_[3], pb_, o[3]);
-#define REQ_K_TIED(slot_, t_, a_)                                                 \
+  o[3] = mfma8(vf_[3], pb_, o[3], sc_);
+  // move the reference point of a row up by g_ >= 0 WHOLE binades (the larger of its two tiles' block exponents): everything
+  // accumulated so far follows; the current block's bytes do not change -- y - 8 e is what it was -- only its exponents do
+#define RAISE_REF()                                                               \
   {                                                                               \
-    static_assert(CH == 1, "one piece per wave");                                 \
-    int off_ = (int)__umul24((unsigned)rowK[0], (unsigned)k_ss32) + k_col[0];     \
-    TIE_(t_, off_)                                                                \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (LDS_AS void*)(smem + (slot_) * TILE8 + wave * 1024), 16, off_, 0, 0, 0); \
-    asm volatile("" : "+v"(a_)); /* ... and what consumes a_ behind it */         \
-  }
-#define REQ_V_TIED(slot_, t_, a_)                                                 \
-  {                                                                               \
-    int off_ = (int)__umul24((unsigned)rowV[0], (unsigned)v_ss32) + v_col[0];     \
-    TIE_(t_, off_)                                                                \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (LDS_AS void*)(smem + VBASE + (slot_) * TILE8 + wave * 1024), 16, off_, 0, 0, 0); \
-    asm volatile("" : "+v"(a_));                                                  \
-  }
-  // move the reference point of the row up by g8_ (>= 0, byte-domain units = 8 x log2): everything accumulated so far and
-  // the current block's y are brought to the new reference
-#define RAISE_REF(g8_)                                                            \
-  {                                                                               \
-    const float alpha_ = __builtin_amdgcn_exp2f(-0.125f * (g8_));                 \
+    const float g_ = fmaxf(half_max(ecur) - EBIAS, 0.f);                          \
+    const float alpha_ = __builtin_amdgcn_exp2f(-g_);                             \
     _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                           \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;     \
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) lacc[i_] *= alpha_;         \
-    m_run8 += (g8_);                                                              \
-    off8 -= (g8_);                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { y0[i_] -= (g8_); y1[i_] -= (g8_); } \
+    m_run8 = __builtin_fmaf(g_, 8.f, m_run8);                                     \
+    off8 = __builtin_fmaf(g_, -8.f, off8);                                        \
+    ecur = fmaxf(ecur - g_, EB_MIN);                                              \
   }
-#define MATRIX_PART(kr_, vr_, sr_, pbr_, pbw_, jabs_, qa_, qb_)                   \
+#define MATRIX_PART(kr_, vr_, sr_, pbr_, scr_, pbw_, scw_, jabs_)                 \
   {                                                                               \
     PRIO_HI()                                                                     \
     i32x4 kfa_[4], kfb_[4];                                                       \
-    PV_PART(vr_, pbr_, qa_, qb_, SEEDS_IN(n0, sr_, 0) KFRAGS(kfa_, kr_, 0))       \
+    PV_PART(vr_, pbr_, scr_, SEEDS_IN(n0, sr_, 0) KFRAGS(kfa_, kr_, 0))           \
     SCHED_M()                                                                     \
-    /* last, partial key block: mask its tail, exact row max (once per workgroup) */ \
-    if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(jabs_) ROW_MAX(mx_cur, y0, y1) }  \
-    /* deferred rescale: the reference point moves only when some row of the wave outgrew it by more than `thr - p_bias`; */ \
-    /* O and the row sums follow AFTER block j-1 went in at the old reference                                            */ \
-    if (!__all(mx_cur <= ythr)) {                                                 \
-      const float g8_ = fmaxf(mx_cur - ybias, 0.f);                               \
-      RAISE_REF(g8_)                                                              \
-    }                                                                             \
+    /* the five MFMAs stay one run AHEAD of the rare branches: left alone, the compiler sinks one that nothing orders below the */ \
+    /* tail-mask branch, out of the issue recipe (an empty statement: no instruction, no wait)                              */ \
+    asm volatile("" : "+v"(lacc), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])); \
+    /* last, partial key block: mask its tail (once per workgroup; the exponents were taken over the clamped rows too) */ \
+    if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(jabs_) }                          \
+    /* the reference point moves only when some tile lies more than `etrig` binades above it; O and the row sums */ \
+    /* follow AFTER block j-1 went in at the old reference                                                              */ \
+    if (!__all(ecur <= etrig_b)) { RAISE_REF() }                                  \
+    scw_ = __float_as_int(ecur); /* its low byte is the E8M0 scale 127 + e */     \
     SEEDS_IN(n1, sr_, 1) /* key tile 1: its seeds and fragments fly under the four MFMAs of tile 0 */ \
     KFRAGS(kfb_, kr_, 1)                                                          \
     QK_TILE(n0, kfa_)                                                             \
     TIE_(n0, n1) /* tile 0 (operands in registers) before tile 1 (operands in flight) */ \
     QK_TILE(n1, kfb_)                                                             \
-    PACK_Y(pbw_) /* the bytes of block j (its reference point is final now): four conversions per MFMA gap */ \
+    PACK_Y(pbw_) /* the bytes of block j: four conversions per MFMA gap */        \
     TIE_(n1, pbw_) /* (keeps the conversions in this block: nothing reads them before the next step) */ \
     SCHED_S()                                                                     \
     PRIO_LO()                                                                     \
@@ -541,28 +570,20 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #endif
   // both roles request their tile pieces inside their VALU part (role X behind its matrix part: it goes from the barrier
   // straight into its MFMAs); the 4-wave kernels (no roles) and waves past the query rows request at the top of the step
-#define STEP(kw_, kr_, vw_, vr_, bw_, sr_, bsx_, ssx_, bsy_, ssy_, pbr_, pbw_, jabs_) \
+#define STEP(kw_, kr_, vw_, vr_, bw_, sr_, bsx_, ssx_, bsy_, ssy_, pbr_, scr_, pbw_, scw_, jabs_) \
   {                                                                               \
     TR_(0)                                                                        \
     if (!wave_active || NW != 8) { STAGE_DMA(kw_, vw_, bw_, jabs_) }              \
     TR_(1)                                                                        \
     if (wave_active) {                                                            \
-      if (NW == 8 && role_y) { /* (role Y's rows move on behind its matrix part, which holds its K and V requests) */ \
-        if (VORTA_I8_REQ_M) VALU_PART(bsy_, ssy_, , , DMA_B(bw_))                 \
-        else VALU_PART(bsy_, ssy_, DMA_K(kw_), DMA_V(vw_), REQ_TAIL(bw_))         \
-      }                                                                           \
+      if (NW == 8 && role_y) { VALU_PART(bsy_, ssy_, DMA_K(kw_), DMA_V(vw_), REQ_TAIL(bw_)) } \
       __builtin_amdgcn_sched_barrier(0);                                          \
       TR_(2)                                                                      \
-      if constexpr (NW == 8 && VORTA_I8_REQ_M) MATRIX_PART(kr_, vr_, sr_, pbr_, pbw_, jabs_, REQ_K_TIED(kw_, lacc, vf_[0]), REQ_V_TIED(vw_, o[1], vf_[2])) \
-      else MATRIX_PART(kr_, vr_, sr_, pbr_, pbw_, jabs_, , )                      \
+      MATRIX_PART(kr_, vr_, sr_, pbr_, scr_, pbw_, scw_, jabs_)                   \
       __builtin_amdgcn_sched_barrier(0);                                          \
       TR_(3)                                                                      \
-      if (NW == 8 && VORTA_I8_REQ_M && role_y) { ROWS_UPDATE() }                  \
       TR_(4)                                                                      \
-      if (NW == 8 && !role_y) {                                                   \
-        if (VORTA_I8_REQ_M) VALU_PART(bsx_, ssx_, , , REQ_TAIL(bw_))              \
-        else VALU_PART(bsx_, ssx_, DMA_K(kw_), DMA_V(vw_), REQ_TAIL(bw_))         \
-      }                                                                           \
+      if (NW == 8 && !role_y) { VALU_PART(bsx_, ssx_, DMA_K(kw_), DMA_V(vw_), REQ_TAIL(bw_)) } \
       if (NW != 8) VALU_PART(bsx_, ssx_, , , )                                    \
     }                                                                             \
     STEP_SYNC()                                                                   \
@@ -604,15 +625,25 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
       const float base = -MAGIC_F * m8;
       TO_Y(y0, y1, n0, n1, base)  // 8 x the plain exp2-domain scores of the first block
       if (blk0 * KVB + KVB > n_kv) { MASK_TAIL(blk0) }
-      ROW_MAX(mx_cur, y0, y1)
+      float mx0;
+      ROW_MAX(mx0, y0, y1)
       // the first block fixes the reference point at its true row max (block blk0 always has a valid key);
       // O and l are still zero, so nothing is rescaled
-      m_run8 = mx_cur;
+      m_run8 = mx0;
       const float shift = ybias - m_run8;
       off8 = __builtin_fmaf(-MAGIC_F, m8, shift);
+      // ... and its two key tiles take their block exponents from their own (masked) values
+      float l0 = y0[0], l1 = y1[0];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { y0[i] += shift; y1[i] += shift; }
-      mx_cur = ybias;
+      for (int i = 1; i < 16; ++i) { l0 = fmaxf(l0, y0[i]); l1 = fmaxf(l1, y1[i]); }
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l0), __float_as_uint(l1), false, false);
+      const float lt = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));  // half 0: tile 0, half 1: tile 1
+      ecur = fmaxf(__builtin_fmaf(lt + shift, 0.125f, CE), EB_MIN);
+      const float ef = ecur - EBIAS;
+      auto e = __builtin_amdgcn_permlane32_swap(__float_as_uint(ef), __float_as_uint(ef), false, false);
+      const float sh0 = __builtin_fmaf(__uint_as_float(e[0]), -8.f, shift), sh1 = __builtin_fmaf(__uint_as_float(e[1]), -8.f, shift);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { y0[i] += sh0; y1[i] += sh1; }
     }
     __syncthreads();  // every wave has read K(0) and the bias tile of K(0) before their slots are overwritten
     {  // step 0: no PV yet -- the scores of block 1, then (role X) the VALU part of block 0
@@ -626,6 +657,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
         QK_TILE(n0, kfa)
         QK_TILE(n1, kfb)
         PACK_Y(pbA_)  // the bytes of block 0
+        scA_ = __float_as_int(ecur);
         __builtin_amdgcn_sched_barrier(0);
         if (!role_y) VALU_PART(2, 0, , , )
       }
@@ -636,33 +668,34 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     // read from (j+1) % 2; role X makes the seeds of block j+2 (bias slot (j+2) % 3, seed slot j % 2) and reads the head of
     // V(j) (slot j % 3), role Y the seeds of block j+1 (bias slot (j+1) % 3, seed slot (j+1) % 2) and the head of V(j-1)
     for (int jj = 1; jj < nsteps; jj += 6) {
-      STEP(1, 0, 2, 0, 1, 0, 0, 1, 2, 0, pbA_, pbB_, blk0 + jj)
+      STEP(1, 0, 2, 0, 1, 0, 0, 1, 2, 0, pbA_, scA_, pbB_, scB_, blk0 + jj)
       if (jj + 1 >= nsteps) break;
-      STEP(0, 1, 0, 1, 2, 1, 1, 0, 0, 1, pbB_, pbA_, blk0 + jj + 1)
+      STEP(0, 1, 0, 1, 2, 1, 1, 0, 0, 1, pbB_, scB_, pbA_, scA_, blk0 + jj + 1)
       if (jj + 2 >= nsteps) break;
-      STEP(1, 0, 1, 2, 0, 0, 2, 1, 1, 0, pbA_, pbB_, blk0 + jj + 2)
+      STEP(1, 0, 1, 2, 0, 0, 2, 1, 1, 0, pbA_, scA_, pbB_, scB_, blk0 + jj + 2)
       if (jj + 3 >= nsteps) break;
-      STEP(0, 1, 2, 0, 1, 1, 0, 0, 2, 1, pbB_, pbA_, blk0 + jj + 3)
+      STEP(0, 1, 2, 0, 1, 1, 0, 0, 2, 1, pbB_, scB_, pbA_, scA_, blk0 + jj + 3)
       if (jj + 4 >= nsteps) break;
-      STEP(1, 0, 0, 1, 2, 0, 1, 1, 0, 0, pbA_, pbB_, blk0 + jj + 4)
+      STEP(1, 0, 0, 1, 2, 0, 1, 1, 0, 0, pbA_, scA_, pbB_, scB_, blk0 + jj + 4)
       if (jj + 5 >= nsteps) break;
-      STEP(0, 1, 1, 2, 0, 1, 2, 0, 1, 1, pbB_, pbA_, blk0 + jj + 5)
+      STEP(0, 1, 1, 2, 0, 1, 2, 0, 1, 1, pbB_, scB_, pbA_, scA_, blk0 + jj + 5)
     }
     // ---- drain: PV of the last block ----
     if (wave_active) {
       const int vs = (nsteps - 1) % V_SLOTS_I8;
-      if ((nsteps - 1) & 1) pbA_ = pbB_;  // the bytes of the last block
-      PV_PART(vs, pbA_, , , )
+      if ((nsteps - 1) & 1) { pbA_ = pbB_; scA_ = scB_; }  // the bytes of the last block
+      PV_PART(vs, pbA_, scA_, )
     }
   }
 #undef MAKE_SEEDS
+#undef SEED_BITS
 #undef SEEDS_IN
 #undef KFRAGS
 #undef QK_TILE
 #undef TO_Y
 #undef PACK_Y
 #undef ROW_MAX
-#undef ROW_MAX_POS
+#undef TILE_EXP
 #undef MASK_TAIL
 #undef VFRAG
 #undef STAGE_DMA
@@ -676,8 +709,6 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #undef PRIO_HI
 #undef PRIO_LO
 #undef PV_PART
-#undef REQ_K_TIED
-#undef REQ_V_TIED
 #undef RAISE_REF
 #undef MATRIX_PART
 #undef ROLE_Y_
@@ -815,16 +846,18 @@ int fill_i8(const vorta_attn_args* a, const vorta_attn_i8_ext* ext, ParamsI8& pp
       !ext->k_head_scale)
     return VORTA_EINVAL;
   if (ext->flags != 0) return VORTA_EUNSUPPORTED;
+  // p_bias: P' = 2^(score - reference + p_bias) (any value: the block scales carry the range); defer: binades a lane's block
+  // may lie above its row's reference point before the reference moves (fp32 accumulators: P' <= 2^(defer + 9))
   const float pb = ext->p_bias != 0.f ? ext->p_bias : 5.f;
-  const float df = ext->defer != 0.f ? ext->defer : 3.f;
-  if (!(pb >= 0.f) || !(df > 0.f) || pb + df > 8.f) return VORTA_EINVAL;  // P' <= 2^(p_bias+defer) must stay below 448
+  const float df = ext->defer != 0.f ? ext->defer : 24.f;
+  if (!(pb >= 0.f) || pb > 16.f || !(df >= 0.f) || df > 64.f) return VORTA_EINVAL;
   pp.k_bias = ext->k_bias; pp.k_bias_sh = ext->k_bias_stride_h;
   pp.q_prep = ext->q_prep; pp.q_prep_sh = ext->q_prep_stride_h;
   pp.k_head_scale = ext->k_head_scale;
   pp.v_descale = ext->v_descale;
   pp.v_descale_sh = ext->v_descale_stride_h;
   pp.p_bias = pb;
-  pp.thr = pb + df;
+  pp.etrig = df;
   return VORTA_OK;
 }
 
