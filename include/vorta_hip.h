@@ -316,7 +316,8 @@ int vorta_i8_quantize_k(const vorta_i8_quant_args* args, void* hip_stream);
  * vorta_attn_fwd_i8 -- the gather flash-attention of vorta_attn_fwd with int8 scores and e4m3 P V.
  *   args->q: 16-bit (args->dtype), strides in elements.  Every WAVE takes its 32 query rows, qt = (q - cq) s with the head's
  *            q_prep, the abs-max over the 32 rows (sq = amax / 127) and rounds them to int8 itself -- queries are read once
- *            per workgroup;
+ *            per workgroup; a wave whose abs-max is below 2^-12 (every row on the head's centre) takes q8 = 0, sq = 1: its scores are
+ *            the bias term alone;
  *   args->k: the int8 rows of vorta_i8_quantize_k, strides in BYTES; k_bias its per-row floats (indexed like k rows:
  *            head * k_bias_stride_h + row, through kv_rows when given); k_head_scale[head] = sk;
  *   args->v: e4m3 (vorta_fp8_v_absmax / vorta_fp8_v_convert), strides in bytes, with v_descale as in vorta_attn_fp8_ext;

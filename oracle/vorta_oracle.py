@@ -769,9 +769,10 @@ def i8_wave_operands(q_rows: np.ndarray, q_prep: np.ndarray, sk: float, k8: np.n
     c0 = f32(f32(1.0 / np.sqrt(D) if scale is None else scale) * f32(1.4426950408889634))
     qt = ((q - np.asarray(q_prep[0], f32)[None, :]).astype(f32) * np.asarray(q_prep[1], f32)[None, :]).astype(f32)
     am = f32(np.abs(qt).max())
-    inv = f32(127.0) / am if am > 0 else f32(0.0)
-    q8 = np.clip(np.rint((qt * inv).astype(f32)), -127, 127).astype(np.float64)
-    sq = (am * f32(1.0 / 127.0)) if am > 0 else f32(1.0)
+    flat = not (am >= f32(2.0 ** -12))  # a wave on the head's centre: q8 = 0, unit scale (the bias term alone makes its scores)
+    inv = f32(1.0) if flat else f32(127.0) / am
+    q8 = np.clip(np.rint((qt * (f32(0.0) if flat else inv)).astype(f32)), -127, 127).astype(np.float64)
+    sq = f32(1.0) if flat else (am * f32(1.0 / 127.0))
     u = f32(f32(sq * c0) * f32(sk))
     # (ABI 7: ONE rounding of the exact product -- the kernel's fused multiply-add into the binade of 1.5 2^23 -- then the clamp)
     seed = np.clip(np.rint(np.asarray(k_bias, np.float64) * np.float64(inv)), -I8_MAGIC_LIMIT, I8_MAGIC_LIMIT)

@@ -157,6 +157,40 @@ def test_i8_dense_ragged_vs_emulator(dtype, block_rows):
     assert rel_fro(out.float().cpu().numpy(), full) <= 0.06
 
 
+def test_i8_wave_on_the_head_centre_keeps_the_bias_term():
+    """query rows that all equal the head's centre (qt = 0, abs-max 0) must give softmax(cq . (k - ck)) -- the bias
+    term alone -- not a uniform row: against the emulator and against exact attention on the 16-bit inputs"""
+    from vorta_amd import ops
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(8)
+    H, S = 2, 640
+    k = rng.standard_normal((H, S, 128)) + 0.5
+    v = rng.standard_normal((H, S, 128))
+    q = rng.standard_normal((H, S, 128)) + 1.5 * rng.standard_normal((H, 1, 128))
+    qd, kd = to_dev(q, dtype), to_dev(k, dtype)
+    i8 = ops.i8_quantize_k(qd, kd)
+    cq = i8.q_prep[:, 0].to(dtype)  # the centre, rounded to the input type: rows 64 ... 127 sit exactly on it
+    qd[:, 64:128] = cq[:, None, :]
+    i8.q_prep[:, 0] = cq.float()
+    v8, vd, _ = ops.fp8_quantize_v(to_dev(v, dtype))
+    out = torch.empty((H, S, 128), dtype=dtype, device=dev())
+    ops.attn_fwd(qd, i8.k8, v8, out, n_q=S, n_kv=S, v_descale=vd, i8=i8)
+    torch.cuda.synchronize()
+    hooks = _hooks(qd, i8)
+    ve, vde = _vdec(v8, vd)
+    ref, amb = np.zeros((H, S, 128)), np.zeros((H, S))
+    for h in range(H):
+        O.fp8_attn_launch(None, None, ve[h], ref[h], vde[h], n_q=S, n_kv=S, ambiguous=amb[h], wave_operands=hooks[h],
+                          p_mode="mx", defer=24.0)
+    _check(out, ref, dtype, amb, _vmax(ve, vde))
+    full = np.stack([O.dense_attention(qd[h].double().cpu().numpy(), kd[h].double().cpu().numpy(),
+                                       to_dev(v, dtype)[h].double().cpu().numpy()) for h in range(H)])
+    o = out.float().cpu().numpy()
+    assert rel_fro(o[:, 64:128], full[:, 64:128]) < 0.08  # (a uniform softmax is off by far more)
+    uniform = np.broadcast_to(to_dev(v, dtype).double().cpu().numpy().mean(1, keepdims=True), full.shape)
+    assert rel_fro(uniform[:, 64:128], full[:, 64:128]) > 3 * rel_fro(o[:, 64:128], full[:, 64:128])
+
+
 def test_i8_rescale_branch_long_keys_and_split_keys():
     """key norms grow along the sequence: the blocks climb tens of binades above the first one's maximum.  With the trigger at
     1 binade (`defer`) the reference point of every wave moves many times, with the default (24) never or once -- both against

@@ -18,7 +18,8 @@ from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balance
                               slot_groups)
 
 _LAYOUTS = {}
-_BUFFERS = {}  # receive buffers per (geometry, head-slot count): a handful, kept when the layout cache is trimmed
+_BUFFERS = {}  # receive buffers per (geometry, head-slot count): kept when the layout cache is trimmed, least recently used out
+MAX_BUFFER_SETS = max(2, int(__import__("os").environ.get("VORTA_SP_BUFFER_SETS", "4")))
 _ROUTINGS = {}  # (local expert ids, device) -> HeadRouting: the device tables are built once per distinct local mix
 SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
 # fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
@@ -71,7 +72,7 @@ class _SpBuffers:
         return self.f8, self.vwire
 
 
-def _layout(H, S, T, D, device, dtype, counts=None):
+def _layout(H, S, T, D, device, dtype, counts=None, extra_slots=0):
     """(layout of this layer's head placement, receive buffers of this rank's head-slot count)"""
     rank, P = SP_STATE.group_local_rank, SP_STATE.sp_size
     counts = tuple(counts) if counts is not None else (H // P,) * P
@@ -79,13 +80,19 @@ def _layout(H, S, T, D, device, dtype, counts=None):
     if lkey not in _LAYOUTS:
         if len(_LAYOUTS) > 512:
             _LAYOUTS.clear()
-        _LAYOUTS[lkey] = UlyssesLayout(H, S, T, D, P, rank, device, dtype, SP_STATE.group, counts=counts)
+        _LAYOUTS[lkey] = UlyssesLayout(H, S, T, D, P, rank, device, dtype, SP_STATE.group, counts=counts, extra_slots=extra_slots)
     lay = _LAYOUTS[lkey]
     # one buffer set per distinct slot count (at most 2 H / P of them); layouts -- one per distinct tuple of head counts, cheap:
     # a few integers and a shared row map -- are evicted on their own, so trimming them never drops gigabytes mid-run
     bkey = (H, S, T, D, P, rank, str(device), dtype, lay.Hl)
     if bkey not in _BUFFERS:
+        # bounded: a set is 4 buffers of rows_total x D plus the 8-bit copies -- hundreds of MB to GB; a process that
+        # sees several resolutions, text lengths or slot counts keeps the MAX_BUFFER_SETS most recently used ones
+        while len(_BUFFERS) >= MAX_BUFFER_SETS:
+            _BUFFERS.pop(next(iter(_BUFFERS)))
         _BUFFERS[bkey] = _SpBuffers(lay)
+    else:
+        _BUFFERS[bkey] = _BUFFERS.pop(bkey)  # most recently used last
     return lay, _BUFFERS[bkey]
 
 
@@ -161,7 +168,7 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
         cost = [float(S + te) ** 2, float(s_low + te) ** 2, float(S) * n_kv]
     placement, order, counts, parts = place_heads(experts, cost, P, S, dense_only)
     sp_attention.last_placement = placement  # (what a test or a curious caller reads back)
-    lay, sb = _layout(H, S, T, D, q.device, q.dtype, counts)
+    lay, sb = _layout(H, S, T, D, q.device, q.dtype, counts, extra_slots=len(order) - H)
     bufs = sb.bufs
     groups = min(SP_GROUPS, min(counts))
     geom = None if dense_only else geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,

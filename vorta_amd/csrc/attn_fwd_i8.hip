@@ -48,10 +48,16 @@ typedef __attribute__((ext_vector_type(16))) int i32x16;
 constexpr int ROWB8 = D;             // bytes per e4m3 row
 constexpr int TILE8 = KVB * ROWB8;   // 8 KiB
 constexpr int NSI8 = 2;              // (template tag of the body; the rings are the constants below)
-constexpr int K_SLOTS_I8 = 2, V_SLOTS_I8 = 3, B_SLOTS_I8 = 3;  // K / V tile rings (8 KiB tiles), key-bias ring (256-B tiles)
+// ONE wait + workgroup barrier per TWO key blocks (round 5).  The wait and the barrier are ~10 % of a step (tools/trace_i8.py:
+// ~42 + 100-180 cycles of ~1 700: the waves of a workgroup reach the barrier apart, all wait for the last).  With every tile
+// requested TWO steps ahead of its first read and rings of 4 (K, V, key bias) no slot is rewritten inside the pair of steps in
+// which another wave may still read it, so the odd steps end without a barrier; slots cycle with period 4 = the unrolling.
+// Against round 4's rings of 2 / 3 / 3 with a barrier per key block, same box: Hunyuan-129f fused layer 39.4-40.1 against
+// 40.6-41.7 ms (+3 %), Wan-14B-81f 27.5-27.9 against 27.6-28.1 (+0.4 %): profiles/r05_i8_loop_experiments.txt.
+constexpr int K_SLOTS_I8 = 4, V_SLOTS_I8 = 4, B_SLOTS_I8 = 4;  // K / V tile rings (8 KiB tiles), key-bias ring (256-B tiles)
 constexpr int SC_BYTES = KVB * 4;    // one float per key of a block
 constexpr int SEED_BYTES = 8 * 2 * SC_BYTES;  // per wave two slots of 64 int32 seeds
-constexpr int SMEM_I8 = (K_SLOTS_I8 + V_SLOTS_I8) * TILE8 + B_SLOTS_I8 * SC_BYTES + SEED_BYTES;  // 44.75 KiB
+constexpr int SMEM_I8 = (K_SLOTS_I8 + V_SLOTS_I8) * TILE8 + B_SLOTS_I8 * SC_BYTES + SEED_BYTES;  // 69 KiB
 constexpr int MAGIC_I = 0x4B400000;  // float bits of 1.5 * 2^23 = 12 582 912
 constexpr float MAGIC_F = 12582912.f;
 constexpr float SEED_LIMIT = 2000000.f;  // |q8 . k8| <= 2 064 512; the sum must stay below 2^22
@@ -164,8 +170,13 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) am = fmaxf(am, __shfl_xor(am, m, 64));  // max is order-free
-    inv_q = am > 0.f ? 127.f / am : 0.f;
-    const float sq = am > 0.f ? am * (1.f / 127.f) : 1.f;
+    // A wave whose 32 rows all sit on the head's centre (abs-max 0, or below 2^-12: such rows carry no score of their own) keeps
+    // the term the centre leaves: q8 = 0 and unit scale, so its scores are u (0 + rint(k_bias)) = softmax of cq . (k - ck), not a
+    // uniform row
+    const bool flat = !(am >= 0x1p-12f);
+    inv_q = flat ? 1.f : 127.f / am;
+    const float sq = flat ? 1.f : am * (1.f / 127.f);
+    const float q_mul = flat ? 0.f : inv_q;
     m8 = 8.f * ((sq * p.scale_log2) * pp.k_head_scale[head]);
     // both are the same in every lane of the wave: keep them in scalar registers (the loop runs at the VGPR budget)
     m8 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m8)));
@@ -177,7 +188,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
         uint32_t word = 0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          int v = (int)__builtin_rintf(qt[16 * ks + 4 * w + b] * inv_q);
+          int v = (int)__builtin_rintf(qt[16 * ks + 4 * w + b] * q_mul);
           v = max(-127, min(127, v));
           word |= ((uint32_t)v & 0xffu) << (8 * b);
         }
@@ -205,6 +216,8 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     v_col[i] = ((lane & 7) ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1)) << 4;
   }
   int rowK[CH], rowV[CH];  // rows of the next K block / next V block to fetch
+  int rowM[CH];            // ... and of the block between them (K runs two blocks ahead of V)
+#define ROWS_SHIFT() _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) { rowV[i_] = rowM[i_]; rowM[i_] = rowK[i_]; }
   int rowB = 0;            // wave 0: row of key `lane` of the next bias tile
 #define ROWS_OF(dst_, blk_)                                                       \
   _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) {                             \
@@ -273,10 +286,11 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   // row sums: one more MFMA per block against a tile of ones (fp4 e2m1 1.0 = 0b0010: 4 registers read) puts sum_k P'[k][q]
-  // into every register of lacc -- the same P' that multiplies V
-  f32x16 lacc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+  // -- the same P' that multiplies V -- into every register of its result.  The result is a TRANSIENT tile (the MFMA starts
+  // from zero) and ONE register of it is added to the running sum l_run: an accumulator tile held 16 registers for one number
+  // per lane.  (Reading V fragments ahead of the matrix part with the registers this frees -- two channel tiles at the tail of
+  // the VALU part -- measured equal: profiles/r05_i8_loop_experiments.txt.)
+  float l_run = 0.f;
   i32x8 ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = 0x22222222;
@@ -388,22 +402,24 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
       if ((jabs_) * KVB + 32 + row_ >= n_kv) y1[i_] = -INFINITY;                  \
     }                                                                             \
   }
-#define VFRAG(dt_, slot_)                                                         \
+#define VFRAG_TO(dst_, dt_, slot_)                                                \
   _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                              \
     const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                      \
         (LDS_AS i32x2*)(smem + (slot_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8));   \
-    vf_[dt_][2 * n_] = t_[0]; vf_[dt_][2 * n_ + 1] = t_[1];                       \
+    dst_[2 * n_] = t_[0]; dst_[2 * n_ + 1] = t_[1];                               \
   }
-  // requests of step j: K(j+2) into the slot K(j) left, V(j+1) into the slot V(j-2) left, the bias tile of K(j+3) into the slot
-  // the bias of K(j) left (its last reader made the seeds of K(j) one step ago); all are read after this step's barrier
+#define VFRAG(dt_, slot_) VFRAG_TO(vf_[dt_], dt_, slot_)
+  // requests of step j: K(j+3), V(j+1) and the bias tile of K(j+4), each into the slot whose tile was last read two steps ago and
+  // each read two steps later at the earliest (the slot arithmetic is at the loop below)
 #define STAGE_DMA(kw_, vw_, bw_, jabs_)                                           \
   DMA_K(kw_)                                                                      \
   DMA_V(vw_)                                                                      \
   DMA_B(bw_)                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
-  ROWS_NEXT() /* the rows of K(j+3) and of the bias tile of K(j+4) */             \
+  ROWS_SHIFT()                                                                    \
+  ROWS_NEXT() /* the rows of the next K block and of the next bias tile */        \
   __builtin_amdgcn_sched_barrier(0);
 #define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#define STEP_NOSYNC() asm volatile("" ::: "memory");  /* (paired steps: the odd step ends without wait or barrier) */
 
   // The two waves of a SIMD (wave w and w + NW/2 of the workgroup) take turns on its pipes, as in attn_fwd_fp8.hip: while
   // one runs its matrix part -- 13 MFMAs back to back: O += V^T P'^T and the row sums of one block (5 x 64 cycles), the raw
@@ -425,26 +441,16 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   // next rows): back to back at the top of the step they cost the wave ~100 cycles each -- every wave of the workgroup
   // asks at the same moment and the address unit takes 16 pieces per step, 16 cycles apiece -- with VALU work between
   // them the queue has drained when the next one comes (tools/trace_i8.py: 176-208 cycles per step for the requests).
-#ifdef VORTA_I8_DIAG_STALE  /* timing only (wrong results): the conversions use the PREVIOUS block's offsets -- no wait for the max chain */
-  float st0_ = 0.f, st1_ = 0.f;
-#define STALE_A_() const float so0_ = st0_, so1_ = st1_;
-#define STALE_B_() st0_ = off0_; st1_ = off1_; off0_ = so0_; off1_ = so1_;
-#else
-#define STALE_A_()
-#define STALE_B_()
-#endif
 #define VALU_PART(bs_, ss_, qa_, qb_, qc_)                                        \
   {                                                                               \
     const float sb_ = *(const float*)(smem + bias_rd + (bs_) * SC_BYTES);         \
     qa_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
     float off0_, off1_;                                                           \
-    STALE_A_()                                                                    \
     TILE_EXP(ecur, off0_, off1_, n0, n1)                                          \
     __builtin_amdgcn_sched_barrier(0);                                            \
     qb_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
-    STALE_B_()                                                                    \
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, off0_); \
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, off1_); \
     __builtin_amdgcn_sched_barrier(0);                                            \
@@ -453,7 +459,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     *(int*)(smem + seed_wr + (ss_) * SC_BYTES) = SEED_BITS(sb_);                  \
   }
 #define ROWS_UPDATE()                                                             \
-  _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];          \
+  ROWS_SHIFT()                                                                    \
   ROWS_NEXT()
 #define REQ_TAIL(bw_)                                                             \
   DMA_B(bw_)                                                                      \
@@ -507,11 +513,12 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #define PRIO_LO()
 #endif
   // (tile requests INSIDE the matrix part, each behind an MFMA, measured 1.3 % slower than in the VALU part: round 4)
+#define ZERO16_ f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}
 #define PV_PART(vr_, pb_, sc_, mid_)                                              \
   i32x8 vf_[4];                                                                   \
   VFRAG(0, vr_) VFRAG(1, vr_) VFRAG(2, vr_) VFRAG(3, vr_)                         \
-  lacc = ROWSUM_MFMA(ones, pb_, lacc, sc_);                                       \
-  TIE_(lacc, vf_[0]) /* the row-sum MFMA before the first that needs a fragment */ \
+  f32x16 lt_ = ROWSUM_MFMA(ones, pb_, ZERO16_, sc_);                              \
+  TIE_(lt_, vf_[0]) /* the row-sum MFMA before the first that needs a fragment */ \
   mid_ /* the score half's first reads */                                         \
   o[0] = mfma8(vf_[0], pb_, o[0], sc_);                                           \
   TIE_(o[0], vf_[1])                                                              \
@@ -527,7 +534,8 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     const float alpha_ = __builtin_amdgcn_exp2f(-g_);                             \
     _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                           \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;     \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) lacc[i_] *= alpha_;         \
+    l_run = (l_run + lt_[0]) * alpha_; /* block j-1 went in at the old reference */ \
+    lt_[0] = 0.f;                                                                 \
     m_run8 = __builtin_fmaf(g_, 8.f, m_run8);                                     \
     off8 = __builtin_fmaf(g_, -8.f, off8);                                        \
     ecur = fmaxf(ecur - g_, EB_MIN);                                              \
@@ -540,7 +548,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     SCHED_M()                                                                     \
     /* the five MFMAs stay one run AHEAD of the rare branches: left alone, the compiler sinks one that nothing orders below the */ \
     /* tail-mask branch, out of the issue recipe (an empty statement: no instruction, no wait)                              */ \
-    asm volatile("" : "+v"(lacc), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])); \
+    asm volatile("" : "+v"(lt_), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])); \
     /* last, partial key block: mask its tail (once per workgroup; the exponents were taken over the clamped rows too) */ \
     if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(jabs_) }                          \
     /* the reference point moves only when some tile lies more than `etrig` binades above it; O and the row sums */ \
@@ -555,6 +563,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     PACK_Y(pbw_) /* the bytes of block j: four conversions per MFMA gap */        \
     TIE_(n1, pbw_) /* (keeps the conversions in this block: nothing reads them before the next step) */ \
     SCHED_S()                                                                     \
+    l_run += lt_[0]; /* (the row-sum MFMA finished long ago) */                   \
     PRIO_LO()                                                                     \
   }
   // Diagnostic builds only (suffixed libraries: vorta_amd/build.py refuses extra flags for the product): -DVORTA_I8_DIAG pulls
@@ -570,7 +579,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #endif
   // both roles request their tile pieces inside their VALU part (role X behind its matrix part: it goes from the barrier
   // straight into its MFMAs); the 4-wave kernels (no roles) and waves past the query rows request at the top of the step
-#define STEP(kw_, kr_, vw_, vr_, bw_, sr_, bsx_, ssx_, bsy_, ssy_, pbr_, scr_, pbw_, scw_, jabs_) \
+#define STEP(kw_, kr_, vw_, vr_, bw_, sr_, bsx_, ssx_, bsy_, ssy_, pbr_, scr_, pbw_, scw_, jabs_, sync_) \
   {                                                                               \
     TR_(0)                                                                        \
     if (!wave_active || NW != 8) { STAGE_DMA(kw_, vw_, bw_, jabs_) }              \
@@ -586,13 +595,13 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
       if (NW == 8 && !role_y) { VALU_PART(bsx_, ssx_, DMA_K(kw_), DMA_V(vw_), REQ_TAIL(bw_)) } \
       if (NW != 8) VALU_PART(bsx_, ssx_, , , )                                    \
     }                                                                             \
-    STEP_SYNC()                                                                   \
+    sync_()                                                                       \
   }
 
   const int nsteps = blk1 - blk0;
   const bool role_y = ROLE_Y_;  // wave-uniform
   if (nsteps > 0) {
-    // ---- prologue: K(0), V(0), K(1) and the bias tiles of K(0), K(1), K(2); the scores of block 0 fix the reference point ----
+    // ---- prologue: K(0), K(1), K(2), V(0) and the bias tiles of K(0) ... K(3); the scores of block 0 fix the reference point ----
     ROWS_OF(rowK, blk0)
     _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     ROW_OF_B(blk0)
@@ -600,16 +609,21 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     DMA_V(0)
     DMA_B(0)
     ROWS_OF(rowK, blk0 + 1)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];  // rows of block 1: V(1) goes out in step 0
     ROW_OF_B(blk0 + 1)
     DMA_K(1)
     DMA_B(1)
-    ROW_OF_B(blk0 + 2)
-    DMA_B(2)
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowV[i_] = rowK[i_];
     ROWS_OF(rowK, blk0 + 2)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) rowM[i_] = rowK[i_];  // rows of block 2: V(2) in step 1
+    ROW_OF_B(blk0 + 2)
+    DMA_K(2)
+    DMA_B(2)
     ROW_OF_B(blk0 + 3)
-    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) posK[i_] = (blk0 + 2) * KVB + 8 * (CH * wave + i_) + (lane >> 3);
-    posB = (blk0 + 3) * KVB + lane;
+    DMA_B(3)
+    ROWS_OF(rowK, blk0 + 3)  // K(3) in step 0
+    ROW_OF_B(blk0 + 4)
+    _Pragma("unroll") for (int i_ = 0; i_ < CH; ++i_) posK[i_] = (blk0 + 3) * KVB + 8 * (CH * wave + i_) + (lane >> 3);
+    posB = (blk0 + 4) * KVB + lane;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave_active) {
@@ -647,7 +661,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     }
     __syncthreads();  // every wave has read K(0) and the bias tile of K(0) before their slots are overwritten
     {  // step 0: no PV yet -- the scores of block 1, then (role X) the VALU part of block 0
-      STAGE_DMA(0, 1, 0, blk0)
+      STAGE_DMA(3, 1, 0, blk0) /* K(3), V(1), the bias tile of K(4) */
       if (wave_active) {
         i32x4 kfa[4], kfb[4];
         SEEDS_IN(n0, 1, 0)
@@ -660,31 +674,34 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
         scA_ = __float_as_int(ecur);
         __builtin_amdgcn_sched_barrier(0);
         if (!role_y) VALU_PART(2, 0, , , )
+        else { MAKE_SEEDS(2, 0) }  /* (role Y makes its seeds two blocks ahead too, see below) */
       }
       STEP_SYNC()
     }
-    // K and seed slots cycle with period 2, V and bias slots with period 3: unrolled by 6.  Step j: K(j+2) -> slot j % 2,
-    // K(j+1) read from (j+1) % 2; V(j+1) -> (j+1) % 3, V(j-1) read from (j-1) % 3; bias(j+3) -> j % 3; seeds of block j+1
-    // read from (j+1) % 2; role X makes the seeds of block j+2 (bias slot (j+2) % 3, seed slot j % 2) and reads the head of
-    // V(j) (slot j % 3), role Y the seeds of block j+1 (bias slot (j+1) % 3, seed slot (j+1) % 2) and the head of V(j-1)
-    for (int jj = 1; jj < nsteps; jj += 6) {
-      STEP(1, 0, 2, 0, 1, 0, 0, 1, 2, 0, pbA_, scA_, pbB_, scB_, blk0 + jj)
+    // Every ring has period 4 (seeds and byte buffers 2): unrolled by 4.  Step j: requests K(j+3) -> slot (j+3) % 4, V(j+1) ->
+    // (j+1) % 4, bias(j+4) -> j % 4 -- each read two steps later at the earliest, so a barrier (end of every EVEN step; step 0
+    // ends with one) lies between request and read, and each into a slot last read two steps ago, before the previous barrier;
+    // reads K(j+1) from (j+1) % 4, V(j-1) from (j-1) % 4, the seeds of block j+1 from (j+1) % 2; BOTH roles make the seeds of block
+    // j+2 (bias slot (j+2) % 4, seed slot j % 2): role Y, whose VALU part comes first, works one block further ahead than it needs
+    // so that no wave reads a bias tile in the pair of steps in which it is rewritten.
+    for (int jj = 1; jj < nsteps; jj += 4) {
+      STEP(0, 2, 2, 0, 1, 0, 3, 1, 3, 1, pbA_, scA_, pbB_, scB_, blk0 + jj, STEP_NOSYNC)
       if (jj + 1 >= nsteps) break;
-      STEP(0, 1, 0, 1, 2, 1, 1, 0, 0, 1, pbB_, scB_, pbA_, scA_, blk0 + jj + 1)
+      STEP(1, 3, 3, 1, 2, 1, 0, 0, 0, 0, pbB_, scB_, pbA_, scA_, blk0 + jj + 1, STEP_SYNC)
       if (jj + 2 >= nsteps) break;
-      STEP(1, 0, 1, 2, 0, 0, 2, 1, 1, 0, pbA_, scA_, pbB_, scB_, blk0 + jj + 2)
+      STEP(2, 0, 0, 2, 3, 0, 1, 1, 1, 1, pbA_, scA_, pbB_, scB_, blk0 + jj + 2, STEP_NOSYNC)
       if (jj + 3 >= nsteps) break;
-      STEP(0, 1, 2, 0, 1, 1, 0, 0, 2, 1, pbB_, scB_, pbA_, scA_, blk0 + jj + 3)
-      if (jj + 4 >= nsteps) break;
-      STEP(1, 0, 0, 1, 2, 0, 1, 1, 0, 0, pbA_, scA_, pbB_, scB_, blk0 + jj + 4)
-      if (jj + 5 >= nsteps) break;
-      STEP(0, 1, 1, 2, 0, 1, 2, 0, 1, 1, pbB_, scB_, pbA_, scA_, blk0 + jj + 5)
+      STEP(3, 1, 1, 3, 0, 1, 2, 0, 2, 0, pbB_, scB_, pbA_, scA_, blk0 + jj + 3, STEP_SYNC)
     }
+    // a loop left behind an odd step has not waited for that step's requests and has no barrier behind it: the drain reads V of
+    // the last block (requested a step earlier), and the tiles still in flight must land before the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // ---- drain: PV of the last block ----
     if (wave_active) {
       const int vs = (nsteps - 1) % V_SLOTS_I8;
       if ((nsteps - 1) & 1) { pbA_ = pbB_; scA_ = scB_; }  // the bytes of the last block
       PV_PART(vs, pbA_, scA_, )
+      l_run += lt_[0];
     }
   }
 #undef MAKE_SEEDS
@@ -698,8 +715,11 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #undef TILE_EXP
 #undef MASK_TAIL
 #undef VFRAG
+#undef VFRAG_TO
 #undef STAGE_DMA
 #undef STEP_SYNC
+#undef STEP_NOSYNC
+#undef ROWS_SHIFT
 #undef VALU_PART
 #undef REQ_TAIL
 #undef ROWS_UPDATE
@@ -725,7 +745,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 
   if (!wave_active) return;
   // ---------------- epilogue ----------------
-  const float l_tot = lacc[0];  // every register holds the row's sum
+  const float l_tot = l_run;
   if (p.n_splits > 1) {
     // unnormalised partials: ws_o[y][sp][pos][d], ws_ml[y][sp][pos][2]
     if (row_ok) {

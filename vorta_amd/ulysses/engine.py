@@ -445,9 +445,12 @@ class UlyssesLayout:
     _ROW_MAPS: dict = {}
 
     def __init__(self, H: int, S: int, T: int, D: int, P: int, rank: int, device, dtype, group=None,
-                 counts: Optional[Sequence[int]] = None):
+                 counts: Optional[Sequence[int]] = None, extra_slots: Optional[int] = None):
         """`counts` = heads per rank (default: H / P everywhere).  Rank j owns the heads order[starts[j]:starts[j + 1]] of
-        the head order given to the exchange; this rank's receive layout has Hl = counts[rank] head slots."""
+        the head order given to the exchange; this rank's receive layout has Hl = counts[rank] head slots.
+        `extra_slots`: the number of extra parts of heads split by query range (`split_placement`: len(order) - H); when
+        given, sum(counts) must be exactly H + extra_slots -- a mistaken counts vector is refused here, not deep inside the
+        first gather.  None = not checked (sum(counts) >= H)."""
         if S % P:
             raise ValueError(f"sequence {S} must be divisible by the sequence-parallel size {P}")
         if counts is None:
@@ -455,6 +458,8 @@ class UlyssesLayout:
                 raise ValueError(f"heads {H} and sequence {S} must be divisible by the sequence-parallel size {P}")
             counts = [H // P] * P
         counts = [int(c) for c in counts]
+        if extra_slots is not None and sum(counts) != H + int(extra_slots):
+            raise ValueError(f"head counts {counts} hold {sum(counts)} slots, the placement has {H} heads + {extra_slots} extra parts")
         if len(counts) != P or sum(counts) < H or min(counts) < 1:
             raise ValueError(f"head counts {counts} do not place {H} heads on {P} ranks (at least one each; more slots than "
                              "heads = heads split by query range, `split_placement`)")
@@ -947,7 +952,7 @@ class UlyssesRoutedAttention:
             r = max(range(P), key=lambda j: (loads[j], -j)) if heaviest_rank else rank
             key = (tuple(counts), r)
             if key not in layouts:
-                lay = UlyssesLayout(H, S, T, 128, P, r, device, dtype, group, counts=counts)
+                lay = UlyssesLayout(H, S, T, 128, P, r, device, dtype, group, counts=counts, extra_slots=len(order) - H)
                 lay.loopback = loopback
                 layouts[key] = lay
                 if lay.Hl not in self.states:
