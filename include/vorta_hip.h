@@ -169,7 +169,12 @@ int vorta_attn_workspace_bytes(const vorta_attn_args* args, uint64_t* ws_o_bytes
  *   multiplies V); the output (ext->out_dtype, bf16 / fp16) is o[d] * v_descale[head][d] / rowsum.
  *   Every other field of vorta_attn_args means what it means for vorta_attn_fwd (row tables, groups, duplicates,
  *   split keys, device-resident lengths).
- *   ext->flags bit1 selects the mixed-precision kernel (csrc/attn_fwd_mx.hip): 16-bit q k^T, e4m3 P V -- see the field.
+ *   ext->flags bit1 selects the mixed-precision kernel (csrc/attn_fwd_mx.hip): 16-bit q k^T, e4m3 P V -- see the field.  Since
+ *   ABI 7 that kernel writes its probabilities with ONE POWER-OF-TWO SCALE PER QUERY ROW AND 32 KEYS (the block scale of the
+ *   P V MFMA's B operand), as vorta_attn_fwd_i8 does: per tile e = rint(max(max c + 64, 0) - 72) for c = score - reference +
+ *   p_bias, probability = e4m3(2^(c - e)) 2^e (round to nearest even, subnormals kept); the reference point is the row's first
+ *   block's maximum and moves only when a tile lies more than `defer` binades above it (default 24, 0 ... 40).  Nothing is
+ *   flushed for lying far below the row's maximum; the all-e4m3 kernel (flags bit1 clear) keeps the single range above.
  */
 typedef struct vorta_fp8_quant_args {
   uint32_t struct_size;
@@ -255,7 +260,8 @@ typedef struct vorta_attn_fp8_ext {
   const float* v_descale;      /* [..][head_dim], indexed by the head id (not the slot) */
   int64_t v_descale_stride_h;  /* floats between heads (head_dim) */
   float p_bias;                /* log2 bias of the e4m3 probabilities; 0 = default (5) */
-  float defer;                 /* deferred-rescale threshold in log2 units; 0 = default (3); p_bias + defer <= 8 */
+  float defer;                 /* deferred-rescale threshold in log2 units; 0 = default (3; mixed kernel: 24); p_bias + defer <= 8
+                                  (mixed kernel: 0 <= defer <= 40, p_bias <= 16) */
   int32_t flags;               /* bit0: row sums by VALU adds of the unrounded P instead of the ones-tile MFMA;
                                   bit1 (ABI 4): MIXED precision -- q, k (and o) are 16-bit tensors of type args->dtype =
                                   out_dtype with strides in elements, the scores run on the 16-bit MFMA with args->scale

@@ -510,6 +510,8 @@ def _fp8_flash_rows(Q: np.ndarray, K: np.ndarray, V: np.ndarray, blk_lo: int, bl
     O = np.zeros((n, V.shape[1]))
     l = np.zeros(n)
     m = None
+    if p_mode == "rne_mx":  # the mixed kernel (attn_fwd_mx.hip) since ABI 7: exp2 + round-to-nearest e4m3 under the same block scales
+        return _i8_mx_flash_rows(z_all, V, blk_lo, blk_hi, p_bias, defer, round_p, block, ambiguous, rne=True)
     if p_mode == "mx":
         # the kernel's byte-domain offset is ~1.5 2^23 x 8 u (u = one integer score unit in the exp2 domain, the operands' last
         # column) rounded to fp32 twice (the row's offset, then the tile's): a probability's y may sit that far from this
@@ -561,7 +563,7 @@ _I8_GROUP = np.arange(64) >> 5
 
 
 def _i8_mx_flash_rows(z_all: np.ndarray, V: np.ndarray, blk_lo: int, blk_hi: int, p_bias: float, etrig: float, round_p: bool,
-                      block: int, ambiguous: Optional[np.ndarray], slack: float = 2e-3):
+                      block: int, ambiguous: Optional[np.ndarray], slack: float = 2e-3, rne: bool = False):
     """One wave of vorta_attn_fwd_i8 (ABI 7, attn_fwd_i8.hip): MX-SCALED probabilities.  Byte domain y = 8 (z - m + p_bias) + 56
     against the row's reference point m (the maximum of its first block).  Per 64-key block and per KEY TILE of 32 consecutive
     keys (`_I8_GROUP`; keys past the end of the list repeat the last one: the kernel clamps its rows), for every query row: the
@@ -570,7 +572,11 @@ def _i8_mx_flash_rows(z_all: np.ndarray, V: np.ndarray, blk_lo: int, blk_hi: int
     only when some (row, tile) of the wave has e > etrig: then every row moves by max(its larger e, 0) whole binades (bytes
     unchanged).  `ambiguous`: as `_fp8_flash_rows`, plus -- where a tile's exponent is within noise of its neighbour -- the
     mass of its probabilities below byte 16 (one exponent further they decode through e4m3's linear subnormals, not to the
-    same values)."""
+    same values).
+    `rne=True`: the MIXED kernel's form of the same scheme (attn_fwd_mx.hip): scores c = z - m + p_bias in the exp2 domain, e =
+    rint(max(max c + 64, 0) - 72) per (row, tile) -- the kernel takes the tile maximum over scores shifted up by 64 binades and
+    reads a tile that is negative throughout as 0 -- probability = e4m3_rne(2^(c - e)) 2^e (v_exp_f32, then
+    v_cvt_scalef32_pk_fp8_f32: round to nearest even with subnormals; the tile's largest lands in [2^7.5, 2^8.5))."""
     assert block == 64
     n = z_all.shape[0]
     O = np.zeros((n, V.shape[1]))
@@ -584,10 +590,16 @@ def _i8_mx_flash_rows(z_all: np.ndarray, V: np.ndarray, blk_lo: int, blk_hi: int
         y = 8.0 * (z - m[:, None] + p_bias) + 56.0
         ypad = np.concatenate([y, np.repeat(y[:, -1:], block - (hi - lo), 1)], 1) if hi - lo < block else y
         ymx = np.stack([ypad[:, _I8_GROUP == g].max(1) for g in (0, 1)], 1)  # (n, 2)
-        t = (ymx - I8_YMID) / 8.0
-        with np.errstate(invalid="ignore"):
-            e = np.maximum(np.rint(np.where(np.isfinite(t), t, I8_EMIN)), I8_EMIN)
-        e_near = np.abs(np.abs(t - np.floor(t)) - 0.5) < slack / 4.0  # a correct kernel may round the other way
+        if rne:
+            cmx = (ymx - 56.0) / 8.0  # the tile maximum in the exp2 domain
+            t = np.maximum(np.where(np.isfinite(cmx), cmx, -1e30) + 64.0, 0.0) - 72.0
+            e = np.rint(t)
+            e_near = np.abs(np.abs(t - np.floor(t)) - 0.5) < 1e-4
+        else:
+            t = (ymx - I8_YMID) / 8.0
+            with np.errstate(invalid="ignore"):
+                e = np.maximum(np.rint(np.where(np.isfinite(t), t, I8_EMIN)), I8_EMIN)
+            e_near = np.abs(np.abs(t - np.floor(t)) - 0.5) < slack / 4.0  # a correct kernel may round the other way
         if j > blk_lo:
             # (a trigger within noise of its threshold needs no mark: moving the reference point changes power-of-two scales on
             # both sides of the accumulation, not one byte and not one value)
@@ -604,7 +616,15 @@ def _i8_mx_flash_rows(z_all: np.ndarray, V: np.ndarray, blk_lo: int, blk_hi: int
         ek = e[:, _I8_GROUP[:hi - lo]]  # (n, keys): each key's lane exponent
         yp = y - 8.0 * ek
         Pex = np.exp2(z - m[:, None] + p_bias)
-        if round_p:
+        if round_p and rne:
+            P8x = np.exp2(np.where(np.isfinite(yp), (yp - 56.0) / 8.0, -np.inf))
+            assert P8x.max() <= 448.0, P8x.max()  # (the hardware conversion would write NaN)
+            P = e4m3_round(P8x) * np.exp2(ek)
+            if ambiguous is not None:
+                near = e4m3_round(P8x * (1 + _FP8_AMBIG)) != e4m3_round(P8x * (1 - _FP8_AMBIG))
+                ambiguous += (Pex * near).sum(1)
+                ambiguous += (Pex * ((P8x < 2.0 ** -5) & e_near[:, _I8_GROUP[:hi - lo]])).sum(1)
+        elif round_p:
             with np.errstate(invalid="ignore"):
                 byte = np.clip(np.rint(np.where(np.isfinite(yp), yp, 0.0)), 0, 126).astype(np.int64)
             P = e4m3_decode(byte) * np.exp2(ek)

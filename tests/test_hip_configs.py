@@ -453,6 +453,7 @@ def test_fp8_headline_sizes_sampled_waves_vs_oracle_emulator(config, precision):
         torch.cuda.synchronize()
         v8_, vd_, _ = ops.fp8_quantize_v(v[0])
         q8, k8, v8, vd = M._operands(q[0], k[0], v8_, vd_, dtype)
+    em = dict(M.MX) if precision == "fp8pv" else {}  # the emulator's mode: the mixed kernel scales its probabilities per tile
     N = S + T
     ref, amb = np.zeros((3, N, 128)), np.full((3, N), np.nan)
     gen = np.random.default_rng(7)
@@ -470,7 +471,7 @@ def test_fp8_headline_sizes_sampled_waves_vs_oracle_emulator(config, precision):
     picks = some([nq], 5)
     last = ((S + te - 1) // 32) * 32  # the wave with the last valid text row / last video rows
     O.fp8_attn_launch(q8[0], k8[0], v8[0], ref[0], vd[0], n_q=nq, n_kv=S + te, q_valid=S + te, ambiguous=amb[0],
-                      wave_filter=lambda g, w0: picks(g, w0) or w0 == last)
+                      wave_filter=lambda g, w0: picks(g, w0) or w0 == last, **em)
     # coreset expert
     hl = torch.tensor([1], dtype=torch.int32, device=dev())
     keep_q, drop_q = ops.coreset_select(q[0], geom.latent, geom.group, geom.n_keep, tail_first=S, n_tail=T, head_list=hl)
@@ -480,17 +481,17 @@ def test_fp8_headline_sizes_sampled_waves_vs_oracle_emulator(config, precision):
     picks = some([nql], 5)
     O.fp8_attn_launch(q8[1], k8[1], v8[1], ref[1], vd[1], n_q=nql, n_kv=geom.S_low + te, q_valid=geom.S_low + te,
                       q_rows=keep_q[0].cpu().numpy(), kv_rows=keep_k[0].cpu().numpy(), dup_rows=drop_q[0].cpu().numpy(),
-                      n_dup_pos=geom.G, ambiguous=amb[1], wave_filter=lambda g, w0: picks(g, w0) or w0 == 0)
+                      n_dup_pos=geom.G, ambiguous=amb[1], wave_filter=lambda g, w0: picks(g, w0) or w0 == 0, **em)
     # sliding-tile expert (query tiles of equal key lists merged, as vorta_amd/routed.py launches them)
     q_rows, kv_rows, n_kv, table, n_lists = geom.sta_launch_tables(te, 256)
     qr, kr, tb = q_rows.cpu().numpy(), kv_rows.cpu().numpy(), table.cpu().numpy()
     bounds = [(int(tb[tb[:, 0] == g, 1].min()), int(tb[tb[:, 0] == g, 2].max())) for g in range(n_lists)]
     O.fp8_attn_launch(q8[2], k8[2], v8[2], ref[2], vd[2], n_q=S, n_kv=n_kv, q_rows=qr, kv_rows=kr, q_group_bounds=bounds,
-                      ambiguous=amb[2], wave_filter=some([b[1] - b[0] for b in bounds], 12))
+                      ambiguous=amb[2], wave_filter=some([b[1] - b[0] for b in bounds], 12), **em)
     if T:
         # inside the fused grid the text launch of the sliding expert is unsplit (vorta_amd/routed.py FUSED_TEXT_SPLITS)
         O.fp8_attn_launch(q8[2], k8[2], v8[2], ref[2], vd[2], n_q=T, q_row_offset=S, q_valid=te, n_kv=S + te,
-                          n_splits=1, ambiguous=amb[2], wave_filter=lambda g, w0: w0 in (0, 64))
+                          n_splits=1, ambiguous=amb[2], wave_filter=lambda g, w0: w0 in (0, 64), **em)
     o = out[0].float().cpu().numpy()
     vmax = F._vmax(v8, vd)
     for h in range(3):

@@ -467,7 +467,7 @@ FAMILY_GATES = {"white": 39.0, "common3": 38.0, "student_t3": 42.0, "smooth": 55
 def test_fp8_operator_psnr_on_structured_inputs(geometry):
     """gate (ii) beyond white noise, at BASELINE configs[4]'s geometry and at the headline's (with text rows): every expert,
     fp8 against the bf16 kernels on the same bf16 inputs, both PSNR conventions printed, the stricter one gated."""
-    from _fp8_inputs import NAMES, families, psnr, smoothed
+    from _fp8_inputs import NAMES, families, psnr, robust_psnr, smoothed
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
     dtype = torch.bfloat16
     if geometry == "wan14b-81f":
@@ -487,7 +487,11 @@ def test_fp8_operator_psnr_on_structured_inputs(geometry):
         torch.cuda.synchronize()
         assert torch.isfinite(out.float()).all(), key
         table = {experts[h]: psnr(out[0, h, :S + te], ref[0, h, :S + te]) for h in range(3)}
-        print(f"fp8 vs bf16 [{geometry}] {NAMES[key]}: " + ", ".join(f"{n} {a:.1f} / {b:.1f} dB rel {c:.3f}" for n, (a, b, c) in table.items()))
+        rob = {experts[h]: robust_psnr(out[0, h, :S + te], ref[0, h, :S + te]) for h in range(3)}
+        # (the all-e4m3 path is gated on PSNR only: its scores carry 3 mantissa bits and its probabilities one exponent range per
+        # row -- the relative error and the PSNR over the 99.9th percentile are printed for the record; "fp8pv" and "i8pv" hold
+        # 0.08 relative, tests/test_hip_mx.py and tests/test_hip_i8.py)
+        print(f"fp8 vs bf16 [{geometry}] {NAMES[key]}: " + ", ".join(f"{n} {a:.1f} / {b:.1f} / p99.9 {rob[n]:.1f} dB rel {c:.3f}" for n, (a, b, c) in table.items()))
         for n, (p_range, p_peak, rel) in table.items():
             assert p_peak >= FAMILY_GATES[key] and p_range >= p_peak, (geometry, key, n, p_range, p_peak, rel)
         if key == "outlier_w":  # per-channel smoothing of q, k: exact for the scores, no help for a floating-point format

@@ -19,6 +19,8 @@ pytestmark = pytest.mark.gpu
 from _util import dev, rel_fro, to_dev  # noqa: E402
 from test_hip_fp8 import RELF_PACK, _check, _vmax  # noqa: E402
 
+MX = dict(p_mode="rne_mx", defer=24.0)  # the emulator's mode for this kernel since ABI 7 (one scale per query row and 32 keys)
+
 
 def _operands(qd, kd, v8, vd, dtype, scale=None):
     """what the kernel multiplies: (q', k, v8 decoded, v_descale) as float64 arrays"""
@@ -43,7 +45,7 @@ def test_mx_dense_ragged_vs_emulator(dtype, block_rows):
     qe, ke, ve, vde = _operands(qd, kd, v8, vd, dtype)
     ref, exact, amb = np.zeros((H, Sq, 128)), np.zeros((H, Sq, 128)), np.zeros((H, Sq))
     for h in range(H):
-        O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, ambiguous=amb[h])
+        O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, ambiguous=amb[h], **MX)
         O.fp8_attn_launch(qe[h], ke[h], ve[h], exact[h], vde[h], n_q=Sq, n_kv=n_kv, q_valid=q_valid, round_p=False)
     _check(out, ref, dtype, amb, _vmax(ve, vde))
     assert rel_fro(out.float().cpu().numpy(), exact) <= RELF_PACK
@@ -54,7 +56,9 @@ def test_mx_dense_ragged_vs_emulator(dtype, block_rows):
 
 
 def test_mx_rescale_branch_long_keys_and_split_keys():
-    """key norms grow along the sequence (the reference point of every wave moves several times); then the same keys cut
+    """key norms grow along the sequence: the blocks climb tens of binades above the first one's maximum.  With the trigger at
+    1 binade (`defer`) the reference point of every wave moves many times, with the default (24) never or once -- both against
+    the emulator at the same trigger and against each other (the branch changes scales, not values); then the same keys cut
     into 3 and 8 splits with the combine kernel"""
     from vorta_amd import ops
     dtype = torch.float16
@@ -66,13 +70,18 @@ def test_mx_rescale_branch_long_keys_and_split_keys():
     qd, kd = to_dev(q, dtype), to_dev(k, dtype)
     v8, vd, _ = ops.fp8_quantize_v(to_dev(v, dtype))
     qe, ke, ve, vde = _operands(qd, kd, v8, vd, dtype)
-    for n_splits in (1, 3, 8):
-        out = torch.empty((H, Sq, 128), dtype=dtype, device=dev())
-        ops.attn_fwd(qd[:, :Sq], kd, v8, out, n_q=Sq, n_kv=Skv, v_descale=vd, n_splits=n_splits)
-        ref, amb = np.zeros((H, Sq, 128)), np.zeros((H, Skv))
-        for h in range(H):
-            O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=Sq, n_kv=Skv, n_splits=n_splits, ambiguous=amb[h])
-        _check(out, ref, dtype, amb[:, :Sq], _vmax(ve, vde))
+    outs = {}
+    for defer in (1.0, 24.0):
+        for n_splits in (1, 3, 8):
+            out = torch.empty((H, Sq, 128), dtype=dtype, device=dev())
+            ops.attn_fwd(qd[:, :Sq], kd, v8, out, n_q=Sq, n_kv=Skv, v_descale=vd, n_splits=n_splits, fp8_opts={"defer": defer})
+            ref, amb = np.zeros((H, Sq, 128)), np.zeros((H, Skv))
+            for h in range(H):
+                O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=Sq, n_kv=Skv, n_splits=n_splits, ambiguous=amb[h],
+                                  p_mode="rne_mx", defer=defer)
+            _check(out, ref, dtype, amb[:, :Sq], _vmax(ve, vde))
+            outs[(defer, n_splits)] = out.float().cpu().numpy()
+    assert rel_fro(outs[(1.0, 1)], outs[(24.0, 1)]) < 2e-3  # scales moved, values did not
 
 
 @pytest.mark.parametrize("block_rows", [128, 256])
@@ -101,7 +110,7 @@ def test_mx_tables_groups_duplicates_heads(block_rows):
     ref, amb = np.zeros((H, rows, 128)), np.zeros((H, rows))
     for h in (3, 0):
         O.fp8_attn_launch(qe[h], ke[h], ve[h], ref[h], vde[h], n_q=n_q, n_kv=n_kv, q_rows=q_rows, q_group_len=glen,
-                          kv_rows=kv_rows, dup_rows=dup, n_dup_pos=60, ambiguous=amb[h])
+                          kv_rows=kv_rows, dup_rows=dup, n_dup_pos=60, ambiguous=amb[h], **MX)
     _check(out, ref, dtype, amb, _vmax(ve, vde))
     assert torch.all(out[2] == 0) and torch.all(out[1] == 0)
 
@@ -148,14 +157,20 @@ def test_mx_routed_attention_vs_oracle(model, fused):
         assert torch.all(out[0, :, S + te:] == 0)
 
 
+# relative Frobenius error against the bf16 kernels: 16-bit scores + probabilities with one scale per query
+# row and 32 keys hold it on EVERY family, Student-t(3) included (0.13-0.15 there up to ABI 6: the probabilities' range)
+MX_REL_GATE = 0.08
+
+
 @pytest.mark.parametrize("geometry", ["wan14b-81f", "hunyuan-129f"])
 def test_mx_operator_psnr_on_every_input_family(geometry):
     """gate (ii): every expert, every input family, precision "fp8pv" against the bf16 kernels on the same bf16 inputs:
     >= 40 dB over max|x| of the 16-bit result -- including the peaked-softmax and outlier-channel families on which the
     all-e4m3 path sits at 36 / 29 / 21 dB"""
-    from _fp8_inputs import NAMES, families, psnr
+    from _fp8_inputs import NAMES, families, psnr, robust_psnr
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
     dtype = torch.bfloat16
+    failures = []
     if geometry == "wan14b-81f":
         latent, tile, window, group, model, T, te = (21, 45, 80), (7, 9, 8), (3, 3, 3), (3, 3, 2), "wan", 0, 0
     else:
@@ -172,7 +187,11 @@ def test_mx_operator_psnr_on_every_input_family(geometry):
         out = routed_attention(q16, k16, v16, routing, geom, fp8="fp8pv", **kw)
         torch.cuda.synchronize()
         assert torch.isfinite(out.float()).all(), key
-        table = {experts[h]: psnr(out[0, h, :S + te], ref[0, h, :S + te]) for h in range(3)}
-        print(f"fp8pv vs bf16 [{geometry}] {NAMES[key]}: " + ", ".join(f"{n} {a:.1f} / {b:.1f} dB rel {c:.3f}" for n, (a, b, c) in table.items()))
-        for n, (p_range, p_peak, rel) in table.items():
-            assert p_peak >= 40.0, (geometry, key, n, p_range, p_peak, rel)
+        table = {experts[h]: psnr(out[0, h, :S + te], ref[0, h, :S + te]) + (robust_psnr(out[0, h, :S + te], ref[0, h, :S + te]),)
+                 for h in range(3)}
+        print(f"fp8pv vs bf16 [{geometry}] {NAMES[key]}: " + ", ".join(f"{n} {a:.1f} / {b:.1f} / p99.9 {d:.1f} dB rel {c:.3f}"
+                                                                       for n, (a, b, c, d) in table.items()))
+        for n, (p_range, p_peak, rel, p_rob) in table.items():
+            if p_peak < 40.0 or rel > MX_REL_GATE:
+                failures.append((geometry, key, n, round(p_peak, 1), round(rel, 3)))
+    assert not failures, failures

@@ -37,8 +37,8 @@ constexpr int SMEM_MX = NSMX * (TILE_BYTES + TILE8);  // 48 KiB
 struct ParamsMx {
   Params p;
   const float* v_descale; int64_t v_descale_sh;
-  float p_bias;  // log2 bias of the packed probabilities
-  float thr;     // p_bias + defer: offset scores above this move the reference point
+  float p_bias;  // log2 bias of the probabilities (P' = 2^(z - reference + p_bias))
+  float etrig;   // binades: a key tile whose block exponent exceeds this moves its row's reference point (rare)
 };
 struct MultiParamsMx {
   ParamsMx seg[MAX_SEGMENTS];
@@ -46,8 +46,11 @@ struct MultiParamsMx {
   int n;
 };
 
-__device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);  // cbsz = blgp = 0: e4m3 x e4m3, no block scale
+// O^T += V8^T P8^T with block scales on the B operand, as attn_fwd_i8.hip (round 5): scale block s of a column = bytes 16 s ...
+// 16 s + 15 of both lanes of the column = one query row x the 32 keys of key tile s; its E8M0 byte is read from the lane of half s
+constexpr int SC_ONE = 127;
+__device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, SC_ONE, 0, sb);  // cbsz = blgp = 0: e4m3 x e4m3
 }
 
 template <typename T, int NW, bool KVTAB, int NS>
@@ -187,10 +190,10 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   // row sums: one more MFMA per block against a tile of ones (fp4 e2m1 1.0 = 0b0010: 4 registers read) puts sum_k P'[k][q]
-  // into every register of lacc -- the same rounded P' that multiplies V
-  f32x16 lacc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+  // into every register of its result -- the same rounded P' that multiplies V.  The result is a transient tile (the MFMA
+  // starts from zero) and ONE register of it is added to the running sum l_run: an accumulator tile held 16 registers for one
+  // number per lane, and this loop is at the register budget (round 5: the block exponents need three more)
+  float l_run = 0.f;
   i32x8 ones;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = 0x22222222;
@@ -198,18 +201,32 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
   i32x8 pb_;  // packed probabilities of the current block (B operand of the PV MFMAs)
 #pragma unroll
   for (int i = 0; i < 8; ++i) pb_[i] = 0;
-  // Online softmax in the exp2 domain.  m_run = reference point of this row (a lower bound of its running max, at most
-  // thr - p_bias below it); the score MFMAs start from minit = p_bias - m_run in every accumulator register, so they
-  // produce z - m_run + p_bias directly and P' = P * 2^p_bias = exp2 of that (P' <= 2^thr <= 256 < 448, the e4m3 maximum).
-  // minit only changes in the (rare) rescale branch.
+  // Online softmax in the exp2 domain.  m_run = reference point of this row (its first block's maximum; it moves again only
+  // when a key tile lies more than `etrig` binades above it); the score MFMAs start from minit = p_bias - m_run + CSH in every
+  // accumulator register, so they produce c = z - m_run + p_bias + CSH directly.  minit only changes in the (rare) rescale branch.
+  // MX-SCALED PROBABILITIES (round 5, as attn_fwd_i8.hip): per query row and key tile of 32 keys, e = rint(max c - CSH - 8); the
+  // e4m3 probability is exp2(c) / 2^(CSH + e) -- v_cvt_scalef32_pk_fp8_f32 divides by the power of two of its scale operand
+  // (tools/probe_cvt_scale.hip), round to nearest even with e4m3's subnormals -- so the tile's largest lands in [2^7.5, 2^8.5)
+  // whatever its distance from the row's maximum, and 2^e goes to the P V MFMA as the B operand's block scale.  The shift CSH
+  // keeps the scores of every key that matters positive: the tile maximum is then a signed-integer max over the float bits.
   float m_run = -1e30f;
-  const float pbias = pp.p_bias, thr = pp.thr;
+  constexpr float CSH = 64.f;
+  constexpr float EBIAS = 12582912.f + 127.f;   // biased exponent eb = 1.5 2^23 + 127 + e: a float that is an integer, whose
+  constexpr float CE = EBIAS - CSH - 8.f;       // low byte is the E8M0 scale byte (eb = max c + CE rounds once, to nearest)
+  constexpr float EB_MIN = EBIAS - 100.f;
+  const float pbias = pp.p_bias, etrig_b = EBIAS + pp.etrig;
   f32x16 sA0, sA1, sB0, sB1;  // scores (minus m_run) of the current / next key block (roles swap every block)
   f32x16 minit;
 #pragma unroll
   for (int i = 0; i < 16; ++i) minit[i] = 0.f;
-  float mx_cur = -1e30f;       // row max of the current block's (offset) scores
+  float ecur = EBIAS;          // biased block exponent of key tile hh (whose scale this lane supplies) of the current block
+  float sc0 = 1.f, sc1 = 1.f;  // 2^(CSH + e) of key tiles 0, 1 of the current block: the conversions' scale operands
 
+  // two floats / 2^floor(log2 scale) -> two e4m3 bytes into the low (hi_ false) or high half of a word
+#define CVT_SC(old_, a_, b_, scale_, hi_)                                         \
+  ([&]() { typedef __attribute__((ext_vector_type(2))) short s2_; int cvt_old_ = (old_);                            \
+           s2_ cvt_r_ = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(*(s2_*)&cvt_old_, (a_), (b_), (scale_), (hi_));    \
+           return *(int*)&cvt_r_; }())
   // scores of a block from the K ring slot `par_` into (d0_, d1_); the tail mask is applied by the consumer
 #define QK(d0_, d1_, par_)                                                        \
   {                                                                               \
@@ -227,11 +244,12 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) mx_ = fmaxf(mx_, b_[i_]);   \
     dst_ = half_max(mx_);                                                         \
   }
-  // The loop only asks two things of the NEXT block's row max: "is it above `thr` (> 0)?" and, if so, its value.  Both
-  // are answered by a signed-integer max over the float bit patterns (order-preserving for non-negative floats, any
-  // negative result reads as "not above"; -inf of masked keys is a negative integer, there are no NaNs): v_max3_i32
-  // needs no canonicalising v_max x,x of the MFMA outputs, and two chains halve the dependent latency.
-#define ROW_MAX_POS(dst_, a_, b_)                                                  \
+  // Block exponents of the NEXT block from its (shifted, hence positive where it matters) scores: signed-integer max over
+  // each key tile's 16 registers (v_max3_i32 needs no canonicalising v_max x,x of the MFMA outputs; a tile that is negative
+  // throughout -- 64 binades under the reference -- reads as "least": its exponent clamps), one half exchange that leaves tile
+  // 0's row max in the lanes of half 0 and tile 1's in half 1 (where the MFMA reads the scales), one add that rounds to the
+  // biased exponent, a second exchange for both tiles' conversion scales (bits (127 + CSH + e) << 23).
+#define TILE_EXP(eh_, s0_, s1_, a_, b_)                                           \
   {                                                                               \
     int m0_ = max(max(__float_as_int(a_[0]), __float_as_int(a_[1])), __float_as_int(a_[2])); \
     int m1_ = max(max(__float_as_int(b_[0]), __float_as_int(b_[1])), __float_as_int(b_[2])); \
@@ -239,10 +257,16 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
       m0_ = max(max(m0_, __float_as_int(a_[i_])), __float_as_int(a_[i_ + 1]));    \
       m1_ = max(max(m1_, __float_as_int(b_[i_])), __float_as_int(b_[i_ + 1]));    \
     }                                                                             \
-    m0_ = max(max(m0_, __float_as_int(a_[15])), __float_as_int(b_[15]));          \
-    m0_ = max(m0_, m1_);                                                          \
-    auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m0_, false, false); \
-    dst_ = __int_as_float(max((int)r_[0], (int)r_[1]));                           \
+    m0_ = max(m0_, __float_as_int(a_[15]));                                       \
+    m1_ = max(m1_, __float_as_int(b_[15]));                                       \
+    auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m1_, false, false); \
+    /* (... , 0): a tile that is negative throughout would hand over its LEAST element; with the maximum read as 0 its */ \
+    /* elements still convert without overflow, and e >= -72 needs no floor                                            */ \
+    const int mt_ = max(max((int)r_[0], (int)r_[1]), 0);                          \
+    eh_ = __int_as_float(mt_) + CE;                                               \
+    auto e_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(eh_), __float_as_uint(eh_), false, false); \
+    s0_ = __uint_as_float((e_[0] + (unsigned)CSH) << 23);                         \
+    s1_ = __uint_as_float((e_[1] + (unsigned)CSH) << 23);                         \
   }
   // the same with the fragments of the first KPRE k-steps already in registers (read at the top of the step,
   // their LDS latency hides under the row-max phase)
@@ -262,15 +286,20 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
   // move the reference point of the row up by g_ (>= 0): everything accumulated so far and the current block's
   // offset scores are brought to the new reference, and the accumulator seed follows.  The empty asm keeps the
   // seed an opaque 16-register value (otherwise the compiler re-materialises the splat before every use).
-#define RAISE_REF(g_, c0_, c1_)                                                   \
+#define RAISE_REF(c0_, c1_)                                                       \
   {                                                                               \
-    const float alpha_ = __builtin_amdgcn_exp2f(-(g_));                           \
+    const float g_ = fmaxf(half_max(ecur) - EBIAS, 0.f); /* whole binades: the larger of the row's two tile exponents */ \
+    const float alpha_ = __builtin_amdgcn_exp2f(-g_);                             \
     _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                           \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;     \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) lacc[i_] *= alpha_;         \
-    m_run += (g_);                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= (g_); c1_[i_] -= (g_); minit[i_] = pbias - m_run; } \
+    l_run *= alpha_;                                                              \
+    m_run += g_;                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= g_; c1_[i_] -= g_; minit[i_] = pbias - m_run + CSH; } \
     asm volatile("" : "+v"(minit));                                               \
+    ecur = fmaxf(ecur - g_, EB_MIN);                                              \
+    auto e2_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(ecur), __float_as_uint(ecur), false, false); \
+    sc0 = __uint_as_float((e2_[0] + (unsigned)CSH) << 23);                        \
+    sc1 = __uint_as_float((e2_[1] + (unsigned)CSH) << 23);                        \
   }
   // top of step j: K(j+NS) -> the slot K(j) left, V(j+NS-1) -> the slot V(j-1) left.  They are read in step
   // j+NS-1, so the barrier that ends step j only waits for the requests of step j-NS+2 and older: with NS = 3
@@ -343,27 +372,24 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
           if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
           if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
         }                                                                         \
-        ROW_MAX(mx_cur, c0_, c1_)                                                 \
       }                                                                           \
-      /* deferred rescale: the reference point moves only when some row of the wave outgrew it by more than */ \
-      /* `thr - p_bias` (so P' <= 2^thr: inside e4m3's range); rows that did not grow                          */ \
-      /* keep theirs (g = 0)                                                                                  */ \
-      if (!__all(mx_cur <= thr)) {                                                \
-        const float g_ = fmaxf(mx_cur - pbias, 0.f);                              \
-        RAISE_REF(g_, c0_, c1_)                                                   \
-      }                                                                           \
+      /* the reference point moves only when some key tile lies more than `etrig` binades above it (the exponents were */ \
+      /* taken over the clamped rows of a partial block too)                                                          */ \
+      if (!__all(ecur <= etrig_b)) { RAISE_REF(c0_, c1_) }                        \
+      const int sb_ = __float_as_int(ecur); /* its low byte: the E8M0 scale 127 + e of this lane's key tile */ \
+      const float cs0_ = sc0, cs1_ = sc1;                                         \
       QK_PRE(n0_, n1_, knext_) /* block j+1 (harmless garbage past the end) */    \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
         c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                \
         c1_[i_] = __builtin_amdgcn_exp2f(c1_[i_]);                                \
       }                                                                           \
-      /* P' -> e4m3 straight from the accumulator registers: a lane owns one query and 32 of the block's 64 keys = the B */ \
-      /* operand of ONE K = 64 MFMA (v_cvt_pk_fp8_f32 keeps the other half of its destination: fed the stale word)      */ \
+      /* P' / 2^(CSH + e) -> e4m3 straight from the accumulator registers: a lane owns one query and 32 of the block's 64 keys */ \
+      /* = the B operand of ONE K = 64 MFMA (the conversion keeps the other half of its destination: fed the stale word)     */ \
       _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                          \
-        pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_], c0_[4 * w_ + 1], pb_[w_], false); \
-        pb_[w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c0_[4 * w_ + 2], c0_[4 * w_ + 3], pb_[w_], true); \
-        pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_], c1_[4 * w_ + 1], pb_[4 + w_], false); \
-        pb_[4 + w_] = __builtin_amdgcn_cvt_pk_fp8_f32(c1_[4 * w_ + 2], c1_[4 * w_ + 3], pb_[4 + w_], true); \
+        pb_[w_] = CVT_SC(pb_[w_], c0_[4 * w_], c0_[4 * w_ + 1], cs0_, false);      \
+        pb_[w_] = CVT_SC(pb_[w_], c0_[4 * w_ + 2], c0_[4 * w_ + 3], cs0_, true);   \
+        pb_[4 + w_] = CVT_SC(pb_[4 + w_], c1_[4 * w_], c1_[4 * w_ + 1], cs1_, false); \
+        pb_[4 + w_] = CVT_SC(pb_[4 + w_], c1_[4 * w_ + 2], c1_[4 * w_ + 3], cs1_, true); \
       }                                                                           \
       _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
         i32x8 vf_;                                                                \
@@ -372,11 +398,13 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
               (LDS_AS i32x2*)(smem + (kcur_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8)); \
           vf_[2 * n_] = t_[0]; vf_[2 * n_ + 1] = t_[1];                           \
         }                                                                         \
-        o[dt_] = mfma8(vf_, pb_, o[dt_]);                                         \
+        o[dt_] = mfma8(vf_, pb_, o[dt_], sb_);                                    \
       }                                                                           \
-      lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pb_, lacc, 4, 0, 0, 0, 0, 0); \
-      ROW_MAX_POS(mx_cur, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */ \
+      const f32x16 lt_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                  \
+          ones, pb_, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 4, 0, 0, SC_ONE, 0, sb_); \
+      TILE_EXP(ecur, sc0, sc1, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */ \
       SCHED_RECIPE()                                                              \
+      l_run += lt_[0];                                                            \
     }                                                                             \
     STEP_SYNC()                                                                   \
   }
@@ -402,14 +430,25 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
           if (blk0 * KVB + 32 + row >= n_kv) sA1[i] = -INFINITY;
         }
       }
-      ROW_MAX(mx_cur, sA0, sA1)
+      float mx0;
+      ROW_MAX(mx0, sA0, sA1)
       // the first block fixes the reference point at its true row max (block blk0 always has a valid key);
       // O and l are still zero, so nothing is rescaled (exp2(-max) could overflow for very negative scores)
-      m_run = mx_cur;
+      m_run = mx0;
+      const float sh = pbias - m_run + CSH;
+      // ... and its two key tiles take their block exponents from their own (masked) values
+      float l0 = sA0[0], l1 = sA1[0];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { sA0[i] += pbias - m_run; sA1[i] += pbias - m_run; minit[i] = pbias - m_run; }
+      for (int i = 1; i < 16; ++i) { l0 = fmaxf(l0, sA0[i]); l1 = fmaxf(l1, sA1[i]); }
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(l0), __float_as_uint(l1), false, false);
+      const float lt = fmaxf(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])) + sh, 0.f);  // half 0: tile 0, half 1: tile 1
+      ecur = lt + CE;
+      auto e = __builtin_amdgcn_permlane32_swap(__float_as_uint(ecur), __float_as_uint(ecur), false, false);
+      sc0 = __uint_as_float((e[0] + (unsigned)CSH) << 23);
+      sc1 = __uint_as_float((e[1] + (unsigned)CSH) << 23);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sA0[i] += sh; sA1[i] += sh; minit[i] = sh; }
       asm volatile("" : "+v"(minit));
-      mx_cur = pbias;
     }
     __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
   }
@@ -437,7 +476,8 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
 #undef QK
 #undef QK_PRE
 #undef ROW_MAX
-#undef ROW_MAX_POS
+#undef TILE_EXP
+#undef CVT_SC
 #undef RAISE_REF
 #undef STEP
 #undef STAGE_DMA
@@ -449,7 +489,7 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
 
   if (!wave_active) return;
   // ---------------- epilogue ----------------
-  const float l_tot = lacc[0];  // every register holds the row's sum
+  const float l_tot = l_run;
   if (p.n_splits > 1) {
     // unnormalised partials: ws_o[y][sp][pos][d], ws_ml[y][sp][pos][2]
     if (row_ok) {
@@ -567,14 +607,16 @@ int fill_mx(const vorta_attn_args* a, const vorta_attn_fp8_ext* ext, ParamsMx& p
   if (pp.p.n_heads == 0 || pp.p.n_groups == 0) return VORTA_OK;
   if (a->variant == 1) return VORTA_EUNSUPPORTED;  // only the pipelined LDS-DMA body exists
   if (!ext->v_descale || ext->v_descale_stride_h < D) return VORTA_EINVAL;
+  // p_bias: P' = 2^(score - reference + p_bias) (any value: the block scales carry the range); defer: binades a key tile may lie
+  // above its row's reference point before the reference moves (fp32 accumulators: P' <= 2^(defer + 9))
   const float pb = ext->p_bias != 0.f ? ext->p_bias : 5.f;
-  const float df = ext->defer != 0.f ? ext->defer : 3.f;
-  if (!(pb >= 0.f) || !(df > 0.f) || pb + df > 8.f) return VORTA_EINVAL;  // P' <= 2^(p_bias+defer) must stay below 448
+  const float df = ext->defer != 0.f ? ext->defer : 24.f;
+  if (!(pb >= 0.f) || pb > 16.f || !(df >= 0.f) || df > 40.f) return VORTA_EINVAL;
   if (ext->flags & 1) return VORTA_EUNSUPPORTED;  // (the VALU row sum is an experiment of the all-e4m3 kernel)
   pp.v_descale = ext->v_descale;
   pp.v_descale_sh = ext->v_descale_stride_h;
   pp.p_bias = pb;
-  pp.thr = pb + df;
+  pp.etrig = df;
   return VORTA_OK;
 }
 
