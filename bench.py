@@ -308,9 +308,10 @@ def main():
                          "inside the step); i8pv: scores on the int8 MFMA with one scale per row (k converted inside the step, q "
                          "by the attention kernel), P V in e4m3")
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
-    ap.add_argument("--sp-groups", type=int, default=int(os.environ.get("VORTA_SP_GROUPS", "1")),
+    ap.add_argument("--sp-groups", default=os.environ.get("VORTA_SP_GROUPS", "auto"),
                     help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
-                         "overlaps the attention of another (1 = exchange, then attend; the measured default)")
+                         "overlaps the attention of another (1 = exchange, then attend); auto (default) = "
+                         "vorta_amd.ulysses.state.default_sp_groups: 1 at 3 heads per rank, 2-3 at 5, chosen on an emulated wire")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="on ONE GPU: the compute side of a P-way Ulysses step -- every layer as the rank that carries the "
                          "largest expert cost in THAT layer (a P-GPU step waits for its slowest rank layer by layer): its heads "
@@ -359,8 +360,12 @@ def main():
     if args.conservative:  # before vorta_amd.ulysses.engine reads the transport switch, and inherited by the child ranks
         args.placement, args.sp_groups, args.no_v_wire = "auto", 1, True  # (auto = even wherever even exists)
         os.environ["VORTA_SP_TRANSPORT"] = "a2a"
-    from vorta_amd.ulysses.state import resolve_placement  # the processors' rule (vorta_amd/attention/_sp.py)
+    from vorta_amd.ulysses.state import default_sp_groups, resolve_placement  # the processors' rules (vorta_amd/attention/_sp.py)
     args.placement = resolve_placement(args.placement, cfg["heads"], max(args.emulate_rank or args.gpus, 1))
+    if args.sp_groups == "auto":
+        prec = {"fp8": True, "fp8pv": "fp8pv", "i8pv": "i8pv"}.get(cfg["dtype"], False)
+        args.sp_groups = default_sp_groups(cfg["heads"] // max(args.emulate_rank or args.gpus, 1), prec)
+    args.sp_groups = max(1, int(args.sp_groups))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_rank:
         # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (never exec: nothing in this
         # process has touched the GPU yet, and nothing will), relay its output and exit with its code

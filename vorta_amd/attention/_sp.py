@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from ..routed import HeadRouting, geometry_for, routed_attention
 from ..ulysses import SP_STATE
-from ..ulysses.state import PLACEMENTS, resolve_placement  # noqa: F401  (one rule for the processors and bench.py)
+from ..ulysses.state import PLACEMENTS, default_sp_groups, resolve_placement  # noqa: F401  (one rule for the processors and bench.py)
 from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balanced_placement, exchange_and_attend, split_align, split_placement,
                               slot_groups)
 
@@ -21,7 +21,16 @@ _LAYOUTS = {}
 _BUFFERS = {}  # receive buffers per (geometry, head-slot count): kept when the layout cache is trimmed, least recently used out
 MAX_BUFFER_SETS = max(2, int(__import__("os").environ.get("VORTA_SP_BUFFER_SETS", "4")))
 _ROUTINGS = {}  # (local expert ids, device) -> HeadRouting: the device tables are built once per distinct local mix
-SP_GROUPS = max(1, int(__import__("os").environ.get("VORTA_SP_GROUPS", "1")))
+# slot groups: a number, or "auto" (default) = `default_sp_groups` of the heads per rank and the precision (ulysses/state.py)
+SP_GROUPS = __import__("os").environ.get("VORTA_SP_GROUPS", "auto")
+SP_GROUPS = SP_GROUPS if SP_GROUPS == "auto" else max(1, int(SP_GROUPS))
+
+
+def _sp_groups(H: int, P: int) -> int:
+    if SP_GROUPS != "auto":
+        return int(SP_GROUPS)
+    from .. import routed as _routed
+    return default_sp_groups(H // max(P, 1), _routed.DEFAULT_FP8)
 # fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
 # 16-bit exchange with the receive-side conversion (A/B; same bytes in the operand buffers either way)
 SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
@@ -113,10 +122,10 @@ def _routing(local_experts: tuple, device, q_ranges: tuple = ()) -> HeadRouting:
 def place_heads(experts, cost, P: int, S: int, dense_only: bool = False, placement: Optional[str] = None, groups: Optional[int] = None):
     """(placement taken, head order, heads per rank, query ranges or None) of one layer: VORTA_SP_PLACEMENT (default `auto`)
     resolved by `resolve_placement`, then the engine's placement of that name.
-    VORTA_SP_GROUPS > 1 (opt-in, to be measured on a multi-GPU node): the local heads travel in that many slot groups (as
+    VORTA_SP_GROUPS (default auto: `default_sp_groups`, chosen on an emulated wire): the local heads travel in that many slot groups (as
     equal as the slot count allows), so the exchange of one group overlaps the attention of another."""
     H = len(experts)
-    groups = SP_GROUPS if groups is None else groups
+    groups = _sp_groups(H, P) if groups is None else groups
     placement = resolve_placement(SP_PLACEMENT if placement is None else placement, H, P)
     parts = None
     if placement == "split" and H >= P and not dense_only:
@@ -170,7 +179,7 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     sp_attention.last_placement = placement  # (what a test or a curious caller reads back)
     lay, sb = _layout(H, S, T, D, q.device, q.dtype, counts, extra_slots=len(order) - H)
     bufs = sb.bufs
-    groups = min(SP_GROUPS, min(counts))
+    groups = min(_sp_groups(H, P), min(counts))
     geom = None if dense_only else geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
                                                 lowres_group_info.reduction_rate, q.device, row_map=lay.row_map)
     shards = [x[0, :, :Sl] for x in (q, k, v)]

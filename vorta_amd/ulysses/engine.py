@@ -35,6 +35,38 @@ TRANSPORT = __import__("os").environ.get("VORTA_SP_TRANSPORT", "a2a")
 HIP_STAGING = __import__("os").environ.get("VORTA_SP_STAGING", "hip") != "torch"
 # slot groups attend on alternating HIP streams (VORTA_SP_GROUP_STREAMS=0: all on the current stream, A/B)
 GROUP_STREAMS = __import__("os").environ.get("VORTA_SP_GROUP_STREAMS", "1") != "0"
+# One-GPU emulation of a rank (loopback) with a WIRE: every collective of the exchange holds a side stream for the time its
+# largest chunk needs at this many GB/s per xGMI link (+ 10 us), and `_finish` makes the consumer wait for it -- so the
+# emulation ranks 1 / 2 / 3 slot groups by what the overlap hides.  0 (default) = transfers are free, as in rounds 2-4.
+# An ASSUMPTION about the links, not a measurement of them (profiles/r05_sp_groups_emulated.txt).
+EMULATE_LINK_GBPS = float(__import__("os").environ.get("VORTA_SP_EMULATE_LINK_GBPS", "0") or 0)
+_WIRE = {}
+
+
+def _wire_sleep(device, nbytes_per_link: float):
+    """handle whose `_finish` waits until a transfer of `nbytes_per_link` over one link WOULD have ended: a spin kernel of that
+    duration on the wire stream (one thread: it takes no CU from the attention), ordered after the current stream"""
+    idx = torch.device(device).index or 0
+    w = _WIRE.get(idx)
+    if w is None:
+        st = torch.cuda.Stream(device=device)
+        # cycles of torch.cuda._sleep per microsecond, measured once
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(st):
+            e0.record(st)
+            torch.cuda._sleep(20_000_000)
+            e1.record(st)
+        e1.synchronize()
+        w = _WIRE[idx] = (st, 20_000_000 / (e0.elapsed_time(e1) * 1e3))
+    st, cyc_per_us = w
+    us = 10.0 + nbytes_per_link / (EMULATE_LINK_GBPS * 1e3)
+    st.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(st):
+        torch.cuda._sleep(int(us * cyc_per_us))
+        ev = torch.cuda.Event()
+        ev.record(st)
+    return ("event", ev)
 
 
 def group_sizes(Hl: int, groups: int) -> List[int]:
@@ -555,7 +587,12 @@ class UlyssesLayout:
         """Enqueue one group of point-to-point operations; returns a handle for `_finish`.
         p2p: list of ("send"|"recv", tensor, peer).  RCCL: asynchronous (the transfer runs on the communicator's
         stream, ordered after everything already enqueued on the current stream); gloo rehearsal: completes here."""
-        if not p2p or self.loopback:
+        if not p2p:
+            return None
+        if self.loopback:
+            if EMULATE_LINK_GBPS > 0 and self.device.type == "cuda":
+                sends = [t.numel() * t.element_size() for k, t, j in p2p if k == "send"]
+                return _wire_sleep(self.device, max(sends, default=0))
             return None
         if not self._staged():
             ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._peer(j), self.group) for k, t, j in p2p]
@@ -572,7 +609,9 @@ class UlyssesLayout:
     @staticmethod
     def _finish(handle):
         """Make the current stream wait for a group started by `_start` (no host synchronisation under RCCL)."""
-        if handle is not None:
+        if handle is not None and handle[0] == "event":  # (the emulated wire of a loopback rank)
+            torch.cuda.current_stream().wait_event(handle[1])
+        elif handle is not None:
             for r in handle[1]:
                 r.wait()
 
@@ -592,6 +631,13 @@ class UlyssesLayout:
                 no = list(out_rows) if out_rows is not None else [o.shape[0] // self.P] * self.P
                 i0, o0 = sum(ni[:me]), sum(no[:me])
                 o[o0:o0 + no[me]].copy_(i[i0:i0 + ni[me]])
+            if EMULATE_LINK_GBPS > 0 and self.device.type == "cuda" and self.P > 1:
+                # the pairs of one call follow each other on every link; a pair's largest chunk to another rank sets its time
+                per_link = 0.0
+                for i, o in pairs:
+                    rows = list(in_rows) if in_rows is not None else [i.shape[0] // self.P] * self.P
+                    per_link += max(r for j, r in enumerate(rows) if j != me) * i.shape[1] * i.element_size()
+                return _wire_sleep(self.device, per_link)
             return None
         kw = {} if in_rows is None else dict(input_split_sizes=list(in_rows), output_split_sizes=list(out_rows))
         if not self._staged():
@@ -729,7 +775,10 @@ class UlyssesLayout:
             if vwire is not None:  # converted while q and k are on the links
                 src, _, buf = convert_v()
                 hv = self._start_a2a([(src.view(self.Hv * Sl, self.D), buf[:P * blk])], *splits)
-                h = None if h is None and hv is None else ("works", (h[1] if h else []) + (hv[1] if hv else []))
+                if hv is not None and hv[0] == "event":  # (emulated wire: the second sleep follows the first on the wire stream)
+                    h = hv
+                else:
+                    h = None if h is None and hv is None else ("works", (h[1] if h else []) + (hv[1] if hv else []))
             return [h]
         if vwire is not None:
             srcs.append(convert_v())
