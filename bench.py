@@ -655,7 +655,7 @@ def main():
             roofline["library_gemm_tflops"] = None
             roofline["library_gemm_error"] = f"{type(exc).__name__}: {exc}"[:200]
     if world == 1 and not args.no_gemm_ceiling and not emu and proc_info is None:
-        borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved)
+        borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, layer_ids)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not emu and proc_info is None:
             res["cpu_baseline"] = cpu_baseline(cfg, layer_ids)
@@ -664,7 +664,7 @@ def main():
         dist.destroy_process_group()
 
 
-def borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, budget_s: float = 20.0):
+def borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, layer_ids=None, budget_s: float = 45.0):
     """Context beside `library_gemm_tflops`, measured after the timed region and never part of `value`: the kernel the
     REFERENCE borrows for its dense expert on this box -- torch.nn.functional.scaled_dot_product_attention, the call at
     /root/reference/vorta/attention/hunyuan.py:169-176 (wan.py:142-145) -- on a sample of 8 heads x (S + T_eff)^2 in 16 bits,
@@ -711,9 +711,77 @@ def borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, budget_s: flo
         res["config"]["borrowed_dense_note"] = ("all-full mix (--native_attention) extrapolated from the sample: ms per head x "
                                                 f"{H} heads x {L} layers x {fwd} forwards; SDPA = the kernel the reference calls "
                                                 "(hunyuan.py:169-176), torch-ROCm build on this box")
+        if layer_ids is not None and time.perf_counter() - t_start < budget_s:
+            borrowed_routed(cfg, S, te, L, layer_ids, q, k, v, ms_sdpa, timed, res, budget_s - (time.perf_counter() - t_start))
     except Exception as exc:  # context only: never let it cost the bench line
         roofline["library_sdpa_tflops"] = None
         roofline["library_sdpa_error"] = f"{type(exc).__name__}: {exc}"[:200]
+
+
+def window_tile_matrix(latent, tile, window, dev):
+    """(n_tiles, n_tiles) bool: may a query tile see a key tile?  Tiles in raster order over the tile grid; per dimension the
+    window centre is the query tile's coordinate clamped so that the window stays inside the grid (SURVEY.md section 8 A8;
+    tests/test_bench_host.py compares it with the oracle's table).  Used only by the borrowed-kernel context measurement."""
+    n = [l // t for l, t in zip(latent, tile)]
+    idx = torch.arange(n[0] * n[1] * n[2], device=dev)
+    co = [idx // (n[1] * n[2]), (idx // n[2]) % n[1], idx % n[2]]
+    ok = torch.ones((idx.numel(), idx.numel()), dtype=torch.bool, device=dev)
+    for d in range(3):
+        half = window[d] // 2
+        c = co[d].clamp(min=half, max=max(n[d] - 1 - half, half))
+        ok &= (co[d][None, :] - c[:, None]).abs() <= half
+    return ok
+
+
+def borrowed_routed(cfg, S, te, L, layer_ids, q, k, v, ms_full, timed, res, budget_s):
+    """The other two library kernels the reference's routed path borrows, on the sample tensors of `borrowed_dense`: SDPA on the
+    coreset expert's pooled sequence (hunyuan.py:441-448) and torch's COMPILED flex_attention under the sliding-tile block mask
+    (sliding_attn_flex.py:137-211; mask restated from SURVEY.md section 8 A8: tile-major order, clamped window, text rules).
+    `step_ms_if_borrowed_routed` = this run's head -> expert assignment through those three kernels, per-head times x head
+    counts; the reference's torch-side pooling / tiling / combine passes are NOT included: a lower bound of its step on this
+    box.  Context only (torch-ROCm is not the reference); tools/bench_borrowed_routed.py is the stand-alone form."""
+    try:
+        import torch.nn.functional as F
+        from torch.nn.attention.flex_attention import create_block_mask, flex_attention
+        dev, hs = q.device, q.shape[1]
+        g = cfg["group"][0] * cfg["group"][1] * cfg["group"][2]
+        n_low = (S // g) * (1 + int(g * (1 - cfg["rate"])) - 1) + te
+        ms_low = timed(lambda: F.scaled_dot_product_attention(q[:, :, :n_low], k[:, :, :n_low], v[:, :, :n_low]), hs, 2)
+        tok = cfg["tile"][0] * cfg["tile"][1] * cfg["tile"][2]
+        tiles = window_tile_matrix(cfg["latent"], cfg["tile"], cfg["window"], dev)
+        T = cfg["text"]
+
+        def mask_mod(b, h, qi, ki):
+            vq, vk = qi < S, ki < S
+            video = vq & vk & tiles[torch.where(vq, qi // tok, 0), torch.where(vk, ki // tok, 0)]
+            return video | (vq & (ki >= S) & (ki < S + te)) | ((qi >= S) & (qi < S + te) & (ki < S + te))
+
+        N = S + T
+        if q.shape[2] < N:  # (the dense sample holds S + T_eff rows)
+            pad = lambda x: torch.cat([x, torch.zeros((1, hs, N - x.shape[2], 128), device=dev, dtype=x.dtype)], 2)
+            q, k, v = pad(q), pad(k), pad(v)
+        t0 = time.perf_counter()
+        bm = torch.compile(create_block_mask)(mask_mod, None, None, N, N, device=dev)
+        flex = torch.compile(flex_attention, dynamic=False)
+        flex(q, k, v, block_mask=bm)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        if first > budget_s:
+            raise TimeoutError(f"first compiled flex_attention call took {first:.0f} s")
+        ms_sl = timed(lambda: flex(q, k, v, block_mask=bm), hs, 2)
+        cnt = [sum(int((ids == e).sum()) for ids in layer_ids) for e in range(3)]
+        fwd = cfg["fwd_per_step"]
+        c = res["config"]
+        c["step_ms_if_borrowed_routed"] = round((cnt[0] * ms_full + cnt[1] * ms_low + cnt[2] * ms_sl) * fwd, 1)
+        c["borrowed_routed_over_own_step"] = round(c["step_ms_if_borrowed_routed"] / res["ms_per_step"], 3)
+        c["borrowed_routed_ms_per_head"] = {"full_sdpa": round(ms_full, 3), "coreset_sdpa": round(ms_low, 3),
+                                            "sliding_flex": round(ms_sl, 3), "flex_first_call_s": round(first, 1)}
+        c["borrowed_routed_note"] = ("this run's routes through the library kernels the reference calls (SDPA full + SDPA on the pooled "
+                                     "sequence + compiled flex_attention under the tile block mask), per-head times x head counts over "
+                                     f"{L} layers x {fwd} forwards; its torch-side pooling / tiling / combine passes left out: a lower bound")
+    except Exception as exc:  # context only
+        res["config"]["step_ms_if_borrowed_routed"] = None
+        res["config"]["borrowed_routed_error"] = f"{type(exc).__name__}: {exc}"[:200]
 
 
 def guarded():

@@ -29,6 +29,9 @@ def test_bench_single_gpu_line():
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and j["vs_baseline"] is None
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(j["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(j["cpu_baseline"]) and "workload" in j["config"]
+    # the library kernels the reference borrows, beside ours (context fields; an error is named, never raised)
+    assert "library_sdpa_tflops" in j["roofline"] and "step_ms_if_borrowed_routed" in j["config"], j["config"]
+    assert j["config"]["step_ms_if_borrowed_routed"] is None or j["config"]["step_ms_if_borrowed_routed"] > 0
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp8"])

@@ -202,3 +202,15 @@ def test_torch_custom_ops_are_registered_with_shape_functions():
         e, lists, counts = torch.ops.vorta.route_scores(torch.empty((1, 6, 3), device="cuda"), 0.3)
         assert e.shape == (6,) and lists.shape == (3, 6) and counts.shape == (3,)
         assert torch.ops.vorta.attn_fwd(x, x, x, torch.empty_like(x), 10, 10) is None
+
+
+def test_bench_window_tile_matrix_is_the_oracles_table():
+    """bench.py restates the clamped tile window for its borrowed-kernel context measurement (compiled flex_attention
+    under that mask); the restatement has to be the mask the oracle pins against the reference's (G3)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    for lat, tile, win in [((33, 45, 80), (11, 9, 8), (3, 3, 3)), ((21, 45, 80), (7, 9, 8), (3, 3, 3)), ((8, 6, 8), (2, 3, 4), (3, 3, 3)),
+                           ((30, 45, 80), (6, 9, 8), (3, 3, 3)), ((4, 6, 4), (2, 3, 2), (3, 3, 3)), ((21, 30, 52), (7, 6, 4), (3, 3, 1))]:
+        got = bench.window_tile_matrix(lat, tile, win, "cpu").numpy()
+        assert np.array_equal(got, O.sta_window_tiles(lat, tile, win)), (lat, tile, win)
