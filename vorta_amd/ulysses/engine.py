@@ -40,6 +40,10 @@ GROUP_STREAMS = __import__("os").environ.get("VORTA_SP_GROUP_STREAMS", "1") != "
 # emulation ranks 1 / 2 / 3 slot groups by what the overlap hides.  0 (default) = transfers are free, as in rounds 2-4.
 # An ASSUMPTION about the links, not a measurement of them (profiles/r05_sp_groups_emulated.txt).
 EMULATE_LINK_GBPS = float(__import__("os").environ.get("VORTA_SP_EMULATE_LINK_GBPS", "0") or 0)
+# Rehearsal on a world of ONE rank (tests/test_hip_rccl_single_rank.py): issue the collectives of the whole-tensor exchange --
+# all_to_all_single with one chunk, the all-reduces, the text all-gather -- although there is no peer, so that the direct RCCL
+# branch runs on the one-GPU box (RCCL refuses two ranks on one device).  Off in every product run.
+FORCE_COLLECTIVES = __import__("os").environ.get("VORTA_SP_FORCE_COLLECTIVES", "0") == "1"
 _WIRE = {}
 
 
@@ -407,7 +411,7 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
     if T and not torch.equal(out_text, texts[0]):
         failed.append("gathered text rows")
     ok = torch.tensor([0 if failed else 1], dtype=torch.int32, device=dev)
-    if P > 1 and not lay.loopback:
+    if (P > 1 or FORCE_COLLECTIVES) and not lay.loopback:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=lay.group)
     esz = torch.empty((), dtype=dt).element_size()
     away = (lay.Hv - Hl) * Sl * D  # elements of one tensor this rank sends to its peers
@@ -651,7 +655,7 @@ class UlyssesLayout:
 
     def _start_allreduce_max(self, x: torch.Tensor):
         """MAX all-reduce of a small float tensor over the sequence-parallel group; handle for `_finish`"""
-        if self.loopback or self.P == 1:
+        if self.loopback or (self.P == 1 and not FORCE_COLLECTIVES):
             return None
         if not self._staged():
             return ("works", [dist.all_reduce(x, op=dist.ReduceOp.MAX, group=self.group, async_op=True)])
@@ -767,7 +771,7 @@ class UlyssesLayout:
             return (vwire.stage, list(starts[:P]), vwire.buf)
 
         in_rank_order = all(first == list(starts[:P]) for _, first, _ in srcs)
-        if TRANSPORT == "a2a" and groups == [(0, Hl)] and in_rank_order and P > 1:
+        if TRANSPORT == "a2a" and groups == [(0, Hl)] and in_rank_order and (P > 1 or FORCE_COLLECTIVES):
             # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides (rows per
             # chunk follow the ranks' head counts on the send side; every peer sends this rank's Hl heads)
             splits = (None, None) if self.even else ([c * Sl for c in counts], [blk] * P)
@@ -859,7 +863,7 @@ class UlyssesLayout:
         blk = Hl * Sl
         g0, g1 = (0, Hl) if slots is None else slots
         dst, first = state["dst"], state["first"]
-        if TRANSPORT == "a2a" and (g0, g1) == (0, Hl) and first == list(self.starts[:P]) and P > 1:
+        if TRANSPORT == "a2a" and (g0, g1) == (0, Hl) and first == list(self.starts[:P]) and (P > 1 or FORCE_COLLECTIVES):
             splits = (None, None) if self.even else ([blk] * P, [c * Sl for c in self.counts])
             return self._start_a2a([(buf[:P * blk], dst.view(self.Hv * Sl, self.D))], *splits)
         dst[first[me] + g0:first[me] + g1].copy_(buf[me * blk + g0 * Sl:me * blk + g1 * Sl].view(g1 - g0, Sl, self.D))
@@ -899,11 +903,11 @@ class UlyssesLayout:
             parts = [torch.empty_like(local) for _ in range(self.P)]
             if self.loopback:
                 parts = [local] * self.P
-            elif self.P > 1 and self._staged():
+            elif (self.P > 1 or FORCE_COLLECTIVES) and self._staged():
                 hp = [torch.empty(local.shape, dtype=local.dtype) for _ in range(self.P)]
                 dist.all_gather(hp, local.cpu(), group=self.group)
                 parts = [h.to(local.device) for h in hp]
-            elif self.P > 1:
+            elif self.P > 1 or FORCE_COLLECTIVES:
                 dist.all_gather(parts, local, group=self.group)
             else:
                 parts = [local]
