@@ -323,6 +323,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   f32x16 y0, y1;          // byte-domain scores (minus 8 e) of one key block (keys 0-31, 32-63 of the block)
   i32x16 n0, n1;          // raw accumulators of the block after it (written by the matrix part)
   float off8 = 0.f;       // ybias - m_run8 - MAGIC_F * m8: the addend of the conversion
+  float offp0 = 0.f, offp1 = 0.f;  // the two tiles' conversion offsets of the block whose scores are in n0, n1
   float ecur = EBIAS;     // biased block exponent of key tile hh (the one whose scale this lane supplies) for the block in y0, y1
 
   // the seed of a key = rint(bias / sq) as the integer the accumulator starts from, 0x4B400000 + seed: ONE multiply-add -- in the
@@ -371,8 +372,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   // signed-integer max over each key tile's 16 registers (v_max3_i32), ONE half exchange that leaves tile 0's row max in the
   // lanes of half 0 and tile 1's in half 1 -- where the MFMA reads the two scales -- one multiply-add to the byte domain, one
   // to the biased exponent; a second exchange hands every lane both exponents for the offsets of its conversions.
-#define TILE_EXP(eh_, off0_, off1_, a_, b_)                                       \
-  {                                                                               \
+#define TILE_MAXES(a_, b_)                                                        \
     int m0_ = max(max(a_[0], a_[1]), a_[2]);                                      \
     int m1_ = max(max(b_[0], b_[1]), b_[2]);                                      \
     _Pragma("unroll") for (int i_ = 3; i_ < 15; i_ += 2) {                        \
@@ -380,7 +380,10 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
       m1_ = max(max(m1_, b_[i_]), b_[i_ + 1]);                                    \
     }                                                                             \
     m0_ = max(m0_, a_[15]);                                                       \
-    m1_ = max(m1_, b_[15]);                                                       \
+    m1_ = max(m1_, b_[15]);
+#define TILE_EXP(eh_, off0_, off1_, a_, b_)                                       \
+  {                                                                               \
+    TILE_MAXES(a_, b_)                                                            \
     auto r_ = __builtin_amdgcn_permlane32_swap((unsigned)m0_, (unsigned)m1_, false, false); \
     const int mt_ = max((int)r_[0], (int)r_[1]); /* half 0: tile 0 over both halves' keys; half 1: tile 1 */ \
     const float ymx_ = __builtin_fmaf(__int_as_float(mt_), m8, off8);             \
@@ -441,18 +444,19 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   // next rows): back to back at the top of the step they cost the wave ~100 cycles each -- every wave of the workgroup
   // asks at the same moment and the address unit takes 16 pieces per step, 16 cycles apiece -- with VALU work between
   // them the queue has drained when the next one comes (tools/trace_i8.py: 176-208 cycles per step for the requests).
+#define VALU_FMA()                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, offp0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, offp1);
 #define VALU_PART(bs_, ss_, qa_, qb_, qc_)                                        \
   {                                                                               \
     const float sb_ = *(const float*)(smem + bias_rd + (bs_) * SC_BYTES);         \
     qa_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
-    float off0_, off1_;                                                           \
-    TILE_EXP(ecur, off0_, off1_, n0, n1)                                          \
+    TILE_EXP(ecur, offp0, offp1, n0, n1)                                          \
     __builtin_amdgcn_sched_barrier(0);                                            \
     qb_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, off0_); \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, off1_); \
+    VALU_FMA()                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                            \
     qc_                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                            \
@@ -471,33 +475,27 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   // that produce / consume them where the recipe's greedy pick would not
 #define TIE_(a_, b_) asm("" : "+v"(a_), "+v"(b_));
 #if VORTA_I8_SCHED == 1
-  // Issue-order recipe of the PV half of the matrix part (sched_group_barrier: 0x008 MFMA, 0x100 DS read): the reads of V
-  // channel tiles 0, 1, then 5 MFMAs -- the row-sum MFMA FIRST: it needs no fragment and covers 64 cycles of the tiles'
-  // round trip -- with the later reads under the earlier ones: V tiles 2, 3, the seeds and the K fragments of key tile 0,
-  // so that the score half starts with its operands in registers.
+  // Issue-order recipe of the PV half of the matrix part (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x002 VALU): the
+  // reads of V channel tiles 0, 1, then 5 MFMAs -- the row-sum MFMA FIRST: it needs no fragment and covers 64 cycles of the
+  // tiles' round trip -- with the later reads under the earlier ones: V tiles 2, 3, the seeds and the K fragments of key tile
+  // 0, so that the score half starts with its operands in registers; and under each of the first four MFMAs eight of the 32
+  // byte conversions of block j (round 5: they sat under the score MFMAs, four per 32-cycle gap, where the partner wave's VALU
+  // part found the SIMD's vector issue three quarters taken; under the 64-cycle P V MFMAs they take a third of it, and the
+  // score half leaves the issue to the partner: +2 %, profiles/r05_i8_loop_experiments.txt 9; with the multiply-adds here as
+  // well the P V half outgrows its MFMAs: -2 ... -3.5 %)
 #define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
 #define SCHED_M()                                                                 \
   SG_(0x100, 8)                                                                   \
-  SG_(0x008, 1) SG_(0x100, 4)                                                     \
-  SG_(0x008, 1) SG_(0x100, 4)                                                     \
-  SG_(0x008, 1) SG_(0x100, 4)                                                     \
-  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
   SG_(0x008, 1)
   // score half (a basic block of its own behind the rare branches): the eight reads of key tile 1 under the four MFMAs of
-  // tile 0 (whose operands are in registers: the wave goes from the branch straight into an MFMA), then tile 1; per MFMA
-  // four of the 32 byte conversions of block j (the 24 issue cycles a 32-cycle MFMA leaves: the VALU part is that much
-  // shorter)
-#ifndef VORTA_I8_SCHED_S
-#define VORTA_I8_SCHED_S 1
-#endif
-#if VORTA_I8_SCHED_S == 1
+  // tile 0 (whose operands are in registers: the wave goes from the branch straight into an MFMA), then tile 1
 #define SCHED_S()                                                                 \
-  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) \
-  SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) SG_(0x008, 1) SG_(0x100, 2) SG_(0x002, 4) \
-  SG_(0x008, 1) SG_(0x002, 4) SG_(0x008, 1) SG_(0x002, 4) SG_(0x008, 1) SG_(0x002, 4) SG_(0x008, 1) SG_(0x002, 4)
-#else
-#define SCHED_S() SG_(0x100, 8) SG_(0x008, 8)
-#endif
+  SG_(0x008, 1) SG_(0x100, 2) SG_(0x008, 1) SG_(0x100, 2) SG_(0x008, 1) SG_(0x100, 2) SG_(0x008, 1) SG_(0x100, 2) \
+  SG_(0x008, 4)
 #else
 #define SCHED_M()
 #define SCHED_S()
@@ -544,13 +542,13 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   {                                                                               \
     PRIO_HI()                                                                     \
     i32x4 kfa_[4], kfb_[4];                                                       \
-    PV_PART(vr_, pbr_, scr_, SEEDS_IN(n0, sr_, 0) KFRAGS(kfa_, kr_, 0))           \
+    PV_PART(vr_, pbr_, scr_, PACK_Y(pbw_) SEEDS_IN(n0, sr_, 0) KFRAGS(kfa_, kr_, 0)) /* + the bytes of block j */ \
     SCHED_M()                                                                     \
     /* the five MFMAs stay one run AHEAD of the rare branches: left alone, the compiler sinks one that nothing orders below the */ \
     /* tail-mask branch, out of the issue recipe (an empty statement: no instruction, no wait)                              */ \
-    asm volatile("" : "+v"(lt_), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])); \
-    /* last, partial key block: mask its tail (once per workgroup; the exponents were taken over the clamped rows too) */ \
-    if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(jabs_) }                          \
+    asm volatile("" : "+v"(lt_), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(pbw_)); \
+    /* last, partial key block: mask its tail and convert again (once per workgroup; the exponents were taken over the clamped rows too) */ \
+    if ((jabs_) * KVB + KVB > n_kv) { MASK_TAIL(jabs_) PACK_Y(pbw_) }             \
     /* the reference point moves only when some tile lies more than `etrig` binades above it; O and the row sums */ \
     /* follow AFTER block j-1 went in at the old reference                                                              */ \
     if (!__all(ecur <= etrig_b)) { RAISE_REF() }                                  \
@@ -560,8 +558,6 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     QK_TILE(n0, kfa_)                                                             \
     TIE_(n0, n1) /* tile 0 (operands in registers) before tile 1 (operands in flight) */ \
     QK_TILE(n1, kfb_)                                                             \
-    PACK_Y(pbw_) /* the bytes of block j: four conversions per MFMA gap */        \
-    TIE_(n1, pbw_) /* (keeps the conversions in this block: nothing reads them before the next step) */ \
     SCHED_S()                                                                     \
     l_run += lt_[0]; /* (the row-sum MFMA finished long ago) */                   \
     PRIO_LO()                                                                     \
