@@ -7,9 +7,9 @@
 // scores are where the mantissa is needed; P (in [0, 1] after the row max) and V (scaled per channel) tolerate e4m3:
 // 16-bit q k^T with e4m3 P, V holds 42-69 dB on every input family.
 //
-// Structure: the pipelined 16-bit kernel (attn_fwd.hip: attn_pipe_dma_body) up to the probabilities -- K tile in 16 bits,
-// XOR-swizzled, LDS-DMA staged, scores one key block ahead, softmax folded into the score MFMA's seed -- and the e4m3
-// kernel (attn_fwd_fp8.hip) from there: the accumulator starts from p_bias - m_run, P' = exp2(acc) = P 2^p_bias is packed
+// Structure: the 16-bit kernel's operands (attn_fwd.hip: K tile in 16 bits, XOR-swizzled, LDS-DMA staged, softmax folded into the
+// score MFMA's seed) in the e4m3 kernel's step (attn_fwd_fp8.hip: the two waves of a SIMD alternate between a matrix part and a
+// VALU part -- round 5; until then one dataflow per wave, as attn_fwd.hip) and the e4m3 kernel from the probabilities on: the accumulator starts from p_bias - m_run, P' = exp2(acc) = P 2^p_bias is packed
 // to e4m3 straight from the accumulator registers (a lane owns one query and 32 of the block's 64 keys = the B operand of
 // ONE K = 64 MFMA), O^T += V8^T P'^T on v_mfma_f32_32x32x64_f8f6f4 with the V tile (rows of 128 bytes) read through
 // ds_read_b64_tr_b8, row sums from one more MFMA against a tile of ones, v_descale in the epilogue.  Per wave and 64-key
@@ -55,8 +55,8 @@ __device__ __forceinline__ f32x16 mfma8(i32x8 a, i32x8 b, f32x16 c, int sb) {
 
 template <typename T, int NW, bool KVTAB, int NS>
 __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restrict__ smem, const int wg) {
-  // NS = depth of the K ring (16 KiB tiles, 16-bit rows) and of the V ring (8 KiB tiles, e4m3 rows): K(j+NS) / V(j+NS-1)
-  // are requested at the top of step j, NS-1 steps before the step that reads them
+  // NS = depth of the K ring (16 KiB tiles, 16-bit rows) and of the V ring (8 KiB tiles, e4m3 rows): K(j+2) / V(j) are requested at
+  // the top of step j, one step before the step that reads them
   static_assert(NS == 2, "ring depth");
   const Params& p = pp.p;
   constexpr int VBASE = NS * TILE_BYTES;  // the V ring sits behind the K ring
@@ -268,31 +268,17 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
     s0_ = __uint_as_float((e_[0] + (unsigned)CSH) << 23);                         \
     s1_ = __uint_as_float((e_[1] + (unsigned)CSH) << 23);                         \
   }
-  // the same with the fragments of the first KPRE k-steps already in registers (read at the top of the step,
-  // their LDS latency hides under the row-max phase)
-#define QK_PRE(d0_, d1_, par_)                                                    \
-  {                                                                               \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
-      V8 k0_, k1_;                                                                \
-      if (ks_ < KPRE) { k0_ = kpre_[ks_][0]; k1_ = kpre_[ks_][1]; }               \
-      else {                                                                      \
-        k0_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_]);               \
-        k1_ = *(const V8*)(smem + (par_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB);   \
-      }                                                                           \
-      d0_ = MF<T>::mfma(k0_, qf[ks_], ks_ == 0 ? minit : d0_);                    \
-      d1_ = MF<T>::mfma(k1_, qf[ks_], ks_ == 0 ? minit : d1_);                    \
-    }                                                                             \
-  }
   // move the reference point of the row up by g_ (>= 0): everything accumulated so far and the current block's
   // offset scores are brought to the new reference, and the accumulator seed follows.  The empty asm keeps the
   // seed an opaque 16-register value (otherwise the compiler re-materialises the splat before every use).
+#define RAISE_L_(a_) l_run = (l_run + lt_[0]) * (a_); lt_[0] = 0.f; /* block j-1 went in at the old reference */
 #define RAISE_REF(c0_, c1_)                                                       \
   {                                                                               \
     const float g_ = fmaxf(half_max(ecur) - EBIAS, 0.f); /* whole binades: the larger of the row's two tile exponents */ \
     const float alpha_ = __builtin_amdgcn_exp2f(-g_);                             \
     _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_)                           \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) o[dt_][i_] *= alpha_;     \
-    l_run *= alpha_;                                                              \
+    RAISE_L_(alpha_)                                                              \
     m_run += g_;                                                                  \
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) { c0_[i_] -= g_; c1_[i_] -= g_; minit[i_] = pbias - m_run + CSH; } \
     asm volatile("" : "+v"(minit));                                               \
@@ -301,124 +287,132 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
     sc0 = __uint_as_float((e2_[0] + (unsigned)CSH) << 23);                        \
     sc1 = __uint_as_float((e2_[1] + (unsigned)CSH) << 23);                        \
   }
-  // top of step j: K(j+NS) -> the slot K(j) left, V(j+NS-1) -> the slot V(j-1) left.  They are read in step
-  // j+NS-1, so the barrier that ends step j only waits for the requests of step j-NS+2 and older: with NS = 3
-  // the 2*CH requests of the current step stay in flight across it (two steps of latency cover, one with NS = 2)
+  // end of a step: the wave's requests have landed, then the workgroup barrier (which also orders every wave's LDS reads of this
+  // step before the next step's overwrites)
+#define STEP_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  // WAVE ROLES (round 5; the e4m3 / int8-score kernels' step, attn_fwd_fp8.hip): the two waves of a SIMD take turns between a
+  // MATRIX part -- O += V^T P^T and the row sums of block j-1 (5 MFMAs of 64 cycles), then the scores of block j+1 (16 MFMAs of
+  // 32) -- and a VALU part -- exp2 + conversion of a block, the block exponents of the next.  One dataflow per wave (rounds 3-5:
+  // the 16-bit kernel's step) had both waves of a SIMD issue-bound in the score phase together and pipe-bound in the P V phase
+  // together: 61 % busy pipes at 1.98 GHz, a third of the wave cycles at a wait; roles: 67.6 % at 1.87 GHz, +4.5 %, the same bits
+  // (tools/measure/r5_pmc_8bit.sh, profiles/r05_fp8pv_roles.txt).
+  //   step j, waves < NW/2 :   matrix(j)  then  valu(convert block j; exponents of block j+1)
+  //   step j, waves >= NW/2:   valu(convert block j-1; exponents of block j)  then  matrix(j)
+  //   matrix(j) = PV(j-1) + row sums, [mask the tail of block j], [move the reference point for block j], QK(j+1)
+  // Requests of step j (top of the step): K(j+2) -> the slot K(j) left, V(j) -> the slot V(j-2) left (P V lags the scores by two
+  // blocks), rings of two.
 #define STAGE_DMA(kfree_, vfree_, j_)                                             \
   DMA_K(kfree_)                                                                   \
   DMA_V(vfree_)                                                                   \
-  ROWS_OF_V(rowV, (j_) + NS)                                                      \
-  ROWS_OF(rowK, (j_) + NS + 1)                                                    \
+  ROWS_OF_V(rowV, (j_) + 1)                                                       \
+  ROWS_OF(rowK, (j_) + 3)                                                         \
   __builtin_amdgcn_sched_barrier(0);
-  // end of a step: own DMA requests older than the current step have landed, then the workgroup barrier (which
-  // also orders every wave's LDS reads of this step before the next step's overwrites)
-#define STEP_SYNC()                                                               \
-  {                                                                               \
-    if constexpr (NS == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-    else if constexpr (CH == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+  int sbp = SC_ONE;  // scale bytes (this lane's key tile) of the block whose bytes are in pb_
+#define VFRAG(dt_, slot_)                                                         \
+  _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                              \
+    const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                      \
+        (LDS_AS i32x2*)(smem + (slot_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8));   \
+    vf_[dt_][2 * n_] = t_[0]; vf_[dt_][2 * n_ + 1] = t_[1];                       \
   }
-
-  // Issue-order recipe for the step's basic block (sched_group_barrier: 0x008 MFMA, 0x100 DS read, 0x400 transcendental,
-  // 0x002 VALU).  Score phase: per MFMA one K-fragment read, two exp, two plain VALU (the converts and half of the row
-  // sum); PV phase: per MFMA the two transposed V reads and four VALU (the rest of the row sum, the next block's row
-  // max).  The score phase is the issue-bound one (exp costs two slots), so everything that can wait moves under the PV
-  // MFMAs.  With the post-RA scheduler off (build.py) the recipe is what the hardware sees: +3.5 % on the dense launch
-  // and +4 % on the fused layer kernel against no recipe; a dozen other groupings measured between -3 % and +2 %.
-  // -DVORTA_MX_SCHED=0 disables it.
-#ifndef VORTA_MX_SCHED
-#define VORTA_MX_SCHED 1
-#endif
-#ifndef VORTA_MX_SC_VALU
-#define VORTA_MX_SC_VALU 2
-#endif
-#ifndef VORTA_MX_PV_VALU
-#define VORTA_MX_PV_VALU 5
-#endif
-#if VORTA_MX_SCHED == 1
-#define SCHED_RECIPE()                                                            \
-  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, VORTA_MX_SC_VALU, 0);             \
-  }                                                                               \
-  _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, VORTA_MX_PV_VALU, 0);             \
-  }                                                                               \
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#else
-#define SCHED_RECIPE()
-#endif
-  // one key block.  The active path is ONE basic block after the (rare) mask / rescale branches: the MFMAs of
-  // the next block's scores, the exp/convert VALU work of this block, the staging traffic and the PV MFMAs are
-  // all visible to the scheduler together.
-#define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, vfree_, j_)                       \
-  { /* kcur_ = j % NS: slot of K(j) (free) and of V(j); knext_ = (j+1) % NS; vfree_ = (j-1) % NS */ \
-    STAGE_DMA(kcur_, vfree_, j_)                                                  \
-    if (wave_active) {                                                            \
-      V8 kpre_[KPRE > 0 ? KPRE : 1][2];                                                          \
-      _Pragma("unroll") for (int ks_ = 0; ks_ < KPRE; ++ks_) {                    \
-        kpre_[ks_][0] = *(const V8*)(smem + (knext_) * TILE_BYTES + k_rd[ks_]);   \
-        kpre_[ks_][1] = *(const V8*)(smem + (knext_) * TILE_BYTES + k_rd[ks_] + 32 * ROWB); \
-      }                                                                           \
-      /* mx_cur (row max of this block's scores) was computed under the previous step's PV MFMAs; only the */ \
-      /* last, partial key block has to mask its tail and redo it here                                      */ \
-      if ((j_) * KVB + KVB > n_kv) {                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                       \
-          const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                     \
-          if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                     \
-          if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                \
-        }                                                                         \
-      }                                                                           \
-      /* the reference point moves only when some key tile lies more than `etrig` binades above it (the exponents were */ \
-      /* taken over the clamped rows of a partial block too)                                                          */ \
-      if (!__all(ecur <= etrig_b)) { RAISE_REF(c0_, c1_) }                        \
-      const int sb_ = __float_as_int(ecur); /* its low byte: the E8M0 scale 127 + e of this lane's key tile */ \
-      const float cs0_ = sc0, cs1_ = sc1;                                         \
-      QK_PRE(n0_, n1_, knext_) /* block j+1 (harmless garbage past the end) */    \
+#define KF_(ks_, t_, slot_) (*(const V8*)(smem + (slot_) * TILE_BYTES + k_rd[ks_] + (t_) * 32 * ROWB))
+#define PV_PART(vslot_, mid_)                                                     \
+  i32x8 vf_[4];                                                                   \
+  VFRAG(0, vslot_) VFRAG(1, vslot_) VFRAG(2, vslot_) VFRAG(3, vslot_)             \
+  f32x16 lt_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                   \
+      ones, pb_, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 4, 0, 0, SC_ONE, 0, sbp); \
+  asm("" : "+v"(lt_), "+v"(vf_[0])); /* the row-sum MFMA before the first that needs a fragment */ \
+  mid_                                                                            \
+  o[0] = mfma8(vf_[0], pb_, o[0], sbp);                                           \
+  o[1] = mfma8(vf_[1], pb_, o[1], sbp);                                           \
+  o[2] = mfma8(vf_[2], pb_, o[2], sbp);                                           \
+  o[3] = mfma8(vf_[3], pb_, o[3], sbp);
+#define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
+  // P V half: the reads of V channel tiles 0, 1, then 5 MFMAs (the row sum first) with the later reads under the earlier ones:
+  // V tiles 2, 3 and the first two k-steps of the next K block
+#define SCHED_M()                                                                 \
+  SG_(0x100, 8)                                                                   \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 4)                                                     \
+  SG_(0x008, 1) SG_(0x100, 2)                                                     \
+  SG_(0x008, 1) SG_(0x100, 2)                                                     \
+  SG_(0x008, 1)
+  // score half: per MFMA one fragment read, two k-steps ahead
+#define SCHED_S()                                                                 \
+  _Pragma("unroll") for (int g_ = 0; g_ < 12; ++g_) { SG_(0x008, 1) SG_(0x100, 1) } \
+  SG_(0x008, 4)
+#define VALU_PART(e0_, e1_, m0_, m1_)                                             \
+  {                                                                               \
+    sbp = __float_as_int(ecur); /* its low byte: the E8M0 scale 127 + e of this lane's key tile */ \
+    const float cs0_ = sc0, cs1_ = sc1;                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+      e0_[i_] = __builtin_amdgcn_exp2f(e0_[i_]);                                  \
+      e1_[i_] = __builtin_amdgcn_exp2f(e1_[i_]);                                  \
+    }                                                                             \
+    _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                            \
+      pb_[w_] = CVT_SC(pb_[w_], e0_[4 * w_], e0_[4 * w_ + 1], cs0_, false);        \
+      pb_[w_] = CVT_SC(pb_[w_], e0_[4 * w_ + 2], e0_[4 * w_ + 3], cs0_, true);     \
+      pb_[4 + w_] = CVT_SC(pb_[4 + w_], e1_[4 * w_], e1_[4 * w_ + 1], cs1_, false); \
+      pb_[4 + w_] = CVT_SC(pb_[4 + w_], e1_[4 * w_ + 2], e1_[4 * w_ + 3], cs1_, true); \
+    }                                                                             \
+    TILE_EXP(ecur, sc0, sc1, m0_, m1_)                                            \
+  }
+  // (the matrix part at a raised priority: without it the roles gain nothing -- 37.7 against 35.9 ms; levels 1, 2, 3 equal)
+#define MX_PRIO_HI() __builtin_amdgcn_s_setprio(2);
+#define MX_PRIO_LO() __builtin_amdgcn_s_setprio(0);
+#define MATRIX_PART(c0_, c1_, n0_, n1_, knext_, j_)                               \
+  {                                                                               \
+    MX_PRIO_HI()                                                                  \
+    V8 ka_[KPRE > 0 ? KPRE : 1][2];                                               \
+    PV_PART(knext_, _Pragma("unroll") for (int ks_ = 0; ks_ < KPRE; ++ks_) { ka_[ks_][0] = KF_(ks_, 0, knext_); ka_[ks_][1] = KF_(ks_, 1, knext_); }) \
+    SCHED_M()                                                                     \
+    asm volatile("" : "+v"(lt_), "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])); \
+    /* last, partial key block: mask its tail (once per workgroup; the exponents were taken over the clamped rows too) */ \
+    if ((j_) * KVB + KVB > n_kv) {                                                \
       _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                         \
-        c0_[i_] = __builtin_amdgcn_exp2f(c0_[i_]);                                \
-        c1_[i_] = __builtin_amdgcn_exp2f(c1_[i_]);                                \
+        const int row_ = (i_ & 3) + 8 * (i_ >> 2) + 4 * hh;                       \
+        if ((j_) * KVB + row_ >= n_kv) c0_[i_] = -INFINITY;                       \
+        if ((j_) * KVB + 32 + row_ >= n_kv) c1_[i_] = -INFINITY;                  \
       }                                                                           \
-      /* P' / 2^(CSH + e) -> e4m3 straight from the accumulator registers: a lane owns one query and 32 of the block's 64 keys */ \
-      /* = the B operand of ONE K = 64 MFMA (the conversion keeps the other half of its destination: fed the stale word)     */ \
-      _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                          \
-        pb_[w_] = CVT_SC(pb_[w_], c0_[4 * w_], c0_[4 * w_ + 1], cs0_, false);      \
-        pb_[w_] = CVT_SC(pb_[w_], c0_[4 * w_ + 2], c0_[4 * w_ + 3], cs0_, true);   \
-        pb_[4 + w_] = CVT_SC(pb_[4 + w_], c1_[4 * w_], c1_[4 * w_ + 1], cs1_, false); \
-        pb_[4 + w_] = CVT_SC(pb_[4 + w_], c1_[4 * w_ + 2], c1_[4 * w_ + 3], cs1_, true); \
-      }                                                                           \
-      _Pragma("unroll") for (int dt_ = 0; dt_ < 4; ++dt_) {                       \
-        i32x8 vf_;                                                                \
-        _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                        \
-          const i32x2 t_ = __builtin_amdgcn_ds_read_tr8_b64_v2i32(                \
-              (LDS_AS i32x2*)(smem + (kcur_) * TILE8 + v_rd[dt_] + n_ * 16 * ROWB8)); \
-          vf_[2 * n_] = t_[0]; vf_[2 * n_ + 1] = t_[1];                           \
-        }                                                                         \
-        o[dt_] = mfma8(vf_, pb_, o[dt_], sb_);                                    \
-      }                                                                           \
-      const f32x16 lt_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                  \
-          ones, pb_, f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 4, 0, 0, SC_ONE, 0, sb_); \
-      TILE_EXP(ecur, sc0, sc1, n0_, n1_) /* VALU work that overlaps the PV MFMAs above */ \
-      SCHED_RECIPE()                                                              \
-      l_run += lt_[0];                                                            \
+    }                                                                             \
+    if (!__all(ecur <= etrig_b)) { RAISE_REF(c0_, c1_) }                          \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 8; ++ks_) {                         \
+      V8 k0_, k1_;                                                                \
+      if (ks_ < KPRE) { k0_ = ka_[ks_][0]; k1_ = ka_[ks_][1]; }                   \
+      else { k0_ = KF_(ks_, 0, knext_); k1_ = KF_(ks_, 1, knext_); }              \
+      n0_ = MF<T>::mfma(k0_, qf[ks_], ks_ == 0 ? minit : n0_);                    \
+      n1_ = MF<T>::mfma(k1_, qf[ks_], ks_ == 0 ? minit : n1_);                    \
+    }                                                                             \
+    SCHED_S()                                                                     \
+    l_run += lt_[0];                                                              \
+    MX_PRIO_LO()                                                                  \
+  }
+  // kcur_ = j % 2: slot K(j) leaves (-> K(j+2)) and V(j) takes; knext_ = (j+1) % 2: slot of K(j+1) and of V(j-1)
+#define STEP(c0_, c1_, n0_, n1_, kcur_, knext_, j_)                               \
+  {                                                                               \
+    STAGE_DMA(kcur_, kcur_, j_) /* (spread over the VALU part, as attn_fwd_i8.hip does, the request registers live across the */ \
+    if (wave_active) {          /*  matrix part: 6 VGPRs spilled, 3 % slower than here: profiles/r05_fp8pv_roles.txt)        */ \
+      if (role_y) VALU_PART(n0_, n1_, c0_, c1_)                                   \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      MATRIX_PART(c0_, c1_, n0_, n1_, knext_, j_)                                 \
+      __builtin_amdgcn_sched_barrier(0);                                          \
+      if (!role_y) VALU_PART(c0_, c1_, n0_, n1_)                                  \
     }                                                                             \
     STEP_SYNC()                                                                   \
   }
-
-  if (blk0 < blk1) {
-    // prologue: K(0..NS-1) and V(0..NS-2) -> their ring slots; then rowK = rows(NS), rowV = rows(NS-1)
+  // wave-uniform: which half starts its steps with the VALU part -- the later-dispatched one (the other way round: 41.2 against
+  // 35.6 ms, profiles/r05_fp8pv_roles.txt)
+  const bool role_y = NW == 8 && wave >= NW / 2;
+  const int nsteps = blk1 - blk0;
+  if (nsteps > 0) {
+    // prologue: K(0), K(1); the scores of block 0 fix the reference point
     ROWS_OF(rowK, blk0)
-    ROWS_OF_V(rowV, blk0)
     DMA_K(0)
-    DMA_V(0)
     ROWS_OF(rowK, blk0 + 1)
     DMA_K(1)
-    ROWS_OF_V(rowV, blk0 + NS - 1)
-    ROWS_OF(rowK, blk0 + NS)
+    ROWS_OF_V(rowV, blk0)
+    ROWS_OF(rowK, blk0 + 2)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (wave_active) {
       QK(sA0, sA1, 0)  // seed 0: plain scores of the first block
@@ -432,11 +426,8 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
       }
       float mx0;
       ROW_MAX(mx0, sA0, sA1)
-      // the first block fixes the reference point at its true row max (block blk0 always has a valid key);
-      // O and l are still zero, so nothing is rescaled (exp2(-max) could overflow for very negative scores)
-      m_run = mx0;
+      m_run = mx0;  // the first block fixes the reference point at its true row max (block blk0 always has a valid key)
       const float sh = pbias - m_run + CSH;
-      // ... and its two key tiles take their block exponents from their own (masked) values
       float l0 = sA0[0], l1 = sA1[0];
 #pragma unroll
       for (int i = 1; i < 16; ++i) { l0 = fmaxf(l0, sA0[i]); l1 = fmaxf(l1, sA1[i]); }
@@ -450,31 +441,40 @@ __device__ __forceinline__ void attn_mx_body(const ParamsMx& pp, char* __restric
       for (int i = 0; i < 16; ++i) { sA0[i] += sh; sA1[i] += sh; minit[i] = sh; }
       asm volatile("" : "+v"(minit));
     }
-    __syncthreads();  // every wave has read K(0) before iteration 0 overwrites its slot with K(2)
-  }
-  if constexpr (NS == 2) {
-    for (int blk = blk0; blk < blk1; blk += 2) {
-      STEP(sA0, sA1, sB0, sB1, 0, 1, 1, blk)
-      if (blk + 1 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 1, 0, 0, blk + 1)
+    __syncthreads();  // every wave has read K(0) before step 0 overwrites its slot with K(2)
+    {  // step 0: no P V yet -- the scores of block 1, then (first role) the VALU part of block 0
+      STAGE_DMA(0, 0, blk0)
+      if (wave_active) {
+        QK(sB0, sB1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (!role_y) VALU_PART(sA0, sA1, sB0, sB1)
+      }
+      STEP_SYNC()
     }
-  } else {  // ring slots cycle with period 3, score roles with period 2: unrolled by 6
-    for (int blk = blk0; blk < blk1; blk += 6) {
-      STEP(sA0, sA1, sB0, sB1, 0, 1, 2, blk)
-      if (blk + 1 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 1, 2, 0, blk + 1)
-      if (blk + 2 >= blk1) break;
-      STEP(sA0, sA1, sB0, sB1, 2, 0, 1, blk + 2)
-      if (blk + 3 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 0, 1, 2, blk + 3)
-      if (blk + 4 >= blk1) break;
-      STEP(sA0, sA1, sB0, sB1, 1, 2, 0, blk + 4)
-      if (blk + 5 >= blk1) break;
-      STEP(sB0, sB1, sA0, sA1, 2, 0, 1, blk + 5)
+    for (int jj = 1; jj < nsteps; jj += 2) {
+      STEP(sB0, sB1, sA0, sA1, 1, 0, blk0 + jj)
+      if (jj + 1 >= nsteps) break;
+      STEP(sA0, sA1, sB0, sB1, 0, 1, blk0 + jj + 1)
+    }
+    // drain: the second role still owes the conversion of the last block; then P V of the last block
+    if (wave_active) {
+      if (role_y) {
+        if ((nsteps - 1) & 1) VALU_PART(sB0, sB1, sA0, sA1)
+        else VALU_PART(sA0, sA1, sB0, sB1)
+      }
+      PV_PART((nsteps - 1) & 1, )
+      l_run += lt_[0];
     }
   }
+#undef VFRAG
+#undef KF_
+#undef PV_PART
+#undef SCHED_M
+#undef SCHED_S
+#undef SG_
+#undef VALU_PART
+#undef MATRIX_PART
 #undef QK
-#undef QK_PRE
 #undef ROW_MAX
 #undef TILE_EXP
 #undef CVT_SC
