@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="hunyuan-129f", choices=sorted(CONFIGS))
     ap.add_argument("--mix", default="uniform", choices=sorted(MIXES))
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp8", "fp8pv", "i8pv"],
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp8", "fp8pv", "i8pv", "auto8"],
                     help="fp8: bf16 inputs, converted to e4m3 inside the timed step (vorta_fp8_quantize_qkv), both "
                          "contractions on the fp8 MFMA, bf16 output; fp8pv: scores in bf16, P V in e4m3 (only v is converted, "
                          "inside the step); i8pv: scores on the int8 MFMA with one scale per row (k converted inside the step, q "
@@ -405,10 +405,12 @@ def main():
     from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
 
     dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16  # (the 8-bit paths take and return bf16)
-    fp8 = True if cfg["dtype"] == "fp8" else (cfg["dtype"] if cfg["dtype"] in ("fp8pv", "i8pv") else False)
+    fp8 = True if cfg["dtype"] == "fp8" else (cfg["dtype"] if cfg["dtype"] in ("fp8pv", "i8pv", "auto8") else False)
+    if fp8 == "auto8" and (world > 1 or args.emulate_rank or args.level == "processor"):
+        raise SystemExit("--dtype auto8 (per-head choice between int8 and 16-bit scores) is a one-GPU, kernel-level line")
     # mixed precision: half of a layer's FLOPs run at the 16-bit rate, half at the e4m3 rate: harmonic mean of the peaks
     # (int8 scores run at the e4m3 MFMA rate: the all-8-bit peak)
-    peak = PEAK_MFMA_FP8_TFLOPS if fp8 in (True, "i8pv") else (2.0 / (1.0 / PEAK_MFMA_TFLOPS + 1.0 / PEAK_MFMA_FP8_TFLOPS)
+    peak = PEAK_MFMA_FP8_TFLOPS if fp8 in (True, "i8pv", "auto8") else (2.0 / (1.0 / PEAK_MFMA_TFLOPS + 1.0 / PEAK_MFMA_FP8_TFLOPS)
                                                                if fp8 == "fp8pv" else PEAK_MFMA_TFLOPS)
     H, L, T, te = cfg["heads"], cfg["layers"], cfg["text"], cfg["text_valid"]
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
@@ -444,7 +446,7 @@ def main():
         # e4m3 operand buffers reused by every layer (the conversion itself runs per layer, inside the step)
         f8buf = (ops.fp8_quantize_qkv(*(x[0] for x in sets[0])) if fp8 is True else
                  ops.fp8_quantize_v(sets[0][2][0]) if fp8 == "fp8pv" else
-                 (ops.fp8_quantize_v(sets[0][2][0]), ops.i8_quantize_k(sets[0][0][0], sets[0][1][0])) if fp8 == "i8pv" else None)
+                 (ops.fp8_quantize_v(sets[0][2][0]), ops.i8_quantize_k(sets[0][0][0], sets[0][1][0])) if fp8 in ("i8pv", "auto8") else None)
         if te:
             geom.sta_tables(te)  # built once per prompt, outside the step (pipeline_hunyuan.py:378-392)
 

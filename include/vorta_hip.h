@@ -31,14 +31,15 @@ extern "C" {
 #define VORTA_EUNSUPPORTED (-2) /* valid request this build does not implement (head_dim, dtype)      */
 #define VORTA_ELAUNCH (-3)      /* the HIP runtime refused the launch (see vorta_last_hip_error)      */
 
-#define VORTA_ABI_VERSION 7 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
+#define VORTA_ABI_VERSION 8 /* 2: adds the fp8 entry points (vorta_fp8_*, vorta_attn_fwd_fp8*); 3: adds vorta_permute_heads;
                                 4: vorta_fp8_quant_args gains slot_first / slot_count and flags bit2, adds vorta_fp8_v_absmax /
                                 vorta_fp8_v_convert; every earlier call means what it meant
                                 5: vorta_fp8_quant_args gains video_tokens / token_offset / total_tokens / src_map and flags
                                 bit3 / bit4 (sequence shards), adds vorta_fp8_quant_ws_partials
                                 6: adds the int8-score entry points (vorta_i8_quantize_k, vorta_attn_fwd_i8, vorta_attn_fwd_batch_i8);
                                 7: the int8-score kernel writes its probabilities with one power-of-two scale per query row
-                                   and 32 keys (vorta_attn_i8_ext.defer becomes the reference-point trigger in binades, default 24) */
+                                   and 32 keys (vorta_attn_i8_ext.defer becomes the reference-point trigger in binades, default 24);
+                                8: adds vorta_i8_tail_flags and vorta_split_heads (per-head choice between int8 and 16-bit scores) */
 
 typedef enum vorta_dtype {
   VORTA_BF16 = 0,
@@ -317,6 +318,22 @@ typedef struct vorta_i8_quant_args {
 } vorta_i8_quant_args;
 
 int vorta_i8_quantize_k(const vorta_i8_quant_args* args, void* hip_stream);
+
+/*
+ * ABI 8 -- per-head choice between the int8-score kernel and the mixed-precision one ("auto8" of the Python host): int8 scores
+ * with ONE key scale per head resolve the bulk of a heavy-tailed head's keys to 0 / +-1 (Student-t(3): abs-max ~ 250 sigma over
+ * 10^7 samples; relative error 0.10-0.19 where every other input family tried stays under 0.07).
+ * vorta_i8_tail_flags: flags[h] = 1 when the root mean square of head h's int8 keys (k8 of vorta_i8_quantize_k, (heads,
+ *   n_tokens, head_dim) view, strides in bytes) over ~1024 evenly spaced rows is below `min_rms` counts, else 0.  Exact integer
+ *   arithmetic: the flag is reproducible.
+ * vorta_split_heads: list0 / list1 = the heads of head_list[0 .. n) (NULL: 0 .. n-1; n = min(*n_heads_dev, n_heads) when
+ *   n_heads_dev is given) whose flag is 0 / 1, order kept; counts[0], counts[1] = their lengths.  The two lists (room for
+ *   n_heads entries each) and the counts (device) are what vorta_attn_args.head_list / n_heads_dev of the two launches take:
+ *   a launch over an empty list exits in its first instruction.  No host synchronisation anywhere.
+ */
+int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_t n_tokens, float min_rms, int32_t* flags, void* hip_stream);
+int vorta_split_heads(const int32_t* head_list, const int32_t* n_heads_dev, int32_t n_heads, const int32_t* flags,
+                      int32_t* list0, int32_t* list1, int32_t* counts, void* hip_stream);
 
 /*
  * vorta_attn_fwd_i8 -- the gather flash-attention of vorta_attn_fwd with int8 scores and e4m3 P V.

@@ -258,7 +258,7 @@ def test_hunyuan_triple_eval_vs_oracle(dual):
 
 
 @pytest.mark.parametrize("dual", [True, False])
-@pytest.mark.parametrize("precision", ["native", "fp8", "i8pv"])
+@pytest.mark.parametrize("precision", ["native", "fp8", "i8pv", "auto8"])
 def test_hunyuan_processor_call_compiles_fullgraph(dual, precision):
     """the production processor call goes through torch.ops.vorta.* (vorta_amd/torch_ops.py), so
     `torch.compile(fullgraph=True)` traces `HunyuanVideoFlashAttnProcessorTripleEval.__call__` without a graph break

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VORTA_HIP_LIB") or os.path.join(_HERE, "csrc", "libvo
 
 VORTA_OK, VORTA_EINVAL, VORTA_EUNSUPPORTED, VORTA_ELAUNCH = 0, -1, -2, -3
 VORTA_BF16, VORTA_FP16, VORTA_FP32, VORTA_FP8E4M3, VORTA_INT8 = 0, 1, 2, 3, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _i32, _i64, _u32, _f32, _vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
 
@@ -150,6 +150,8 @@ SYMBOLS = {
     "vorta_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _vp]),
     "vorta_attn_fwd_batch_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _i32, _vp]),
     "vorta_i8_quantize_k": (C.c_int, [C.POINTER(I8QuantArgs), _vp]),
+    "vorta_i8_tail_flags": (C.c_int, [C.POINTER(Tensor), _i32, _i32, C.c_float, _vp, _vp]),
+    "vorta_split_heads": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vorta_attn_fwd_i8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnI8Ext), _vp]),
     "vorta_attn_fwd_batch_i8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnI8Ext), _i32, _vp]),
     "vorta_coreset_select": (C.c_int, [C.POINTER(CoresetArgs), _vp]),

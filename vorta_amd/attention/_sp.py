@@ -203,6 +203,8 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     # attention -- --native_attention, the PSNR reference -- stays in the dtype of q,k,v on one GPU and under SP alike
     from .. import routed as _routed
     fp8 = _routed.DEFAULT_FP8 if not dense_only else False  # False, True (all e4m3), "fp8pv" (16-bit scores), "i8pv" (int8)
+    if fp8 == "auto8":  # the per-head choice between int8 and 16-bit scores is a one-GPU feature: under sequence parallelism
+        fp8 = "fp8pv"   # every head takes the kernel that holds 0.04 relative error on every input family
     f8, vwire = sb.fp8(fp8) if fp8 else (None, None)
     if vwire is not None:
         vwire.lay = lay  # the layouts of one slot count share the buffers; the head offsets are this layer's

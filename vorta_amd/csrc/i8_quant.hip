@@ -208,7 +208,80 @@ __global__ void i8_head_scale_kernel(const IParams p) {
   }
 }
 
+// grid (heads), 1024 threads = 64 row lanes x 16 channel groups of 16: the sum of squares of ~1024 evenly spaced int8 rows of
+// the head in a FIXED order (row lane rl takes samples rl, rl + 64, ...; the 16 bytes of a lane in order; lanes pairwise at
+// distance 512, 256, ... 1): exact in int64, so the flag does not depend on the order at all
+__global__ __launch_bounds__(1024) void i8_tail_kernel(const char* k8, int64_t sh, int64_t ss, int n_tokens, int stride, int cand,
+                                                        float min_rms, int* flags) {
+  const int h = blockIdx.x, t = threadIdx.x, cg = t & 7, rl = t >> 3;  // 8 lanes x 16 bytes per row, 128 row lanes
+  long long acc = 0;
+  for (int i = rl; i < cand; i += 128) {
+    const int64_t r = min((int64_t)i * stride, (int64_t)n_tokens - 1);
+    const int4 w = *(const int4*)(k8 + (int64_t)h * sh + r * ss + cg * 16);
+    const int v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int x = (int)(signed char)((v[e] >> (8 * b)) & 0xff);
+        acc += x * x;
+      }
+  }
+  __shared__ long long red[1024];
+  red[t] = acc;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (t < off) red[t] += red[t + off];
+    __syncthreads();
+  }
+  if (t == 0) {
+    const double mean2 = (double)red[0] / ((double)cand * D);
+    flags[h] = mean2 < (double)min_rms * (double)min_rms ? 1 : 0;
+  }
+}
+
+// one thread: order-preserving split of a head list by a per-head flag
+__global__ void split_heads_kernel(const int* head_list, const int* n_dev, int n, const int* flags, int* list0, int* list1,
+                                   int* counts) {
+  if (threadIdx.x || blockIdx.x) return;
+  const int m = n_dev ? min(max(*n_dev, 0), n) : n;
+  int c0 = 0, c1 = 0;
+  for (int y = 0; y < m; ++y) {
+    const int h = head_list ? head_list[y] : y;
+    if (flags[h]) list1[c1++] = h;
+    else list0[c0++] = h;
+  }
+  counts[0] = c0;
+  counts[1] = c1;
+}
+
 }  // namespace
+
+extern "C" int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_t n_tokens, float min_rms, int32_t* flags,
+                                   void* hip_stream) {
+  if (!k8 || heads < 0 || n_tokens < 0 || !(min_rms >= 0.f)) return VORTA_EINVAL;
+  if (heads == 0) return VORTA_OK;
+  if (!k8->ptr || !flags || n_tokens == 0) return VORTA_EINVAL;
+  if (((uintptr_t)k8->ptr & 15) || (k8->stride_s % 16) || (k8->stride_h % 16) || k8->stride_s < D) return VORTA_EINVAL;
+  int stride = n_tokens / SAMPLES;
+  if (stride < 1) stride = 1;
+  stride |= 1;
+  const int cand = (n_tokens + stride - 1) / stride;
+  hipLaunchKernelGGL(i8_tail_kernel, dim3(heads), dim3(1024), 0, (hipStream_t)hip_stream, (const char*)k8->ptr, k8->stride_h,
+                     k8->stride_s, n_tokens, stride, cand, min_rms, flags);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
+}
+
+extern "C" int vorta_split_heads(const int32_t* head_list, const int32_t* n_heads_dev, int32_t n_heads, const int32_t* flags,
+                                 int32_t* list0, int32_t* list1, int32_t* counts, void* hip_stream) {
+  if (n_heads < 0) return VORTA_EINVAL;
+  if (!flags || !list0 || !list1 || !counts) return VORTA_EINVAL;
+  hipLaunchKernelGGL(split_heads_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, head_list, n_heads_dev, n_heads, flags,
+                     list0, list1, counts);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
+}
 
 extern "C" int vorta_i8_quantize_k(const vorta_i8_quant_args* a, void* hip_stream) {
   if (!a || a->struct_size != sizeof(vorta_i8_quant_args)) return VORTA_EINVAL;

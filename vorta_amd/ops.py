@@ -555,6 +555,41 @@ def i8_quantize_k(q: torch.Tensor, k: torch.Tensor, *, out: Optional[I8Operands]
     return out
 
 
+# "auto8": a head whose int8 keys have a root mean square below this many counts (the bulk of a heavy-tailed head rounds to
+# 0 / +-1 under one scale per head) runs with 16-bit scores instead: Student-t(3) keys sit at 0.5-2, every other input family of
+# tests/_fp8_inputs.py at 5 or more (white noise 26)
+I8_TAIL_MIN_RMS = float(__import__("os").environ.get("VORTA_I8_TAIL_MIN_RMS", "3.2"))
+
+
+def i8_tail_flags(k8: torch.Tensor, min_rms: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """vorta_i8_tail_flags: (H,) int32, 1 for the heads whose int8 keys `k8` (H,S,D) are too coarse for int8 scores."""
+    _require_gpu(k8)
+    if k8.dtype != torch.int8 or k8.dim() != 3:
+        raise ValueError("i8_tail_flags takes the (H,S,D) int8 keys of i8_quantize_k")
+    H, S, _ = k8.shape
+    if out is None:
+        out = torch.empty((H,), dtype=torch.int32, device=k8.device)
+    t = _tensor(k8)
+    _C.check(_C.lib().vorta_i8_tail_flags(C.byref(t), H, S, float(I8_TAIL_MIN_RMS if min_rms is None else min_rms),
+                                          out.data_ptr(), _stream()), "vorta_i8_tail_flags")
+    return out
+
+
+def split_heads(flags: torch.Tensor, head_list: Optional[torch.Tensor], n_heads: int,
+                n_heads_dev: Optional[torch.Tensor] = None):
+    """vorta_split_heads: the heads of `head_list[:n]` (None: 0 .. n-1) with flag 0 and with flag 1, order kept, as two
+    (head_list, n_heads, n_heads_dev) slot-argument dicts for attn_fwd / coreset_select -- everything stays on the device."""
+    _require_gpu(flags)
+    dev = flags.device
+    lists = torch.empty((2, max(n_heads, 1)), dtype=torch.int32, device=dev)
+    counts = torch.empty((2,), dtype=torch.int32, device=dev)
+    _C.check(_C.lib().vorta_split_heads(head_list.data_ptr() if head_list is not None else None,
+                                        n_heads_dev.data_ptr() if n_heads_dev is not None else None, int(n_heads),
+                                        flags.data_ptr(), lists[0].data_ptr(), lists[1].data_ptr(), counts.data_ptr(), _stream()),
+             "vorta_split_heads")
+    return tuple(dict(head_list=lists[i], n_heads=int(n_heads), n_heads_dev=counts[i:i + 1]) for i in range(2))
+
+
 def _fp8_v_args(v: torch.Tensor, amax: torch.Tensor, per_head: bool):
     _require_gpu(v, amax)
     if v.dtype not in _DT or v.dim() != 3:

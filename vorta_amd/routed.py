@@ -169,7 +169,7 @@ STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
 # unchanged inference scripts pick the e4m3 path up from the environment or from `set_attention_precision("fp8")`
 # False (native), True (all e4m3), "fp8pv" (16-bit scores, e4m3 P V) or "i8pv" (int8 scores: one key scale per head, one query scale per wave; e4m3 P V)
 _PREC_ENV = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower()
-DEFAULT_FP8 = True if _PREC_ENV == "fp8" else (_PREC_ENV if _PREC_ENV in ("fp8pv", "i8pv") else False)
+DEFAULT_FP8 = True if _PREC_ENV == "fp8" else (_PREC_ENV if _PREC_ENV in ("fp8pv", "i8pv", "auto8") else False)
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
 # the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
 FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
@@ -188,12 +188,13 @@ FUSED_TEXT_FIRST = FUSED_TEXT_SPLITS > 0
 def set_attention_precision(precision: str) -> None:
     """"native" (the dtype of q,k,v: the reference's behaviour), "fp8" (both contractions in e4m3: fastest, 40 dB against
     native only where the softmax is flat), "fp8pv" (scores in 16 bits, P V in e4m3: >= 42 dB on every input family
-    tried) or "i8pv" (scores in int8 with a scale per row at the e4m3 MFMA rate, P V in e4m3: >= 40 dB on every family,
-    DESIGN.md (c)); 16-bit output in every case"""
+    tried), "i8pv" (scores in int8 at the e4m3 MFMA rate, P V in e4m3: >= 40 dB on every family, relative error <= 0.07 on
+    all but heavy-tailed inputs) or "auto8" ("i8pv" per head, with 16-bit scores -- "fp8pv" -- for the heads whose int8 keys
+    would be too coarse; chosen on the device, one GPU); 16-bit output in every case"""
     global DEFAULT_FP8
-    if precision not in ("native", "fp8", "fp8pv", "i8pv"):
-        raise ValueError("precision is 'native', 'fp8', 'fp8pv' or 'i8pv'")
-    DEFAULT_FP8 = True if precision == "fp8" else (precision if precision in ("fp8pv", "i8pv") else False)
+    if precision not in ("native", "fp8", "fp8pv", "i8pv", "auto8"):
+        raise ValueError("precision is 'native', 'fp8', 'fp8pv', 'i8pv' or 'auto8'")
+    DEFAULT_FP8 = True if precision == "fp8" else (precision if precision in ("fp8pv", "i8pv", "auto8") else False)
 _SIDE_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
 
 
@@ -268,6 +269,19 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         v8, vd, _ = ops.fp8_quantize_v(v3, out=vo)
         i8 = ops.i8_quantize_k(q3, k3, out=ko)
         base = dict(q=q3, k=i8.k8, v=v8, scale=scale, v_descale=vd, i8=i8)
+    elif fp8 == "auto8":
+        # per head: int8 scores where the head's int8 keys resolve their bulk, 16-bit scores where they do not (heavy tails);
+        # P V in e4m3 with block-scaled probabilities either way.  The choice is made on the device (ops.i8_tail_flags over the
+        # int8 keys, ops.split_heads over every expert's head list): two fused launches per layer, one of them usually over
+        # empty lists (its workgroups exit in their first instruction), no host synchronisation
+        if routing.partials or kv_splits and int(kv_splits) > 1:
+            raise ValueError("'auto8' does not take heads split by query range or key splits (sequence-parallel placements)")
+        vo, ko = fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 2 else (None, None)
+        v8, vd, _ = ops.fp8_quantize_v(v3, out=vo)
+        i8 = ops.i8_quantize_k(q3, k3, out=ko)
+        tail = ops.i8_tail_flags(i8.k8)
+        base = dict(q=q3, k=i8.k8, v=v8, scale=scale, v_descale=vd, i8=i8)
+        base_tail = dict(q=q3, k=k3, v=v8, scale=scale, v_descale=vd)
     elif fp8 == "fp8pv":  # scores in 16 bits, P V in e4m3: only v is converted (exact per-channel abs-max, one pass + one)
         v8, vd, _ = ops.fp8_quantize_v(v3, out=fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 3 else None)
         base = dict(q=q3, k=k3, v=v8, scale=scale, v_descale=vd)
@@ -278,6 +292,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         base = dict(q=f8.q, k=f8.k, v=f8.v, scale=scale, v_descale=f8.v_descale)
 
     split_kw = dict(n_splits=int(kv_splits)) if kv_splits and int(kv_splits) > 1 else {}
+    slot_of = routing.slot_args  # (expert, H) -> head_list / n_heads / n_heads_dev of a launch ("auto8": one of the two parts)
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     def expert_full():
@@ -285,7 +300,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         if routing.counts_host is None or routing.counts_host[0] > 0:
             calls.append(dict(base, out=o_e[0], n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full", **split_kw,
                               q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
-                              flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **routing.slot_args(0, H)))
+                              flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **slot_of(0, H)))
         for hl, t0, t1 in routing.partials or ():
             # a head whose other query tokens another rank computes: every key, the query rows [t0, t1) of the VIDEO tokens;
             # the part that ends at the last video token also owns the head's text queries (they follow it in token order)
@@ -304,7 +319,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
 
     # ---- expert 1: coreset attention (hunyuan.py:410-457 / wan.py:243-270) ----
     def expert_lowres():
-        sl = routing.slot_args(1, H)
+        sl = slot_of(1, H)
         # key side: the same rows as the reference's packed [centres | margins] list (coreset_select.py:116-124) in
         # group-major ascending order -- softmax does not see the order of the keys, the K/V gather does
         gm = CORESET_KV_GROUP_MAJOR
@@ -325,7 +340,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
 
     # ---- expert 2: sliding-tile attention (hunyuan.py:459-507 / wan.py:272-294) ----
     def expert_sliding():
-        sl = routing.slot_args(2, H)
+        sl = slot_of(2, H)
         if STA_MERGE and sliding_block_rows in (128, 256):
             q_rows, kv_rows, n_kv, table, n_lists = geom.sta_launch_tables(te, sliding_block_rows)
             calls = [dict(base, out=o_e[2], n_q=S, n_kv=n_kv, q_rows=q_rows, kv_rows=kv_rows, kv_rows_stride_g=n_kv,
@@ -365,6 +380,19 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         # 128-row launch with less padding (Hunyuan 129f: 4.77 s vs 4.91 s per step)
         sliding_block_rows = 256
     experts = [(expert_full, live(0)), (expert_lowres, live(1)), (expert_sliding, live(2))]
+    if fp8 == "auto8" and fp8_views is None:
+        if concurrent:
+            raise ValueError("'auto8' runs its two parts as fused grids (concurrent=False)")
+        parts = [ops.split_heads(tail, **routing.slot_args(e, H)) if on else None for e, (_, on) in enumerate(experts)]
+        for which, b in ((0, base), (1, base_tail)):  # int8-score heads, then 16-bit-score heads
+            base = b
+            slot_of = lambda e, H_, which=which: parts[e][which]  # noqa: E731
+            calls = [c for fn, on in experts if on for c in fn()]
+            if fused:
+                ops.attn_fwd_batch(calls)
+            else:
+                launch(calls)
+        return out
     if not concurrent:
         calls = [c for fn, on in experts if on for c in fn()]
         if fused:
