@@ -324,14 +324,16 @@ int vorta_i8_quantize_k(const vorta_i8_quant_args* args, void* hip_stream);
  * with ONE key scale per head resolve the bulk of a heavy-tailed head's keys to 0 / +-1 (Student-t(3): abs-max ~ 250 sigma over
  * 10^7 samples; relative error 0.10-0.19 where every other input family tried stays under 0.07).
  * vorta_i8_tail_flags: flags[h] = 1 when the root mean square of head h's int8 keys (k8 of vorta_i8_quantize_k, (heads,
- *   n_tokens, head_dim) view, strides in bytes) over ~1024 evenly spaced rows is below `min_rms` counts, else 0.  Exact integer
- *   arithmetic: the flag is reproducible.
+ *   n_tokens, head_dim) view, strides in bytes) over ~1024 evenly spaced tokens is below `min_rms` counts, else 0; row_map (NULL:
+ *   token = row) gives the row of each token inside a head's view (the Ulysses receive layout).  Exact integer arithmetic: the
+ *   flag is reproducible, and the same under sequence parallelism.
  * vorta_split_heads: list0 / list1 = the heads of head_list[0 .. n) (NULL: 0 .. n-1; n = min(*n_heads_dev, n_heads) when
  *   n_heads_dev is given) whose flag is 0 / 1, order kept; counts[0], counts[1] = their lengths.  The two lists (room for
  *   n_heads entries each) and the counts (device) are what vorta_attn_args.head_list / n_heads_dev of the two launches take:
  *   a launch over an empty list exits in its first instruction.  No host synchronisation anywhere.
  */
-int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_t n_tokens, float min_rms, int32_t* flags, void* hip_stream);
+int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_t n_tokens, const int32_t* row_map, float min_rms, int32_t* flags,
+                        void* hip_stream);
 int vorta_split_heads(const int32_t* head_list, const int32_t* n_heads_dev, int32_t n_heads, const int32_t* flags,
                       int32_t* list0, int32_t* list1, int32_t* counts, void* hip_stream);
 

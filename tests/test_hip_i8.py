@@ -393,6 +393,15 @@ def test_auto8_flags_heavy_tailed_heads_and_each_head_equals_the_kernel_it_was_g
         for h, f in enumerate(flags.tolist()):
             want = outs["fp8pv" if f else "i8pv"][0, h]
             assert torch.equal(outs["auto8"][0, h], want), (experts, h, f)
+    # the form the sequence-parallel path uses: converted views + 16-bit keys + flags handed in; flags through a row map
+    v8, vd, _ = ops.fp8_quantize_v(v[0])
+    o_views = routed_attention(q, k, v, routing, geom, model="wan", fp8=False, fp8_views=(q[0], i8.k8, v8, vd, i8, k[0], flags))
+    assert torch.equal(o_views, outs["auto8"])
+    perm = torch.randperm(q.shape[2], device=dev)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device=dev)
+    shuffled = i8.k8[:, inv].contiguous()  # row perm[t] of the shuffled keys holds token t
+    assert ops.i8_tail_flags(shuffled, row_map=perm.to(torch.int32)).tolist() == flags.tolist()
     # device-resident routes (counts only the device knows): the same bits
     routing = HeadRouting.from_expert_ids([0, 1, 2, 1, 2], dev)
     rd = HeadRouting.from_device(routing.lists, torch.tensor(routing.counts_host, dtype=torch.int32, device=dev))

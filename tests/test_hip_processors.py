@@ -522,6 +522,9 @@ def _sp_worker_fp8(rank, world, port, ret):
     vorta_amd.set_attention_precision("i8pv")  # scores in int8, P V in e4m3
     fulli8 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
     fulli8_2 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
+    vorta_amd.set_attention_precision("auto8")  # per head int8 or 16-bit scores
+    fulla = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+    assert torch.equal(fulla, fulli8)  # nothing flagged on these inputs
     vorta_amd.set_attention_precision("fp8")
     SP_STATE.setup_sp_group(world)
     rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
@@ -553,6 +556,14 @@ def _sp_worker_fp8(rank, world, port, ret):
         part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=sc, **_wan_kwargs())
         ref = fl[:, rank * Sl:(rank + 1) * Sl].float()
         res[("i8pv", groups, placement)] = (float((part.float() - ref).abs().max()), rel(ref, nt))
+    # "auto8": the per-head choice on the receive layout (tail flags through the row map): the single-process bits
+    vorta_amd.set_attention_precision("auto8")
+    for groups, placement in ((1, "even"), (2, "even")):
+        _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = groups, True, placement
+        _sp._LAYOUTS.clear(); _sp._BUFFERS.clear()
+        part = proc(attn, shard, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
+        ref = fulla[:, rank * Sl:(rank + 1) * Sl].float()
+        res[("auto8", groups, placement)] = (float((part.float() - ref).abs().max()), rel(ref, nat))
     vorta_amd.set_attention_precision("native")
     _sp.SP_GROUPS, _sp.SP_V_WIRE, _sp.SP_PLACEMENT = 1, True, "uneven"
     ret[rank] = res
@@ -574,7 +585,7 @@ def test_processor_under_sequence_parallel_rehearsal_fp8():
     ret = mp.Manager().dict()
     mp.spawn(_sp_worker_fp8, args=(2, port, ret), nprocs=2, join=True)
     for r in (0, 1):
-        assert len(ret[r]) == 18
+        assert len(ret[r]) == 20
         for key, (d, one) in ret[r].items():
             assert d == 0.0 and 0.0 < one < 0.1, (key, dict(ret[r]))
 

@@ -150,7 +150,7 @@ SYMBOLS = {
     "vorta_attn_fwd_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _vp]),
     "vorta_attn_fwd_batch_fp8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnFp8Ext), _i32, _vp]),
     "vorta_i8_quantize_k": (C.c_int, [C.POINTER(I8QuantArgs), _vp]),
-    "vorta_i8_tail_flags": (C.c_int, [C.POINTER(Tensor), _i32, _i32, C.c_float, _vp, _vp]),
+    "vorta_i8_tail_flags": (C.c_int, [C.POINTER(Tensor), _i32, _i32, _vp, C.c_float, _vp, _vp]),
     "vorta_split_heads": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vorta_attn_fwd_i8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnI8Ext), _vp]),
     "vorta_attn_fwd_batch_i8": (C.c_int, [C.POINTER(AttnArgs), C.POINTER(AttnI8Ext), _i32, _vp]),

@@ -203,17 +203,20 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     # attention -- --native_attention, the PSNR reference -- stays in the dtype of q,k,v on one GPU and under SP alike
     from .. import routed as _routed
     fp8 = _routed.DEFAULT_FP8 if not dense_only else False  # False, True (all e4m3), "fp8pv" (16-bit scores), "i8pv" (int8)
-    if fp8 == "auto8":  # the per-head choice between int8 and 16-bit scores is a one-GPU feature: under sequence parallelism
-        fp8 = "fp8pv"   # every head takes the kernel that holds 0.04 relative error on every input family
-    f8, vwire = sb.fp8(fp8) if fp8 else (None, None)
+    auto8 = fp8 == "auto8"
+    if auto8 and (kv_splits > 1 or any(x is not None for x in local_parts) or dense_only):
+        auto8, fp8 = False, "fp8pv"  # (heads split by query range / key splits: the kernel that holds every family, for every head)
+    f8, vwire = sb.fp8("i8pv" if auto8 else fp8) if fp8 else (None, None)
     if vwire is not None:
         vwire.lay = lay  # the layouts of one slot count share the buffers; the head offsets are this layer's
 
     def attend(g0, g1, gi):
         views = None
-        if fp8 == "i8pv":  # k of the slot group that has landed -> int8 (q by the kernel); v arrived as e4m3
+        if fp8 == "i8pv" or auto8:  # k of the slot group that has landed -> int8 (q by the kernel); v arrived as e4m3
             i8 = lay.i8_views(bufs, sb.i8, slots=(g0, g1))
             views = (qv[g0:g1], i8.k8[g0:g1], lay.head_view(vwire.buf)[g0:g1], vwire.descale(g0, g1), i8.heads(g0, g1))
+            if auto8:  # + the 16-bit keys as they landed and the group's tail flags: each head to the kernel that holds it
+                views += (kv[g0:g1], ops.i8_tail_flags(i8.k8[g0:g1], row_map=rm[:S + T]))
         elif fp8 == "fp8pv":  # q, k as they landed; v arrived as e4m3 (converted on the send side)
             views = (qv[g0:g1], kv[g0:g1], lay.head_view(vwire.buf)[g0:g1], vwire.descale(g0, g1))
         elif fp8:  # the slot group that has landed is converted while the next one is in flight

@@ -211,12 +211,13 @@ __global__ void i8_head_scale_kernel(const IParams p) {
 // grid (heads), 1024 threads = 64 row lanes x 16 channel groups of 16: the sum of squares of ~1024 evenly spaced int8 rows of
 // the head in a FIXED order (row lane rl takes samples rl, rl + 64, ...; the 16 bytes of a lane in order; lanes pairwise at
 // distance 512, 256, ... 1): exact in int64, so the flag does not depend on the order at all
-__global__ __launch_bounds__(1024) void i8_tail_kernel(const char* k8, int64_t sh, int64_t ss, int n_tokens, int stride, int cand,
-                                                        float min_rms, int* flags) {
+__global__ __launch_bounds__(1024) void i8_tail_kernel(const char* k8, int64_t sh, int64_t ss, const int* row_map, int n_tokens,
+                                                        int stride, int cand, float min_rms, int* flags) {
   const int h = blockIdx.x, t = threadIdx.x, cg = t & 7, rl = t >> 3;  // 8 lanes x 16 bytes per row, 128 row lanes
   long long acc = 0;
   for (int i = rl; i < cand; i += 128) {
-    const int64_t r = min((int64_t)i * stride, (int64_t)n_tokens - 1);
+    const int64_t tok = min((int64_t)i * stride, (int64_t)n_tokens - 1);
+    const int64_t r = row_map ? (int64_t)row_map[tok] : tok;  // (the zero-copy Ulysses layout: token -> row of the head's view)
     const int4 w = *(const int4*)(k8 + (int64_t)h * sh + r * ss + cg * 16);
     const int v[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
@@ -257,8 +258,8 @@ __global__ void split_heads_kernel(const int* head_list, const int* n_dev, int n
 
 }  // namespace
 
-extern "C" int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_t n_tokens, float min_rms, int32_t* flags,
-                                   void* hip_stream) {
+extern "C" int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_t n_tokens, const int32_t* row_map, float min_rms,
+                                   int32_t* flags, void* hip_stream) {
   if (!k8 || heads < 0 || n_tokens < 0 || !(min_rms >= 0.f)) return VORTA_EINVAL;
   if (heads == 0) return VORTA_OK;
   if (!k8->ptr || !flags || n_tokens == 0) return VORTA_EINVAL;
@@ -268,7 +269,7 @@ extern "C" int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_
   stride |= 1;
   const int cand = (n_tokens + stride - 1) / stride;
   hipLaunchKernelGGL(i8_tail_kernel, dim3(heads), dim3(1024), 0, (hipStream_t)hip_stream, (const char*)k8->ptr, k8->stride_h,
-                     k8->stride_s, n_tokens, stride, cand, min_rms, flags);
+                     k8->stride_s, row_map, n_tokens, stride, cand, min_rms, flags);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? VORTA_OK : vorta_set_hip_error(e);
 }

@@ -561,16 +561,19 @@ def i8_quantize_k(q: torch.Tensor, k: torch.Tensor, *, out: Optional[I8Operands]
 I8_TAIL_MIN_RMS = float(__import__("os").environ.get("VORTA_I8_TAIL_MIN_RMS", "3.2"))
 
 
-def i8_tail_flags(k8: torch.Tensor, min_rms: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """vorta_i8_tail_flags: (H,) int32, 1 for the heads whose int8 keys `k8` (H,S,D) are too coarse for int8 scores."""
+def i8_tail_flags(k8: torch.Tensor, min_rms: Optional[float] = None, out: Optional[torch.Tensor] = None,
+                  row_map: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """vorta_i8_tail_flags: (H,) int32, 1 for the heads whose int8 keys `k8` (H,rows,D) are too coarse for int8 scores.
+    `row_map` (int32, one entry per token): the row of each token inside a head's view (Ulysses receive layout)."""
     _require_gpu(k8)
     if k8.dtype != torch.int8 or k8.dim() != 3:
         raise ValueError("i8_tail_flags takes the (H,S,D) int8 keys of i8_quantize_k")
-    H, S, _ = k8.shape
+    H = k8.shape[0]
+    n = int(row_map.numel()) if row_map is not None else k8.shape[1]
     if out is None:
         out = torch.empty((H,), dtype=torch.int32, device=k8.device)
     t = _tensor(k8)
-    _C.check(_C.lib().vorta_i8_tail_flags(C.byref(t), H, S, float(I8_TAIL_MIN_RMS if min_rms is None else min_rms),
+    _C.check(_C.lib().vorta_i8_tail_flags(C.byref(t), H, n, _ptr(row_map), float(I8_TAIL_MIN_RMS if min_rms is None else min_rms),
                                           out.data_ptr(), _stream()), "vorta_i8_tail_flags")
     return out
 

@@ -190,7 +190,7 @@ def set_attention_precision(precision: str) -> None:
     native only where the softmax is flat), "fp8pv" (scores in 16 bits, P V in e4m3: >= 42 dB on every input family
     tried), "i8pv" (scores in int8 at the e4m3 MFMA rate, P V in e4m3: >= 40 dB on every family, relative error <= 0.07 on
     all but heavy-tailed inputs) or "auto8" ("i8pv" per head, with 16-bit scores -- "fp8pv" -- for the heads whose int8 keys
-    would be too coarse; chosen on the device, one GPU); 16-bit output in every case"""
+    would be too coarse; chosen on the device); 16-bit output in every case"""
     global DEFAULT_FP8
     if precision not in ("native", "fp8", "fp8pv", "i8pv", "auto8"):
         raise ValueError("precision is 'native', 'fp8', 'fp8pv', 'i8pv' or 'auto8'")
@@ -261,8 +261,13 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         fp8 = DEFAULT_FP8
     if fp8_views is not None:
         base = dict(q=fp8_views[0], k=fp8_views[1], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
-        if len(fp8_views) == 5:  # int8 keys: + their I8Operands (row biases, query preparation, head scales)
+        if len(fp8_views) in (5, 7):  # int8 keys: + their I8Operands (row biases, query preparation, head scales)
             base.update(i8=fp8_views[4])
+        if len(fp8_views) == 7:  # "auto8" on converted views: + the 16-bit keys and the heads' tail flags (sequence-parallel path)
+            if routing.partials or kv_splits and int(kv_splits) > 1:
+                raise ValueError("'auto8' does not take heads split by query range or key splits")
+            base_tail = dict(q=fp8_views[0], k=fp8_views[5], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
+            tail, fp8 = fp8_views[6], "auto8"
     elif fp8 == "i8pv":  # int8 scores: k -> int8 rows (centred, balanced, one scale per head) + a float bias per row, v -> e4m3;
         # q is centred, balanced and rounded by the attention kernel itself
         vo, ko = fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 2 else (None, None)
@@ -380,7 +385,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         # 128-row launch with less padding (Hunyuan 129f: 4.77 s vs 4.91 s per step)
         sliding_block_rows = 256
     experts = [(expert_full, live(0)), (expert_lowres, live(1)), (expert_sliding, live(2))]
-    if fp8 == "auto8" and fp8_views is None:
+    if fp8 == "auto8" and (fp8_views is None or len(fp8_views) == 7):
         if concurrent:
             raise ValueError("'auto8' runs its two parts as fused grids (concurrent=False)")
         parts = [ops.split_heads(tail, **routing.slot_args(e, H)) if on else None for e, (_, on) in enumerate(experts)]
