@@ -195,3 +195,28 @@ def test_mx_operator_psnr_on_every_input_family(geometry):
             if p_peak < 40.0 or rel > MX_REL_GATE:
                 failures.append((geometry, key, n, round(p_peak, 1), round(rel, 3)))
     assert not failures, failures
+
+
+@pytest.mark.parametrize("block_rows", [128, 256])
+def test_8bit_kernels_with_one_two_three_key_blocks(block_rows):
+    """The wave-role loops (e4m3, mixed, int8-score kernels) lag P V two blocks behind the scores, start with a step that has no
+    P V and end with a drain: every short key count -- 1 ... 3 blocks of 64, whole and ragged -- against exact attention on the
+    16-bit operands (a pipeline slip gives garbage, not a rounding error), padded query rows zero, untouched rows untouched."""
+    from vorta_amd import ops
+    rng = np.random.default_rng(7)
+    H, Sq, dtype = 2, 300, torch.bfloat16
+    for n_kv in (1, 40, 64, 65, 127, 128, 129, 192, 193, 200):
+        q, k, v = rng.standard_normal((H, Sq, 128)), rng.standard_normal((H, n_kv, 128)), rng.standard_normal((H, n_kv, 128))
+        qd, kd, vd16 = to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype)
+        want = O.dense_attention(qd.double().cpu().numpy(), kd.double().cpu().numpy(), vd16.double().cpu().numpy(),
+                                 kv_valid=n_kv, q_valid=Sq - 20)
+        v8, vd, _ = ops.fp8_quantize_v(vd16)
+        i8 = ops.i8_quantize_k(qd[:, :n_kv].contiguous(), kd)  # (q is only sampled for the centre and balance statistics)
+        cases = {"fp8pv": dict(q=qd, k=kd, v=v8, v_descale=vd), "i8pv": dict(q=qd, k=i8.k8, v=v8, v_descale=vd, i8=i8)}
+        for name, c in cases.items():
+            out = torch.full((H, Sq + 4, 128), 7.0, dtype=dtype, device=dev())
+            ops.attn_fwd(c.pop("q"), c.pop("k"), c.pop("v"), out, n_q=Sq, n_kv=n_kv, q_valid=Sq - 20, block_rows=block_rows, **c)
+            torch.cuda.synchronize()
+            got = out.float().cpu().numpy()
+            assert np.isfinite(got).all() and (got[:, Sq:] == 7.0).all() and (got[:, Sq - 20:Sq] == 0).all(), (name, n_kv)
+            assert rel_fro(got[:, :Sq - 20], want[:, :Sq - 20]) <= 0.08, (name, n_kv, rel_fro(got[:, :Sq - 20], want[:, :Sq - 20]))
