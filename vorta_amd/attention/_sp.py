@@ -204,8 +204,6 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     from .. import routed as _routed
     fp8 = _routed.DEFAULT_FP8 if not dense_only else False  # False, True (all e4m3), "fp8pv" (16-bit scores), "i8pv" (int8)
     auto8 = fp8 == "auto8"
-    if auto8 and (kv_splits > 1 or any(x is not None for x in local_parts) or dense_only):
-        auto8, fp8 = False, "fp8pv"  # (heads split by query range / key splits: the kernel that holds every family, for every head)
     f8, vwire = sb.fp8("i8pv" if auto8 else fp8) if fp8 else (None, None)
     if vwire is not None:
         vwire.lay = lay  # the layouts of one slot count share the buffers; the head offsets are this layer's

@@ -264,8 +264,6 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         if len(fp8_views) in (5, 7):  # int8 keys: + their I8Operands (row biases, query preparation, head scales)
             base.update(i8=fp8_views[4])
         if len(fp8_views) == 7:  # "auto8" on converted views: + the 16-bit keys and the heads' tail flags (sequence-parallel path)
-            if routing.partials or kv_splits and int(kv_splits) > 1:
-                raise ValueError("'auto8' does not take heads split by query range or key splits")
             base_tail = dict(q=fp8_views[0], k=fp8_views[5], v=fp8_views[2], scale=scale, v_descale=fp8_views[3])
             tail, fp8 = fp8_views[6], "auto8"
     elif fp8 == "i8pv":  # int8 scores: k -> int8 rows (centred, balanced, one scale per head) + a float bias per row, v -> e4m3;
@@ -279,8 +277,6 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         # P V in e4m3 with block-scaled probabilities either way.  The choice is made on the device (ops.i8_tail_flags over the
         # int8 keys, ops.split_heads over every expert's head list): two fused launches per layer, one of them usually over
         # empty lists (its workgroups exit in their first instruction), no host synchronisation
-        if routing.partials or kv_splits and int(kv_splits) > 1:
-            raise ValueError("'auto8' does not take heads split by query range or key splits (sequence-parallel placements)")
         vo, ko = fp8_operands if isinstance(fp8_operands, tuple) and len(fp8_operands) == 2 else (None, None)
         v8, vd, _ = ops.fp8_quantize_v(v3, out=vo)
         i8 = ops.i8_quantize_k(q3, k3, out=ko)
@@ -298,6 +294,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
 
     split_kw = dict(n_splits=int(kv_splits)) if kv_splits and int(kv_splits) > 1 else {}
     slot_of = routing.slot_args  # (expert, H) -> head_list / n_heads / n_heads_dev of a launch ("auto8": one of the two parts)
+    slot_part = lambda i, hl: dict(head_list=hl, n_heads=1, n_heads_dev=None)  # noqa: E731  (a head split by query range)
 
     # ---- expert 0: full attention (hunyuan.py:136-189 / wan.py:142-145) ----
     def expert_full():
@@ -306,7 +303,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
             calls.append(dict(base, out=o_e[0], n_q=S + T, n_kv=S + te, q_valid=S + te, tag="full", **split_kw,
                               q_rows=None if rm is None else rm[:S + T], kv_rows=None if rm is None else rm[:S + te],
                               flops=nheads(0) * 4.0 * (S + te) ** 2 * D, **slot_of(0, H)))
-        for hl, t0, t1 in routing.partials or ():
+        for pi, (hl, t0, t1) in enumerate(routing.partials or ()):
             # a head whose other query tokens another rank computes: every key, the query rows [t0, t1) of the VIDEO tokens;
             # the part that ends at the last video token also owns the head's text queries (they follow it in token order)
             if not (0 <= t0 < t1 <= S):
@@ -314,7 +311,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
             e1, v1 = (S + T, S + te) if (t1 == S and T > 0) else (t1, t1)
             part = dict(base, out=o_e[0], n_q=e1 - t0, n_kv=S + te, q_valid=v1 - t0, tag="full_part", **split_kw,
                         kv_rows=None if rm is None else rm[:S + te], flops=4.0 * (v1 - t0) * (S + te) * D,
-                        head_list=hl, n_heads=1, n_heads_dev=None)
+                        **slot_part(pi, hl))
             if rm is None:
                 part.update(q_row_offset=t0)
             else:
@@ -389,9 +386,11 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
         if concurrent:
             raise ValueError("'auto8' runs its two parts as fused grids (concurrent=False)")
         parts = [ops.split_heads(tail, **routing.slot_args(e, H)) if on else None for e, (_, on) in enumerate(experts)]
+        pparts = [ops.split_heads(tail, hl, 1) for hl, _, _ in routing.partials or ()]
         for which, b in ((0, base), (1, base_tail)):  # int8-score heads, then 16-bit-score heads
             base = b
             slot_of = lambda e, H_, which=which: parts[e][which]  # noqa: E731
+            slot_part = lambda i, hl, which=which: pparts[i][which]  # noqa: E731
             calls = [c for fn, on in experts if on for c in fn()]
             if fused:
                 ops.attn_fwd_batch(calls)
