@@ -184,7 +184,7 @@ def processor_level(cfg, mix, dev, dt, fp8):
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
     width = H * 128
-    vorta_amd.set_attention_precision(fp8 if fp8 in ("fp8pv", "i8pv") else "fp8" if fp8 else "native")
+    vorta_amd.set_attention_precision(fp8 if fp8 in ("fp8pv", "i8pv", "auto8") else "fp8" if fp8 else "native")
     gen = torch.Generator(device=dev).manual_seed(1234)
 
     def lin(i, o):
@@ -363,7 +363,7 @@ def main():
     from vorta_amd.ulysses.state import default_sp_groups, resolve_placement  # the processors' rules (vorta_amd/attention/_sp.py)
     args.placement = resolve_placement(args.placement, cfg["heads"], max(args.emulate_rank or args.gpus, 1))
     if args.sp_groups == "auto":
-        prec = {"fp8": True, "fp8pv": "fp8pv", "i8pv": "i8pv"}.get(cfg["dtype"], False)
+        prec = {"fp8": True, "fp8pv": "fp8pv", "i8pv": "i8pv", "auto8": "auto8"}.get(cfg["dtype"], False)
         args.sp_groups = default_sp_groups(cfg["heads"] // max(args.emulate_rank or args.gpus, 1), prec)
     args.sp_groups = max(1, int(args.sp_groups))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_rank:
@@ -406,8 +406,6 @@ def main():
 
     dt = torch.float16 if cfg["dtype"] == "fp16" else torch.bfloat16  # (the 8-bit paths take and return bf16)
     fp8 = True if cfg["dtype"] == "fp8" else (cfg["dtype"] if cfg["dtype"] in ("fp8pv", "i8pv", "auto8") else False)
-    if fp8 == "auto8" and (world > 1 or args.emulate_rank or args.level == "processor"):
-        raise SystemExit("--dtype auto8 (per-head choice between int8 and 16-bit scores) is a one-GPU, kernel-level line")
     # mixed precision: half of a layer's FLOPs run at the 16-bit rate, half at the e4m3 rate: harmonic mean of the peaks
     # (int8 scores run at the e4m3 MFMA rate: the all-8-bit peak)
     peak = PEAK_MFMA_FP8_TFLOPS if fp8 in (True, "i8pv", "auto8") else (2.0 / (1.0 / PEAK_MFMA_TFLOPS + 1.0 / PEAK_MFMA_FP8_TFLOPS)

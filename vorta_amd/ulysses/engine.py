@@ -937,11 +937,11 @@ class _RankState:
             for b in self.bufs[:3]:
                 b.normal_()
         self.f8 = self.vwire = self.i8 = None
-        if fp8 in ("fp8pv", "i8pv"):  # only v is e4m3, converted on the send side (it always travels as bytes); "i8pv": k is
+        if fp8 in ("fp8pv", "i8pv", "auto8"):  # only v is e4m3, converted on the send side (it always travels as bytes); "i8pv": k is
             # rounded to int8 on this side, slot group by slot group (q by the attention kernel)
             if not v_wire:
                 raise ValueError(f"precision '{fp8}' under sequence parallelism converts v on the send side (v_wire)")
-            if fp8 == "i8pv":
+            if fp8 in ("i8pv", "auto8"):
                 self.i8 = lay.i8_operands()
             buf8 = torch.zeros((lay.rows_total, lay.D), dtype=torch.uint8, device=lay.device)
             if loopback:
@@ -1060,10 +1060,12 @@ class UlyssesRoutedAttention:
 
         def attend(g0, g1, gi):
             views = None
-            if self.fp8 == "i8pv":  # k of the slot group that has landed -> int8; q as it landed; v arrived as e4m3
+            if self.fp8 in ("i8pv", "auto8"):  # k of the slot group that has landed -> int8; q as it landed; v arrived as e4m3
                 i8 = lay.i8_views(st.bufs, st.i8, slots=(g0, g1))
                 views = (q[g0:g1], i8.k8[g0:g1], lay.head_view(st.vwire.buf)[g0:g1], st.vwire.descale(g0, g1),
                          i8.heads(g0, g1))
+                if self.fp8 == "auto8":  # + the 16-bit keys and the group's tail flags: each head to the kernel that holds it
+                    views += (k[g0:g1], ops.i8_tail_flags(i8.k8[g0:g1], row_map=lay.row_map[:lay.S + lay.T]))
             elif self.fp8 == "fp8pv":  # 16-bit q, k as they landed; v arrived as e4m3
                 views = (q[g0:g1], k[g0:g1], lay.head_view(st.vwire.buf)[g0:g1], st.vwire.descale(g0, g1))
             elif self.fp8:  # the slot group that has landed is converted while the next one is in flight
