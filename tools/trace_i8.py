@@ -56,7 +56,7 @@ def one(i):
 def main():
     if len(sys.argv) > 1:
         return one(int(sys.argv[1]))
-    for i in (1, 2, 3, 4, 6, 7):
+    for i in (1, 2, 3, 4, 5, 6, 7):
         lib = os.path.join(ROOT, "vorta_amd", "csrc", f"libvorta_hip_tri{i}.so")
         if not os.path.exists(lib):
             print("missing", lib)
