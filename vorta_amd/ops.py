@@ -556,8 +556,8 @@ def i8_quantize_k(q: torch.Tensor, k: torch.Tensor, *, out: Optional[I8Operands]
 
 
 # "auto8": a head whose int8 keys have a root mean square below this many counts (the bulk of a heavy-tailed head rounds to
-# 0 / +-1 under one scale per head) runs with 16-bit scores instead: Student-t(3) keys sit at 0.5-2, every other input family of
-# tests/_fp8_inputs.py at 5 or more (white noise 26)
+# 0 / +-1 under one scale per head) runs with 16-bit scores instead: at full size Student-t(3) keys sit at 0.3-1.0, the outlier-weight
+# families of tests/_fp8_inputs.py (which int8 scores hold) at 4.1-4.8, every other family at 17-25 (profiles/r05_auto8_tail_statistic.txt)
 I8_TAIL_MIN_RMS = float(__import__("os").environ.get("VORTA_I8_TAIL_MIN_RMS", "3.2"))
 
 
