@@ -430,3 +430,43 @@ def test_auto8_relative_error_on_every_input_family():
         print(f"auto8 vs bf16, {name}: flagged heads {flags}, rel {rel:.4f}, PSNR {db:.1f} dB")
         assert rel <= I8_REL_GATE and db >= 40.0, (name, rel, db)
         assert flags == ([1, 1, 1] if name == "student_t3" else [0, 0, 0]), (name, flags)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_routed_attention_random_configs_8bit(seed):
+    """The routed op under "fp8pv", "i8pv" and "auto8" on random small geometries -- odd tile / window / group shapes, experts
+    without heads, text lengths, host- or device-resident routes, fused or serial launches: finite, padded text rows zero,
+    every head within 0.15 relative of the 16-bit kernels (an indexing slip is off by O(1)), and every head of "auto8" bit for
+    bit one of the other two."""
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, routed_attention
+    rng = np.random.default_rng(9100 + seed)
+    group = [(2, 3, 2), (3, 1, 2), (1, 2, 2), (2, 2, 1)][int(rng.integers(0, 4))]
+    tile = tuple(int(rng.integers(1, 4)) for _ in range(3))
+    latent = tuple(int(np.lcm(g, t)) * int(rng.integers(1, 4)) for g, t in zip(group, tile))
+    window = tuple(int(rng.choice([1, 3, 5])) for _ in range(3))
+    model = ("hunyuan", "wan")[int(rng.integers(0, 2))]
+    T = int(rng.integers(1, 20)) if model == "hunyuan" else 0
+    te = int(rng.integers(1, T + 1)) if T else 0
+    H = int(rng.integers(1, 7))
+    experts = rng.integers(0, 3, size=H)
+    Sv = latent[0] * latent[1] * latent[2]
+    q, k, v = (to_dev(rng.standard_normal((1, H, Sv + T, 128)), torch.bfloat16) for _ in range(3))
+    geom = RoutedGeometry(latent, tile, window, group, 0.5, dev())
+    host = HeadRouting.from_expert_ids(experts.tolist(), dev())
+    routing = host if rng.integers(0, 2) else HeadRouting.from_device(
+        host.lists, torch.tensor(host.counts_host, dtype=torch.int32, device=dev()))
+    kw = dict(model=model, text_len=T, text_valid=te, fused=bool(rng.integers(0, 2)))
+    desc = dict(seed=seed, model=model, latent=latent, tile=tile, window=window, group=group, T=T, te=te, experts=experts.tolist())
+    ref = routed_attention(q, k, v, routing, geom, fp8=False, **kw).float()
+    outs = {p: routed_attention(q, k, v, routing, geom, fp8=p, **kw) for p in ("fp8pv", "i8pv", "auto8")}
+    torch.cuda.synchronize()
+    for p, out in outs.items():
+        o = out.float()
+        assert torch.isfinite(o).all(), (p, desc)
+        if T:
+            assert (o[0, :, Sv + te:] == 0).all(), (p, desc)
+        for h in range(H):
+            rel = float((o[0, h] - ref[0, h]).norm() / ref[0, h].norm().clamp_min(1e-6))
+            assert rel <= 0.15, (p, h, rel, desc)
+    for h in range(H):
+        assert torch.equal(outs["auto8"][0, h], outs["i8pv"][0, h]) or torch.equal(outs["auto8"][0, h], outs["fp8pv"][0, h]), (h, desc)
