@@ -35,6 +35,10 @@ CONFIGS = {
     # authors' own benchmark shape (vorta/constants.py:8-12, scripts/hunyuan/train.sh:10-18)
     "hunyuan-117f": dict(model="hunyuan", latent=(30, 45, 80), heads=24, layers=60, fwd_per_step=1, text=256,
                          text_valid=96, tile=(6, 9, 8), window=(3, 3, 3), group=(2, 3, 2), rate=0.5, dtype="bf16"),
+    # BASELINE.json configs[0]: Wan-2.1 1.3B 49x320x512, --native_attention (scripts/wan/inference.py:154-163 -> wan.py:142-145):
+    # every head takes the dense expert (the mix is forced to all-full); its CPU leg runs IN FULL
+    "wan1.3b-49f": dict(model="wan", latent=(13, 20, 32), heads=12, layers=30, fwd_per_step=2, text=0, text_valid=0,
+                        tile=(13, 10, 8), window=(3, 3, 3), group=(1, 2, 2), rate=0.5, dtype="bf16", native_only=True),
     # BASELINE.json configs[1]
     "wan1.3b-81f": dict(model="wan", latent=(21, 30, 52), heads=12, layers=30, fwd_per_step=2, text=0, text_valid=0,
                         tile=(7, 6, 4), window=(3, 3, 3), group=(3, 3, 2), rate=0.5, dtype="bf16"),
@@ -83,7 +87,33 @@ def algorithmic_flops(cfg, experts):
     return n[0] * f_full + n[1] * f_low + n[2] * f_sl, dict(full=f_full, lowres=f_low, sliding=f_sl)
 
 
-def cpu_baseline(cfg, layer_ids):
+def cpu_baseline_full(cfg, cores, cpu_model, gpu_dtype, steps: int = 2):
+    """BASELINE.json configs[0] / BASELINE.md section 3: the --native_attention path of Wan-2.1 1.3B at 49x320x512 on the CPU, run
+    IN FULL -- `steps` denoising steps x 2 forwards (CFG) x 30 layers, every layer the dense attention of all 12 heads on its own
+    seeded post-RoPE q, k, v (torch-CPU SDPA, the call the reference makes at wan.py:142-145), nothing extrapolated."""
+    import torch.nn.functional as F
+    H, L, fwd = cfg["heads"], cfg["layers"], cfg["fwd_per_step"]
+    S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
+    dt = torch.bfloat16
+    sets = []
+    for i in range(2):
+        gen = torch.Generator().manual_seed(1234 + i)
+        sets.append(tuple(torch.randn((1, H, S, 128), generator=gen).to(dt) for _ in range(3)))
+    with torch.no_grad():
+        F.scaled_dot_product_attention(*sets[0])  # warm the dispatcher and the thread pool
+        t0 = time.perf_counter()
+        for _ in range(steps * fwd):
+            for l in range(L):
+                F.scaled_dot_product_attention(*sets[l % 2])
+        step_s = (time.perf_counter() - t0) / steps
+    return {"value": S * fwd / step_s, "unit": "video_tokens/s", "cores": int(cores), "kind": "full", "cpu_model": cpu_model,
+            "dtype": "bf16", "gpu_dtype": gpu_dtype, "step_s": round(step_s, 2),
+            "sample": f"the whole workload, nothing extrapolated: {steps} denoising steps x {fwd} forwards x {L} layers of dense "
+                      f"attention over {H} heads x S = {S} (torch-CPU SDPA, bf16, {cores} threads); the port of the path "
+                      "(oracle-checked torch-CPU restatement), not the reference's own Python"}
+
+
+def cpu_baseline(cfg, layer_ids, gpu_dtype="bf16"):
     """SURVEY.md §8(d) / BASELINE.md §3: the CPU restatement of the path timed on this host -- torch-CPU SDPA for the
     contractions, the oracle's index code (oracle/vorta_oracle.py: group tables + cosine ranking, tile-major order,
     clamped tile windows) for the coreset selection / pooling / unpooling and the sliding-tile key lists -- ONE head per
@@ -106,6 +136,8 @@ def cpu_baseline(cfg, layer_ids):
     hy = cfg["model"] == "hunyuan"
     T, te = (cfg["text"], cfg["text_valid"]) if hy else (0, 0)
     dt = torch.bfloat16
+    if cfg.get("native_only"):
+        return cpu_baseline_full(cfg, cores, cpu_model, gpu_dtype)
     gen = torch.Generator().manual_seed(0)
     q, k, v = (torch.randn((1, 1, S + T, 128), generator=gen).to(dt) for _ in range(3))
     sdpa = lambda a, b, c: F.scaled_dot_product_attention(a, b, c)
@@ -156,7 +188,7 @@ def cpu_baseline(cfg, layer_ids):
     step_s = layer_s * cfg["fwd_per_step"]
     tokens = S * cfg["fwd_per_step"]
     return {"value": tokens / step_s, "unit": "video_tokens/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model,
-            "dtype": "bf16", "step_s_extrapolated": round(step_s, 1),
+            "dtype": "bf16", "gpu_dtype": gpu_dtype, "step_s_extrapolated": round(step_s, 1),
             "seconds_per_head": {k_: round(v_, 3) for k_, v_ in times.items()},
             "sample": f"one head per expert at the full sequence (S = {S}, text {T}/{te}): torch-CPU SDPA (bf16, "
                       f"{cores} threads) + the oracle's index code for coreset ranking / pooling / unpooling and the "
@@ -184,7 +216,8 @@ def processor_level(cfg, mix, dev, dt, fp8):
     S = cfg["latent"][0] * cfg["latent"][1] * cfg["latent"][2]
     hy = cfg["model"] == "hunyuan"
     width = H * 128
-    vorta_amd.set_attention_precision(fp8 if fp8 in ("fp8pv", "i8pv", "auto8") else "fp8" if fp8 else "native")
+    vorta_amd.set_attention_precision(fp8 if fp8 in ("fp8pv", "i8pv", "auto8") else "fp8" if fp8 else "native",
+                                      measurement_only=True)
     gen = torch.Generator(device=dev).manual_seed(1234)
 
     def lin(i, o):
@@ -275,6 +308,73 @@ def processor_level(cfg, mix, dev, dt, fp8):
     return one_step, fingerprint_tensor, layer_ids, info
 
 
+XGMI_LINK_GBPS = 153.0  # per direction and link, 7 links per GPU (MI355X_MICROARCH.md)
+
+
+def exchange_breakdown(sp, cfg, args, ms_per_step, barrier, dist, dev, world, fp8, backend, reps: int = 2):
+    """Two more passes over the same layers, each bracketed like the timed region (barrier + synchronize, MAX over ranks):
+      * exchange only -- staging pass, every slot group's all_to_all_single in and back, text all-gather, un-permute, NO attention:
+        `exchange_ms_per_layer`, and with the bytes a rank puts on each link, the rate the links reached;
+      * compute only -- the same layers with the layouts in loopback (every local pass, no transfer): `compute_ms_per_layer`.
+    `exposed_exchange_ms_per_layer` = timed step / layers - compute only: what of the exchange the step did NOT hide behind
+    attention (with one slot group: all of it; with several: what is left).  Bytes are counted from the layouts: per layer and
+    tensor a rank sends `heads of peer j x S/P x D` elements to peer j over their link."""
+    L, fwd = cfg["layers"], cfg["fwd_per_step"]
+    n_layers = L * fwd
+
+    def timed(fn):
+        fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) * 1e3 / reps / n_layers
+
+    def all_layers(**kw):
+        for _ in range(fwd):
+            for l in range(L):
+                sp.layer(l, **kw)
+
+    ex_ms = timed(lambda: all_layers(exchange_only=True))
+    lays = list({id(x): x for x in sp.lays}.values())
+    for x in lays:
+        x.loopback = True
+    try:
+        comp_ms = timed(all_layers)
+    finally:
+        for x in lays:
+            x.loopback = False
+    esz = 2
+    v_bytes = 1 if (fp8 and not args.no_v_wire) or fp8 in ("fp8pv", "i8pv", "auto8") else esz
+    link_in = link_out = egress = 0.0
+    for lay in sp.lays:
+        peers = [j for j in range(lay.P) if j != lay.rank]
+        chunk = lambda heads: heads * lay.Sl * lay.D
+        link_in += max(chunk(lay.counts[j]) for j in peers) * (2 * esz + v_bytes)  # q, k, v to the peer holding most heads
+        link_out += chunk(lay.Hl) * esz  # o back: this rank's slots to every peer
+        egress += sum(chunk(lay.counts[j]) for j in peers) * (2 * esz + v_bytes) + len(peers) * chunk(lay.Hl) * esz
+    link_bytes = (link_in + link_out) / len(sp.lays)
+    rate = link_bytes / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else 0.0
+    step_ms_per_layer = ms_per_step / n_layers
+    return {"exchange_ms_per_layer": round(ex_ms, 4), "compute_ms_per_layer": round(comp_ms, 4),
+            "step_ms_per_layer": round(step_ms_per_layer, 4),
+            "exposed_exchange_ms_per_layer": round(max(step_ms_per_layer - comp_ms, 0.0), 4),
+            "hidden_fraction_of_exchange": round(1.0 - max(step_ms_per_layer - comp_ms, 0.0) / ex_ms, 3) if ex_ms > 0 else None,
+            "bytes_per_link_per_layer": int(link_bytes), "bytes_per_link_per_16bit_tensor": int(link_bytes * esz / (3 * esz + v_bytes)),
+            "egress_bytes_per_rank_per_layer": int(egress / len(sp.lays)), "v_bytes_per_element_on_the_wire": v_bytes,
+            "link_GBps_in_exchange_only": round(rate, 1), "frac_of_link_peak": round(rate / XGMI_LINK_GBPS, 3),
+            "aggregate_egress_GBps": round(egress / len(sp.lays) / (ex_ms * 1e-3) / 1e9, 1) if ex_ms > 0 else 0.0,
+            "frac_of_7_links": round(egress / len(sp.lays) / (ex_ms * 1e-3) / 1e9 / (7 * XGMI_LINK_GBPS), 3) if ex_ms > 0 else 0.0,
+            "link_peak_GBps": XGMI_LINK_GBPS, "slot_groups": args.sp_groups,
+            "what": f"rank 0's layouts, mean over {len(sp.lays)} layers; times = MAX over ranks of {reps} passes, barrier-bracketed; "
+                    "exchange only = staging + all_to_all_single in and back + text all-gather, no attention; compute only = the "
+                    "layers in loopback (no transfer)" + ("; gloo rehearsal: host-staged messages, the rates say nothing about xGMI"
+                                                           if backend != "nccl" else "")}
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
     <same arguments>` as a child (one rank per GPU, rendezvous on 127.0.0.1 at a free port) and pass its stdout / stderr
@@ -293,6 +393,142 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def supervise(args) -> int:
+    """One of the N processes a launcher (torch.distributed.run) started for a multi-GPU run, acting as a GPU-FREE supervisor: it
+    runs the measurement in a CHILD process (same arguments, same rank environment; never an exec) and, when ANY rank's first
+    attempt fails -- a self-check mismatch, an RCCL error, a collective that never completes -- starts ONE fresh child per rank
+    with `--conservative` (auto placement, one slot group, v in 16 bits: the oldest form of the exchange), whose line carries
+    `"fallback": "conservative"` and `"first_attempt_error"`.  The supervisors agree through the launcher's own TCPStore
+    (TORCHELASTIC_USE_AGENT_STORE; each attempt's ranks rendezvous under their own prefix of it, `attempt_store`), so a
+    failed first attempt cannot leave a multi-GPU run without a number.  Rank 0's supervisor relays its child's stdout; the JSON
+    lines of a failed attempt that is followed by a fallback go to stderr, so stdout carries ONE JSON line."""
+    import subprocess
+    from datetime import timedelta
+
+    from torch.distributed import PrefixStore, TCPStore
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    store = PrefixStore("/vorta_bench_supervisor", TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world,
+                                                            False, timedelta(seconds=120)))
+    cap_s = float(os.environ.get("VORTA_BENCH_ATTEMPT_TIMEOUT_S", "1500"))
+    current = {}
+
+    def on_term(signum, frame):  # the launcher ends its processes: end exactly the child this supervisor started, then leave
+        p_ = current.get("proc")
+        if p_ is not None and p_.poll() is None:
+            p_.kill()
+        os._exit(128 + signum)
+    import signal
+    signal.signal(signal.SIGTERM, on_term)
+
+    def attempt(n: int, extra, first_error):
+        env = dict(os.environ, VORTA_BENCH_WORKER="1", VORTA_BENCH_ATTEMPT=str(n))  # (`attempt_store`: a namespace per attempt)
+        if first_error is not None:
+            env["VORTA_BENCH_FIRST_ATTEMPT_ERROR"] = first_error[:600]
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else None, text=True)
+        current["proc"] = proc
+        held = []
+        if rank == 0:
+            import threading
+
+            def pump():
+                for line in proc.stdout:
+                    if line.startswith("{"):
+                        held.append(line.rstrip("\n"))
+                    else:
+                        sys.stdout.write(line)
+                        sys.stdout.flush()
+            th = threading.Thread(target=pump, daemon=True)
+            th.start()
+        t0 = time.perf_counter()
+        killed = False
+        while proc.poll() is None:
+            time.sleep(0.5)
+            # another rank's attempt has failed: this rank's child can only be waiting for it -- give it a moment to leave by
+            # itself (its process group's watchdog), then end exactly this child
+            if not killed and (store.check([f"a{n}/failed"]) and time.perf_counter() - float(store.get(f"a{n}/failed")) > 20.0
+                               or time.perf_counter() - t0 > cap_s):
+                proc.kill()
+                killed = True
+        rc = proc.returncode
+        if rank == 0:
+            th.join(10.0)
+        if rc != 0 and not store.check([f"a{n}/failed"]):
+            store.set(f"a{n}/failed", repr(time.perf_counter()))  # (one host: the supervisors share a clock)
+        store.set(f"a{n}/rc/{rank}", str(rc))
+        store.wait([f"a{n}/rc/{j}" for j in range(world)], timedelta(seconds=cap_s + 120))
+        rcs = [int(store.get(f"a{n}/rc/{j}")) for j in range(world)]
+        return rc, rcs, held
+
+    rc, rcs, held = attempt(0, [], None)
+    if all(x == 0 for x in rcs) or args.conservative or args.no_fallback:
+        if rank == 0:
+            for l in held:
+                print(l, flush=True)
+        return rc if rc != 0 else max(rcs, key=abs)
+    first_error = f"exit codes {rcs}"
+    if rank == 0:
+        errs = [l for l in held if l.startswith('{"error"')]
+        if errs:
+            try:
+                first_error = json.loads(errs[-1]).get("error", first_error) + f" (exit codes {rcs})"
+            except ValueError:
+                pass
+        for l in held:
+            print("[bench attempt 0] " + l, file=sys.stderr, flush=True)
+        print(f"[bench] first attempt failed ({first_error}); one fresh --conservative child per rank", file=sys.stderr, flush=True)
+        store.set("a0/error", first_error)
+    else:
+        store.wait(["a0/error"], timedelta(seconds=60))
+        first_error = store.get("a0/error").decode()
+    rc, rcs, held = attempt(1, ["--conservative"], first_error)
+    if rank == 0:
+        for l in held:
+            print(l, flush=True)
+    return rc if rc != 0 else max(rcs, key=abs)
+
+
+def attempt_store(attempt: int, world: int, timeout):
+    """init_process_group arguments that give every ATTEMPT of a supervised run its own rendezvous namespace in the launcher's
+    TCPStore (torch 2.10 hands all processes of a launch the same un-prefixed store: a second process group of the same ranks
+    would read the first one's stale addresses and connect to the dead).  Without the launcher's store: env:// as it is."""
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() != "true":
+        return {}
+    from torch.distributed import PrefixStore, TCPStore
+    store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, False, timeout)
+    return dict(store=PrefixStore(f"/vorta_bench/attempt_{attempt}", store), rank=int(os.environ["RANK"]), world_size=world)
+
+
+def stub_worker(args, rank: int, world: int, attempt: int) -> int:
+    """CPU stand-in of a worker for the supervisor's rehearsal (VORTA_BENCH_STUB = comma-separated behaviours of the FIRST attempt:
+    "fail" every rank exits 3 after a collective, "fail0" only rank 0 raises while the others wait in a collective, "hang1" rank 1
+    never joins): a real gloo process group per attempt (its own rendezvous prefix), one all-reduce, ONE JSON line from rank 0."""
+    import torch.distributed as dist
+    from datetime import timedelta
+    how = os.environ["VORTA_BENCH_STUB"].split(",") if attempt == 0 and not args.conservative else []
+    if "hang1" in how and rank == 1:
+        time.sleep(3600)
+    pg_timeout = timedelta(seconds=float(os.environ.get("VORTA_BENCH_TIMEOUT_S", "120")))
+    dist.init_process_group("gloo", timeout=pg_timeout, **attempt_store(attempt, world, pg_timeout))
+    if "fail0" in how and rank == 0:
+        print(json.dumps({"error": "stub: rank 0 failed before the collective", "n_gpus": world}), flush=True)
+        os._exit(1)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if "fail" in how:
+        if rank == 0:
+            print(json.dumps({"error": "stub: exchange self-check failed", "n_gpus": world}), flush=True)
+        dist.destroy_process_group()
+        return 3
+    if rank == 0:
+        print("[stub] a line that is not JSON", flush=True)
+        print(json.dumps({"metric": "stub", "value": float(t.item()), "n_gpus": world, "conservative": bool(args.conservative),
+                          **({"fallback": "conservative", "first_attempt_error": os.environ.get("VORTA_BENCH_FIRST_ATTEMPT_ERROR", "")}
+                             if attempt > 0 else {})}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     # the host driver only supports dmabuf IPC: must be in the environment before HIP / HSA initialise
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -308,10 +544,11 @@ def main():
                          "inside the step); i8pv: scores on the int8 MFMA with one scale per row (k converted inside the step, q "
                          "by the attention kernel), P V in e4m3")
     ap.add_argument("--qkv-sets", type=int, default=2, help="distinct synthetic Q/K/V sets cycled over the layers")
-    ap.add_argument("--sp-groups", default=os.environ.get("VORTA_SP_GROUPS", "auto"),
+    ap.add_argument("--sp-groups", default=os.environ.get("VORTA_SP_GROUPS", "1"),
                     help="N>1: exchange the local heads in this many slot groups so that the exchange of one group "
-                         "overlaps the attention of another (1 = exchange, then attend); auto (default) = "
-                         "vorta_amd.ulysses.state.default_sp_groups: 1 at 3 heads per rank, 2-3 at 5, chosen on an emulated wire")
+                         "overlaps the attention of another (1 = exchange, then attend: the default until a node run has "
+                         "measured the links); auto = vorta_amd.ulysses.state.default_sp_groups: 1 at 3 heads per rank, 2-3 at "
+                         "5, ranked on an EMULATED wire (profiles/r05_sp_groups_emulated.txt)")
     ap.add_argument("--emulate-rank", type=int, default=0, metavar="P",
                     help="on ONE GPU: the compute side of a P-way Ulysses step -- every layer as the rank that carries the "
                          "largest expert cost in THAT layer (a P-GPU step waits for its slowest rank layer by layer): its heads "
@@ -329,8 +566,12 @@ def main():
                          "whose heads leave the chip under one round of workgroups (small models on many ranks); changes the "
                          "summation order, so never on by default")
     ap.add_argument("--conservative", action="store_true",
-                    help="N>1 fallback: --placement even --sp-groups 1, one all_to_all_single per tensor "
-                         "(VORTA_SP_TRANSPORT=a2a), v exchanged in 16 bits -- the oldest, most exercised form of the exchange")
+                    help="N>1 fallback: --placement auto --sp-groups 1 (one all_to_all_single per tensor for the whole layer), v "
+                         "exchanged in 16 bits -- the oldest, most exercised form of the exchange; what a failed first attempt "
+                         "falls back to by itself")
+    ap.add_argument("--no-fallback", action="store_true",
+                    help="N>1 under a launcher: a failed first attempt is final (default: every rank starts one fresh "
+                         "--conservative child and its line is labelled \"fallback\": \"conservative\")")
     ap.add_argument("--no-selfcheck", action="store_true",
                     help="N>1: skip the exchange self-check that runs before the warm-up (integer-tagged q,k,v through layer "
                          "0's exchange with identity attention, compared exactly on every rank)")
@@ -357,9 +598,10 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.dtype:
         cfg["dtype"] = args.dtype
-    if args.conservative:  # before vorta_amd.ulysses.engine reads the transport switch, and inherited by the child ranks
+    if cfg.get("native_only"):  # --native_attention: the dense expert for every head
+        args.mix = "all-full"
+    if args.conservative:
         args.placement, args.sp_groups, args.no_v_wire = "auto", 1, True  # (auto = even wherever even exists)
-        os.environ["VORTA_SP_TRANSPORT"] = "a2a"
     from vorta_amd.ulysses.state import default_sp_groups, resolve_placement  # the processors' rules (vorta_amd/attention/_sp.py)
     args.placement = resolve_placement(args.placement, cfg["heads"], max(args.emulate_rank or args.gpus, 1))
     if args.sp_groups == "auto":
@@ -375,6 +617,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if (world > 1 and os.environ.get("VORTA_BENCH_WORKER") != "1"
+            and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"):
+        # started by torch.distributed.run (the driver's N > 1 command, or `self_launch` above): this process stays GPU-free
+        # and supervises a child; without the launcher's store (another launcher) the process is the worker itself
+        sys.exit(supervise(args))
+    attempt = int(os.environ.get("VORTA_BENCH_ATTEMPT", "0"))
+    if os.environ.get("VORTA_BENCH_STUB"):  # tests/test_bench_host.py: the supervisor's protocol on CPU ranks, no GPU anywhere
+        sys.exit(stub_worker(args, rank, world, attempt))
     # VORTA_BENCH_BACKEND=gloo: 1-GPU rehearsal of the N>1 code path (all ranks share cuda:0, host-staged
     # messages); the driver's multi-GPU runs use RCCL ("nccl"), one rank per GPU
     backend = os.environ.get("VORTA_BENCH_BACKEND", "nccl")
@@ -388,9 +638,9 @@ def main():
         from datetime import timedelta
         pg_timeout = timedelta(seconds=float(os.environ.get("VORTA_BENCH_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout, **attempt_store(attempt, world, pg_timeout))
         else:
-            dist.init_process_group(backend, timeout=pg_timeout)
+            dist.init_process_group(backend, timeout=pg_timeout, **attempt_store(attempt, world, pg_timeout))
 
     # what the process group saw: one entry per rank (proof that N ranks on N devices ran the step over RCCL)
     props = torch.cuda.get_device_properties(dev_index)
@@ -477,7 +727,8 @@ def main():
     # node, gloo in the one-GPU rehearsals): vorta_amd/ulysses/engine.py exchange_selfcheck on layer 0's placement
     selfcheck = None
     if world > 1 and not args.no_selfcheck:
-        selfcheck = sp.selfcheck(0, break_order=os.environ.get("VORTA_SP_SELFCHECK_BREAK") == "1")
+        # (VORTA_SP_SELFCHECK_BREAK=1, tests only: breaks the FIRST attempt, so the fallback has something to recover from)
+        selfcheck = sp.selfcheck(0, break_order=os.environ.get("VORTA_SP_SELFCHECK_BREAK") == "1" and attempt == 0)
         if not selfcheck["ok"]:
             if rank == 0:
                 print(json.dumps({"error": "exchange self-check failed: the head exchange did not deliver the expected rows",
@@ -517,6 +768,11 @@ def main():
         dist.all_reduce(fingerprint)
     fingerprint = int(fingerprint.item())
     tokens = S * cfg["fwd_per_step"]
+
+    # ---- N > 1: what the exchange costs and how much of it the step hides (after the timed region, never part of `value`) ----
+    exchange = None
+    if world > 1:
+        exchange = exchange_breakdown(sp, cfg, args, ms_per_step, barrier, dist, dev, world, fp8, backend)
 
     # ---- roofline of the dominant kernel symbol (largest share of the timed region) ----
     summ = tl.summary()  # keyed by (expert tag, kernel symbol)
@@ -588,6 +844,9 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "backend": (backend if world > 1 else None), "output_fingerprint": fingerprint,
         **({"exchange_selfcheck": selfcheck} if selfcheck is not None else {}),
+        **({"fallback": "conservative", "first_attempt_error": os.environ.get("VORTA_BENCH_FIRST_ATTEMPT_ERROR", "")}
+           if attempt > 0 else {}),
+        **({"exchange": exchange} if exchange is not None else {}),
         "process_group": {"world_size": dist.get_world_size() if world > 1 else 1,
                           "backend": dist.get_backend() if world > 1 else None,
                           "distinct_devices": len({(r["host"], r["uuid"] or r["device"]) for r in ranks_seen}),
@@ -658,7 +917,7 @@ def main():
         borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, layer_ids)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not emu and proc_info is None:
-            res["cpu_baseline"] = cpu_baseline(cfg, layer_ids)
+            res["cpu_baseline"] = cpu_baseline(cfg, layer_ids, cfg["dtype"])
         abandoned = res.pop("_abandoned_thread", False)
         print(json.dumps(res), flush=True)
         if abandoned:  # the line is out; do not wait for a thread that may never return
@@ -719,14 +978,19 @@ def borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, layer_ids=Non
             # could HANG rather than fail, and a context measurement must not be able to cost the bench line
             import threading
             left = budget_s - (time.perf_counter() - t_start)
+            # the thread writes into a dict of its OWN: an abandoned thread that finishes late must not touch `res`
+            # while the main thread serialises it
+            private = {"config": {}, "ms_per_step": res["ms_per_step"]}
             th = threading.Thread(target=borrowed_routed, daemon=True,
-                                  args=(cfg, S, te, L, layer_ids, q, k, v, ms_sdpa, timed, res, left, dev))
+                                  args=(cfg, S, te, L, layer_ids, q, k, v, ms_sdpa, timed, private, left, dev))
             th.start()
             th.join(max(left, 1.0) + 60.0)
             if th.is_alive():
                 res["config"]["step_ms_if_borrowed_routed"] = None
                 res["config"]["borrowed_routed_error"] = "no answer within the deadline (torch.compile of flex_attention); abandoned"
                 res["_abandoned_thread"] = True
+            else:
+                res["config"].update(private["config"])
     except Exception as exc:  # context only: never let it cost the bench line
         roofline["library_sdpa_tflops"] = None
         roofline["library_sdpa_error"] = f"{type(exc).__name__}: {exc}"[:200]

@@ -2,8 +2,9 @@
 
 The one-GPU box cannot hold two RCCL ranks (RCCL refuses two ranks on one device: "invalid usage"), and the gloo
 rehearsals take the host-staged branch of the exchange.  This run takes the DIRECT branch -- the calls the driver's 8-GPU
-run makes: `all_to_all_single(..., async_op=True)` with equal and with per-rank splits, the MAX / SUM all-reduces of the
-8-bit paths' statistics, the text all-gather -- on a world of one, where every collective is a copy RCCL performs on its own
+run makes: `all_to_all_single(..., async_op=True)` with equal and with per-rank splits, for the whole tensor and per slot
+group (round 6: the only transport), the MAX / SUM all-reduces of the 8-bit paths' statistics, the text all-gather -- on a
+world of one, where every collective is a copy RCCL performs on its own
 stream.  What it proves: the dtypes and shapes are ones RCCL accepts, the handles are waited for where the consumers need the
 data (a missing wait shows as a mismatch against the loopback run, which does the same copies in stream order), and the
 self-check passes on this transport.  What it cannot prove: anything about peers."""
@@ -49,6 +50,7 @@ def main():
                      ("i8pv", torch.bfloat16)):
         for placement, groups in (("even", 1), ("even", 2), ("uneven", 2), ("split", 1)):
             outs = {}
+            a2a_before = calls.get("all_to_all_single", 0)
             for loopback in (True, False):
                 sp = ulysses.UlyssesRoutedAttention(cfg, layer_ids, per_head, dev, dt, 0, 1, groups=groups, loopback=loopback,
                                                     fp8=prec, placement=placement)
@@ -64,7 +66,8 @@ def main():
             finite = all(bool(torch.isfinite(a[0].float()).all()) for a in outs[False][0])
             case = {"precision": str(prec), "dtype": str(dt), "placement": placement, "groups": groups,
                     "selfcheck_ok": bool(outs[False][1]["ok"]), "failed": outs[False][1].get("failed", []),
-                    "equals_loopback": bool(same), "finite": finite}
+                    "equals_loopback": bool(same), "finite": finite,
+                    "a2a_calls": calls.get("all_to_all_single", 0) - a2a_before}
             ok = ok and case["selfcheck_ok"] and same and finite
             report["cases"].append(case)
     dist.barrier()

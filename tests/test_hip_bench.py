@@ -52,33 +52,52 @@ def test_bench_two_rank_rehearsal(dtype):
     sc = j["exchange_selfcheck"]
     assert sc["ok"] is True and sc["bytes"] > 0 and sc["ms"] > 0 and sc["failed_on_this_rank"] == []
     assert ("v as e4m3" in sc["what"]) == (dtype == "fp8")
+    # the N > 1 line explains itself: what the exchange costs alone, what the step hid, bytes per link against the link's peak
+    ex = j["exchange"]
+    assert {"exchange_ms_per_layer", "compute_ms_per_layer", "exposed_exchange_ms_per_layer", "bytes_per_link_per_layer",
+            "bytes_per_link_per_16bit_tensor", "frac_of_link_peak", "frac_of_7_links", "egress_bytes_per_rank_per_layer"} <= set(ex)
+    assert ex["exchange_ms_per_layer"] > 0 and ex["compute_ms_per_layer"] > 0 and ex["bytes_per_link_per_layer"] > 0
+    # tiny: S = 1728, 2 ranks, 4 heads to the peer: 4 x 864 x 128 x 2 B per 16-bit tensor
+    assert ex["bytes_per_link_per_16bit_tensor"] == 4 * 864 * 128 * 2 and ex["v_bytes_per_element_on_the_wire"] == (1 if dtype == "fp8" else 2)
+    assert "fallback" not in j
 
 
-def test_bench_selfcheck_catches_a_misordered_exchange_and_conservative_line():
-    """VORTA_SP_SELFCHECK_BREAK=1 (test-only): the last rank swaps two heads of its copy of the placement -> the run must stop
-    before the warm-up with ONE JSON error line and a non-zero exit code.  --conservative: even placement, one slot group,
-    one all_to_all_single per tensor, v in 16 bits -- same layer output as the default exchange."""
+def test_bench_selfcheck_catches_a_misordered_exchange_and_falls_back_to_a_conservative_child():
+    """VORTA_SP_SELFCHECK_BREAK=1 (test-only): the last rank swaps two heads of its copy of the placement in the FIRST attempt.
+    With --no-fallback the run stops before the warm-up with ONE JSON error line and a non-zero exit code.  By default every
+    rank's GPU-free supervisor (bench.py `supervise`) starts one fresh --conservative child: exit code 0, ONE JSON line on
+    stdout, labelled `"fallback": "conservative"` with the first attempt's error; the failed attempt's lines go to stderr.
+    --conservative: auto placement, one slot group, v in 16 bits -- same layer output as the default exchange."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     base = [sys.executable, "bench.py", "--gpus", "2", "--config", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
-    r = subprocess.run(base, cwd=ROOT, env=dict(env, VORTA_SP_SELFCHECK_BREAK="1"), capture_output=True, text=True, timeout=900)
+    r = subprocess.run(base + ["--no-fallback"], cwd=ROOT, env=dict(env, VORTA_SP_SELFCHECK_BREAK="1"), capture_output=True,
+                       text=True, timeout=900)
     assert r.returncode != 0
     err = [l for l in r.stdout.splitlines() if l.startswith('{"error"')]
     assert len(err) == 1 and not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')], r.stdout[-2000:]
     e = json.loads(err[0])
     assert e["exchange_selfcheck"]["ok"] is False and "self-check" in e["error"]
-    fps = {}
+    # the same broken first attempt, fallback on (the default): the run comes back with a number, and says how
+    r = subprocess.run(base, cwd=ROOT, env=dict(env, VORTA_SP_SELFCHECK_BREAK="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1, r.stdout[-2000:]
+    j = _line(r.stdout)
+    assert j["fallback"] == "conservative" and "self-check" in j["first_attempt_error"] and j["exchange_selfcheck"]["ok"] is True
+    assert "[bench attempt 0]" in r.stderr and "auto" not in j["config"]["parallelism"].split("head placement")[0][-8:]
+    fps = {("fallback", "bf16"): j["output_fingerprint"]}
     for name, extra in (("default", []), ("conservative", ["--conservative"])):
         for dtype in ("bf16", "fp8"):
             r = subprocess.run(base + ["--dtype", dtype] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, (name, dtype, r.stdout[-1500:], r.stderr[-3000:])
             j = _line(r.stdout)
-            assert j["exchange_selfcheck"]["ok"] is True
+            assert j["exchange_selfcheck"]["ok"] is True and "fallback" not in j
             fps[(name, dtype)] = j["output_fingerprint"]
             if name == "conservative":
-                assert "even head placement" in j["config"]["parallelism"] and j["switches"]["env"]["VORTA_SP_TRANSPORT"] == "a2a"
+                assert "even head placement" in j["config"]["parallelism"]
                 assert "v as e4m3" not in j["exchange_selfcheck"]["what"]
-    assert fps[("default", "bf16")] == fps[("conservative", "bf16")] != 0 and fps[("default", "fp8")] == fps[("conservative", "fp8")] != 0
+    assert fps[("default", "bf16")] == fps[("conservative", "bf16")] == fps[("fallback", "bf16")] != 0
+    assert fps[("default", "fp8")] == fps[("conservative", "fp8")] != 0
 
 
 def test_bench_plain_command_launches_its_ranks_and_fp8_exchange_variants_agree():
@@ -155,22 +174,21 @@ def test_bench_two_rank_rehearsal_with_heads_split_by_query_range():
 def test_bench_three_rank_rehearsal_heads_not_divisible():
     """3 ranks sharing the GPU (gloo, host-staged): 8 heads do not divide by 3 -- the reference's reshard and the equal-count
     placement both refuse that -- but head counts that follow the routes place them (3 + 3 + 2 and the like).  One collective
-    per tensor with per-rank split sizes and grouped send / recv give the same layer, 16-bit and e4m3."""
+    per tensor with per-rank split sizes, for the whole layer and per slot group, give the same layer, 16-bit and e4m3."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(VORTA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     base = [sys.executable, "bench.py", "--gpus", "3", "--config", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
     for dtype in ("bf16", "fp8"):
         fps = {}
-        for transport in ("a2a", "p2p"):
-            r = subprocess.run(base + ["--dtype", dtype], cwd=ROOT, env=dict(env, VORTA_SP_TRANSPORT=transport),
+        for groups in ("1", "2"):  # one collective per tensor with per-rank split sizes, for the layer and per slot group
+            r = subprocess.run(base + ["--dtype", dtype, "--sp-groups", groups], cwd=ROOT, env=env,
                                capture_output=True, text=True, timeout=900)
-            assert r.returncode == 0, (dtype, transport, r.stdout[-1500:], r.stderr[-3000:])
+            assert r.returncode == 0, (dtype, groups, r.stdout[-1500:], r.stderr[-3000:])
             j = _line(r.stdout)
             assert j["n_gpus"] == 3 and j["process_group"]["world_size"] == 3 and "uneven" in j["config"]["parallelism"]
             assert j["exchange_selfcheck"]["ok"] is True and "head counts" in j["exchange_selfcheck"]["what"]
-            assert j["switches"]["env"].get("VORTA_SP_TRANSPORT") == transport
-            fps[transport] = j["output_fingerprint"]
-        assert fps["a2a"] == fps["p2p"] != 0, (dtype, fps)
+            fps[groups] = j["output_fingerprint"]
+        assert fps["1"] == fps["2"] != 0, (dtype, fps)
     r = subprocess.run(base + ["--placement", "even"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0  # H % P != 0: the equal-count placement has no answer
 

@@ -793,6 +793,46 @@ def test_routed_vs_native_attention_operator_psnr(mix):
     assert 5.0 < per["coreset"] < 60.0 and 5.0 < per["sliding-tile"] < 60.0
 
 
+def test_routed_vs_native_attention_on_structured_inputs():
+    """north_star "PSNR >= 40 dB vs --native_attention", at the operator, on inputs WITH the structure the method assumes
+    (tests/_structured_inputs.py: sliding-tile heads whose attention is local at a third of a tile, coreset heads whose
+    window tokens are duplicates, white noise of share `noise` on top; full-attention heads white noise) -- the stand-in for
+    a trained router, which the offline image cannot have (hunyuan.py:562-605).  Where the 22 dB white-noise floor lifts:
+    >= 40 dB per expert and for the whole operator up to 5 % noise, decaying to the floor as the structure is drowned; with the
+    structures SWAPPED between the experts (a router that chose wrongly) the experts stay near the floor.  The table is
+    printed (tools/structured_psnr.py writes it at full size into profiles/)."""
+    import bench
+    from _structured_inputs import structured_layer
+    from vorta_amd.routed import HeadRouting, RoutedGeometry, dense_attention, routed_attention
+    latent, tile, group = (12, 24, 16), (3, 6, 4), (3, 3, 2)
+    H = 12
+    experts = [int(e) for e in bench.layer_experts(dict(heads=H), "uniform", 0)]
+    geom = RoutedGeometry(latent, tile, WINDOW, group, 0.5, dev())
+    route = HeadRouting.from_expert_ids(experts, dev())
+    psnr = lambda a, b: 10 * math.log10(((b.float().max() - b.float().min()).item() ** 2) / max(((a.float() - b.float()) ** 2).mean().item(), 1e-30))
+    table = {}
+    for matched in (True, False):
+        for noise in (0.0, 0.05, 0.1, 0.25, 0.5, 1.0):
+            gen = torch.Generator(device=dev()).manual_seed(123)
+            q, k, v = (x.to(torch.bfloat16) for x in structured_layer(latent, experts, tile, group, noise, gen, dev(), matched=matched))
+            out = routed_attention(q, k, v, route, geom, model="wan")
+            ref = dense_attention(q, k, v)
+            per = {name: psnr(out[0, [h for h in range(H) if experts[h] == e]], ref[0, [h for h in range(H) if experts[h] == e]])
+                   for e, name in enumerate(("full", "coreset", "sliding-tile"))}
+            table[(matched, noise)] = (psnr(out, ref), per)
+            print(f"routed vs native, structured inputs ({'matched' if matched else 'SWAPPED'}), noise {noise:4.2f}: whole op "
+                  f"{table[(matched, noise)][0]:6.2f} dB; per expert {dict((n, round(p, 1)) for n, p in per.items())}")
+    for noise in (0.0, 0.05):  # the bar, where the method's premise holds
+        whole, per = table[(True, noise)]
+        assert whole >= 40.0 and per["coreset"] >= 40.0 and per["sliding-tile"] >= 40.0 and per["full"] > 100.0, (noise, whole, per)
+    assert table[(True, 0.1)][1]["sliding-tile"] >= 40.0 and table[(True, 0.25)][1]["sliding-tile"] >= 40.0
+    # structure is what lifts it: monotone in the noise share, the white-noise floor at 1, and no lift for mismatched heads
+    for name in ("coreset", "sliding-tile"):
+        seq = [table[(True, n)][1][name] for n in (0.0, 0.05, 0.1, 0.25, 0.5)]
+        assert all(a >= b - 0.5 for a, b in zip(seq, seq[1:])), (name, seq)
+        assert table[(True, 1.0)][1][name] < 35.0 and table[(False, 0.05)][1][name] < 35.0, name
+
+
 @pytest.mark.parametrize("precision", [False, "i8pv", True])
 def test_full_attention_head_split_by_query_range(precision):
     """HeadRouting.partials (sequence parallelism below whole heads, ulysses/engine.py split_placement): a full-attention

@@ -508,16 +508,16 @@ def test_hunyuan_pipeline_token_shard_takes_any_frame_count(world):
             assert err <= 2e-2 * max(mag, 1.0) and shape_ok and same_scores, (r, ret[r])
 
 
-@pytest.mark.parametrize("precision", ["native", "fp8"])
+@pytest.mark.parametrize("precision", ["native", "auto8"])
 def test_hunyuan_pipeline_under_sequence_parallel_rehearsal(precision, monkeypatch):
     """2 ranks sharing the one GPU (gloo, host-staged transport): whole latents on every rank, token-sharded inside the
     transformer, global rotary table and attention mask from the stock forward, video == single process.  With
-    VORTA_ATTENTION_PRECISION=fp8 the unchanged call goes through the e4m3 kernels (text rows and padding through the
-    segmented quantiser): the ranks still agree bit for bit; against the single-process fp8 run the video differs by
-    another realisation of the rounding noise (the key centres are means of other sample rows)."""
+    VORTA_ATTENTION_PRECISION=auto8 the unchanged call goes through the 8-bit kernels (text rows and padding through the
+    segmented quantiser, v as e4m3 on the wire): the ranks still agree bit for bit; against the single-process 8-bit run
+    the video differs by another realisation of the rounding noise (the key centres are means of other sample rows)."""
     import torch.multiprocessing as mp
-    if precision == "fp8":
-        monkeypatch.setenv("VORTA_ATTENTION_PRECISION", "fp8")
+    if precision != "native":
+        monkeypatch.setenv("VORTA_ATTENTION_PRECISION", precision)
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         ret = mgr.dict()

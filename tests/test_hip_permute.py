@@ -116,8 +116,10 @@ def test_exchange_engine_on_device_equals_the_cpu_engine(groups):
         texts = [x.to(device) for x in texts_c]
         b = [lay.new_buffer() for _ in range(4)]
 
+        sgs = lay.grouping(groups)[0]  # (with P = 1 a slot group's rows are the slots' own: same buffers either way)
+
         def attend(g0, g1, gi):
-            lay.head_view(b[3])[g0:g1].copy_(lay.head_view(b[0])[g0:g1])
+            sgs[gi].head_view(b[3]).copy_(sgs[gi].head_view(b[0]))
 
         o = torch.zeros((S, H, D), dtype=torch.bfloat16, device=device).transpose(0, 1)
         t = torch.zeros((H, T, D), dtype=torch.bfloat16, device=device)

@@ -285,7 +285,7 @@ def test_hunyuan_processor_call_compiles_fullgraph(dual, precision):
               latent_shape=LATENT,
               flex_attn_mask_func=create_sliding_tile_attn_mask_func(LATENT, WINDOW, TILE, T, te, dev()))
     proc = HunyuanVideoFlashAttnProcessorTripleEval()
-    vorta_amd.set_attention_precision(precision)
+    vorta_amd.set_attention_precision(precision, measurement_only=True)
     try:
         def call(h, e, sc):
             return proc(attn, h, e, mask, rope, routing_score=sc, tau_sparse=0.3, **kw)
@@ -348,7 +348,7 @@ def test_hunyuan_processor_call_is_sync_free_and_graph_capturable(dual, precisio
     kw = dict(lowres_group_info=get_group_info(LATENT, GROUP, 0.5, dev()), window_size=WINDOW, tile_size=TILE,
               latent_shape=LATENT, flex_attn_mask_func=create_sliding_tile_attn_mask_func(LATENT, WINDOW, TILE, T, te, dev()))
     proc = HunyuanVideoFlashAttnProcessorTripleEval()
-    vorta_amd.set_attention_precision(precision)
+    vorta_amd.set_attention_precision(precision, measurement_only=True)
     try:
         call = lambda: proc(attn, hidden, enc, mask, rope, routing_score=score, tau_sparse=0.3, **kw)
         call()  # warm-up: geometry tables, allocator pools
@@ -510,7 +510,7 @@ def _sp_worker_fp8(rank, world, port, ret):
     for h, e in enumerate([0, 1, 1, 1, 1, 1]):
         score2[0, h, e] = 0.8
     native2 = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score2, **_wan_kwargs())
-    vorta_amd.set_attention_precision("fp8")
+    vorta_amd.set_attention_precision("fp8", measurement_only=True)
     full2 = {}
     for center in (False, True):
         routed.FP8_CENTER_K = center
@@ -525,7 +525,7 @@ def _sp_worker_fp8(rank, world, port, ret):
     vorta_amd.set_attention_precision("auto8")  # per head int8 or 16-bit scores
     fulla = proc(attn, hidden, None, None, None, tau_sparse=0.3, routing_score=score, **_wan_kwargs())
     assert torch.equal(fulla, fulli8)  # nothing flagged on these inputs
-    vorta_amd.set_attention_precision("fp8")
+    vorta_amd.set_attention_precision("fp8", measurement_only=True)
     SP_STATE.setup_sp_group(world)
     rel = lambda a, b: float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
     nat = native[:, rank * Sl:(rank + 1) * Sl].float()

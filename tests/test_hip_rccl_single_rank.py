@@ -19,8 +19,12 @@ def test_exchange_on_a_real_rccl_group_of_one_rank_equals_the_loopback_run():
     rep = json.loads(lines[-1])
     bad = [c for c in rep["cases"] if not (c["selfcheck_ok"] and c["equals_loopback"] and c["finite"])]
     assert rep["backend"] == "nccl" and len(rep["cases"]) == 20 and not bad and r.returncode == 0, (bad, r.stderr[-2000:])
-    # the collectives went through torch.distributed (not around it): the slot-group cases exchange peer to peer (no peer
-    # here), the ten whole-tensor cases issue q, k, v in and o back per layer (+ the self-check's)
+    # the collectives went through torch.distributed (not around it): EVERY case -- the slot-group ones too, since round 6 a
+    # slot group is a receive layout of its own -- issues q, k, v in and o back per layer and group as all_to_all_single
+    # (+ the self-check's); nothing is exchanged point to point
     calls = rep["collective_calls"]
-    assert calls.get("all_to_all_single", 0) >= 10 * 4 * 3 and calls.get("all_reduce", 0) > 0 and calls.get("all_gather", 0) > 0, calls
+    assert calls.get("all_to_all_single", 0) >= 20 * 4 * 4 and calls.get("all_reduce", 0) > 0 and calls.get("all_gather", 0) > 0, calls
+    assert calls.get("batch_isend_irecv", 0) == 0, calls
+    grouped = [c for c in rep["cases"] if c["groups"] > 1]
+    assert len(grouped) == 10 and all(c["a2a_calls"] >= 2 * 4 * 4 for c in grouped), grouped  # 2 groups x 4 layers x 4 tensors
     print(rep["collective_calls"])

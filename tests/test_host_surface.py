@@ -214,3 +214,34 @@ def test_bench_window_tile_matrix_is_the_oracles_table():
                            ((30, 45, 80), (6, 9, 8), (3, 3, 3)), ((4, 6, 4), (2, 3, 2), (3, 3, 3)), ((21, 30, 52), (7, 6, 4), (3, 3, 1))]:
         got = bench.window_tile_matrix(lat, tile, win, "cpu").numpy()
         assert np.array_equal(got, O.sta_window_tiles(lat, tile, win)), (lat, tile, win)
+
+
+def test_all_e4m3_scores_are_not_a_product_precision():
+    """"fp8" (e4m3 q k^T) reaches 20.8-35.7 dB on structured inputs -- no product switch may select it: the
+    setter refuses it without `measurement_only=True`, the environment variable refuses it at import."""
+    import subprocess
+    import sys
+
+    import vorta_amd
+    from vorta_amd import routed
+    before = routed.DEFAULT_FP8
+    try:
+        with pytest.raises(ValueError, match="not a product precision"):
+            vorta_amd.set_attention_precision("fp8")
+        assert routed.DEFAULT_FP8 == before
+        for p in routed.PRODUCT_PRECISIONS:
+            vorta_amd.set_attention_precision(p)
+            assert routed.DEFAULT_FP8 == (False if p == "native" else p)
+        vorta_amd.set_attention_precision("fp8", measurement_only=True)
+        assert routed.DEFAULT_FP8 is True
+        with pytest.raises(ValueError):
+            vorta_amd.set_attention_precision("fp4")
+    finally:
+        routed.DEFAULT_FP8 = before
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import vorta_amd.routed"], cwd=root, capture_output=True, text=True,
+                       env=dict(os.environ, VORTA_ATTENTION_PRECISION="fp8"))
+    assert r.returncode != 0 and "not a product precision" in r.stderr
+    r = subprocess.run([sys.executable, "-c", "import vorta_amd.routed as r; print(r.DEFAULT_FP8)"], cwd=root, capture_output=True,
+                       text=True, env=dict(os.environ, VORTA_ATTENTION_PRECISION="auto8"))
+    assert r.returncode == 0 and r.stdout.strip() == "auto8", r.stderr[-500:]

@@ -121,13 +121,33 @@ def _engine_worker(rank, world, port, ret):
     b3 = [lay.new_buffer().fill_(-1) for _ in range(4)]
     seen = []
 
+    sgs = lay.grouping(2)[0]  # a slot group is a receive layout of its own inside the buffers
+
     def attend(g0, g1, gi):
         seen.append((g0, g1, gi))
-        lay.head_view(b3[3])[g0:g1].copy_(lay.head_view(b3[0])[g0:g1])
+        sg = sgs[gi]
+        for t in range(3):  # every slot of the group holds its head's whole sequence + text, in token order, through ITS row map
+            hv, rmg = sg.head_view(b3[t]), sg.lay.row_map.long()
+            for i in range(g0, g1):
+                h = order3[rank * Hl + i]
+                want = torch.cat([_tag(torch.tensor(float(h)), torch.arange(S).view(S, 1), dd[0]),
+                                  _tag(torch.tensor(float(h)), torch.arange(T).view(T, 1) + 90000, dd[0])]) + 1e7 * t
+                assert torch.equal(hv[i - g0][rmg], want), (t, i)
+        sg.head_view(b3[3]).copy_(sg.head_view(b3[0]))
 
     o3, t3 = torch.full((H, Sl, D), -2.0), torch.full((H, T, D), -2.0)
     exchange_and_attend(lay, shards, b3, order3, texts, slot_groups(Hl, 2), attend, o3, t3)
     ok = ok and seen == [(0, Hl // 2, 0), (Hl // 2, Hl, 1)] and torch.equal(o3, shards[0]) and torch.equal(t3, texts[0])
+    # every group's exchange is ONE all_to_all_single per tensor (the reference's collective, vorta/ulysses/utils.py:48,80):
+    # 3 tensors in + 1 back, per group -- counted on the wire API
+    calls = []
+    real = dist.all_to_all_single
+    dist.all_to_all_single = lambda *a, **kw: (calls.append(1), real(*a, **kw))[1]
+    try:
+        exchange_and_attend(lay, shards, b3, order3, texts, slot_groups(Hl, 2), attend, o3, t3)
+    finally:
+        dist.all_to_all_single = real
+    ok = ok and len(calls) == 8 and not hasattr(lay, "_start")
     # the same layout expressed with the oracle's reference maps: seq->head of the head-permuted shard
     ret[rank] = (bool(ok), order, shards[0].numpy(), keep, rm.numpy())
     dist.barrier()
@@ -154,9 +174,8 @@ def test_zero_copy_layout_round_trip(world):
 
 def _uneven_worker(rank, world, port, ret):
     """ranks holding DIFFERENT numbers of heads (balanced_placement): every head's full sequence lands on its rank, the
-    identity attention travels back, one group and two slot groups, both transports"""
+    identity attention travels back, one group and two slot groups (per-rank split sizes of the all_to_all_single)"""
     _init(rank, world, port)
-    import vorta_amd.ulysses.engine as E
     from vorta_amd.ulysses import UlyssesLayout, balanced_placement, exchange_and_attend, slot_groups
     P = world
     H, S, T, D = 3 * world + 1, 24 * world, 5, 4
@@ -175,27 +194,27 @@ def _uneven_worker(rank, world, port, ret):
         shards = [_tag(hs, ss, dd) + 1e7 * t for t in range(3)]
         texts = [_tag(hs, torch.arange(T).view(1, T, 1) + 90000, dd) + 1e7 * t for t in range(3)]
         rm = lay.row_map.long()
-        for transport in ("a2a", "p2p"):
-            E.TRANSPORT = transport
-            bufs = [lay.new_buffer().fill_(-1) for _ in range(4)]
-            sg = slot_groups(Hl, min(groups, min(counts)))
-            seen = []
+        bufs = [lay.new_buffer().fill_(-1) for _ in range(4)]
+        sg = slot_groups(Hl, min(groups, min(counts)))
+        sgs = lay.grouping(len(sg))[0]
+        seen = []
 
-            def attend(g0, g1, gi):
-                seen.append((g0, g1))
-                for t in range(3):  # every local head slot holds its head's whole sequence + text, in token order
-                    hv = lay.head_view(bufs[t])
-                    for i in range(g0, g1):
-                        h = order[lay.starts[rank] + i]
-                        want = torch.cat([_tag(torch.tensor(float(h)), torch.arange(S).view(S, 1), dd[0]),
-                                          _tag(torch.tensor(float(h)), torch.arange(T).view(T, 1) + 90000, dd[0])]) + 1e7 * t
-                        assert torch.equal(hv[i][rm], want), (transport, groups, t, i)
-                lay.head_view(bufs[3])[g0:g1].copy_(lay.head_view(bufs[0])[g0:g1])
+        def attend(g0, g1, gi):
+            seen.append((g0, g1))
+            grp = sgs[gi]
+            rmg = grp.lay.row_map.long()
+            for t in range(3):  # every local head slot holds its head's whole sequence + text, in token order
+                hv = grp.head_view(bufs[t])
+                for i in range(g0, g1):
+                    h = order[lay.starts[rank] + i]
+                    want = torch.cat([_tag(torch.tensor(float(h)), torch.arange(S).view(S, 1), dd[0]),
+                                      _tag(torch.tensor(float(h)), torch.arange(T).view(T, 1) + 90000, dd[0])]) + 1e7 * t
+                    assert torch.equal(hv[i - g0][rmg], want), (groups, t, i)
+            grp.head_view(bufs[3]).copy_(grp.head_view(bufs[0]))
 
-            o, tx = torch.full((H, Sl, D), -2.0), torch.full((H, T, D), -2.0)
-            exchange_and_attend(lay, shards, bufs, order, texts, sg, attend, o, tx)
-            ok = ok and seen == sg and torch.equal(o, shards[0]) and torch.equal(tx, texts[0])
-        E.TRANSPORT = "a2a"
+        o, tx = torch.full((H, Sl, D), -2.0), torch.full((H, T, D), -2.0)
+        exchange_and_attend(lay, shards, bufs, order, texts, sg, attend, o, tx)
+        ok = ok and seen == sg and torch.equal(o, shards[0]) and torch.equal(tx, texts[0])
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -205,28 +224,24 @@ def _selfcheck_worker(rank, world, port, ret):
     """exchange_selfcheck (bench.py's N > 1 pre-flight): integer-tagged q,k,v through the layout's own exchange, exact on every
     rank; a rank whose copy of the head order differs must fail it everywhere"""
     _init(rank, world, port)
-    import vorta_amd.ulysses.engine as E
     from vorta_amd.ulysses import (UlyssesLayout, balanced_head_order, balanced_placement, exchange_selfcheck, slot_groups)
     P = world
     S, T, D = 40 * world, 6, 8
     res = {}
-    for H, uneven in ((2 * world, False), (3 * world + 1, True)):
+    for H, uneven in ((3 * world, False), (5 * world + 1, True)):  # (3 and >= 3 slots per rank: up to three slot groups)
         experts = ([0, 2, 2, 1, 2, 2, 1] * H)[:H]
         cost = [7.0, 2.0, 1.0]
-        for groups in (1, 2):
+        for groups in (1, 2, 3):
             if uneven:
                 order, counts = balanced_placement(experts, cost, P, groups)
             else:
                 order, counts = balanced_head_order(experts, cost, P, groups), None
             lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.bfloat16, counts=counts)
             sg = slot_groups(lay.Hl, min(groups, min(lay.counts)))
-            for transport in ("a2a", "p2p"):
-                E.TRANSPORT = transport
-                for brk in (False, True):
-                    bufs = [lay.new_buffer() for _ in range(4)]
-                    r = exchange_selfcheck(lay, order, sg, bufs, break_order=brk)
-                    res[(H, groups, transport, brk)] = (r["ok"], r["bytes"] > 0, r["ms"] >= 0)
-    E.TRANSPORT = "a2a"
+            for brk in (False, True):
+                bufs = [lay.new_buffer() for _ in range(4)]
+                r = exchange_selfcheck(lay, order, sg, bufs, break_order=brk)
+                res[(H, groups, brk)] = (r["ok"], r["bytes"] > 0, r["ms"] >= 0)
     ret[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -235,9 +250,8 @@ def _selfcheck_worker(rank, world, port, ret):
 def _split_worker(rank, world, port, ret):
     """heads split by QUERY RANGE over two ranks (split_placement): both ranks receive the head, each returns its range
     (zeros elsewhere: the identity attention of exchange_selfcheck honours the range), and every token shard must come
-    back whole -- one group and two slot groups, both transports; a wrong range table must fail"""
+    back whole -- one group and two slot groups; a wrong range table must fail"""
     _init(rank, world, port)
-    import vorta_amd.ulysses.engine as E
     from vorta_amd.ulysses import UlyssesLayout, exchange_selfcheck, slot_groups, split_placement, placement_loads
     P = world
     S, D = 512 * world, 8
@@ -254,17 +268,14 @@ def _split_worker(rank, world, port, ret):
         res[("ratio", gk)] = max(loads) * P / sum(loads)
         lay = UlyssesLayout(H, S, T, D, P, rank, "cpu", torch.bfloat16, counts=counts)
         sg = slot_groups(lay.Hl, min(groups, min(lay.counts)))
-        for transport in ("a2a", "p2p"):
-            E.TRANSPORT = transport
-            bufs = [lay.new_buffer() for _ in range(4)]
-            r = exchange_selfcheck(lay, order, sg, bufs, parts=parts)
-            res[(gk, transport, "ok")] = r["ok"]
-            # the same exchange told that every slot is whole must lose the rows only the other part returned
-            wrong = [None if p is None else (min(p[0] + 32, p[1] - 32), p[1]) for p in parts]
-            bufs = [lay.new_buffer() for _ in range(4)]
-            r = exchange_selfcheck(lay, order, sg, bufs, parts=wrong)
-            res[(gk, transport, "wrong ranges")] = r["ok"]
-    E.TRANSPORT = "a2a"
+        bufs = [lay.new_buffer() for _ in range(4)]
+        r = exchange_selfcheck(lay, order, sg, bufs, parts=parts)
+        res[(gk, "ok")] = r["ok"]
+        # the same exchange told that every slot is whole must lose the rows only the other part returned
+        wrong = [None if p is None else (min(p[0] + 32, p[1] - 32), p[1]) for p in parts]
+        bufs = [lay.new_buffer() for _ in range(4)]
+        r = exchange_selfcheck(lay, order, sg, bufs, parts=wrong)
+        res[(gk, "wrong ranges")] = r["ok"]
     ret[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -279,9 +290,8 @@ def test_heads_split_by_query_range_round_trip(world):
         for groups in (1, 2, 11, 12):  # (1x: with 6 text rows per head)
             assert res[("extra", groups)] >= 1, res            # the mix needs at least one split
             assert res[("ratio", groups)] <= 1.03, res  # (32-token steps of a 512-token shard are coarse)
-            for transport in ("a2a", "p2p"):
-                assert res[(groups, transport, "ok")] is True, (r, groups, transport)
-                assert res[(groups, transport, "wrong ranges")] is False, (r, groups, transport)
+            assert res[(groups, "ok")] is True, (r, groups)
+            assert res[(groups, "wrong ranges")] is False, (r, groups)
 
 
 def test_split_placement_reaches_one_percent_on_wan14b_at_eight_ranks():
@@ -371,14 +381,14 @@ def test_split_placement_boundaries_are_workgroup_aligned_at_production_sizes():
                     assert all(t0 % a == 0 and (t1 == S or t1 % a == 0) and t1 - t0 >= a for t0, t1 in rs), (S, P, rs)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_exchange_selfcheck_passes_and_catches_a_misordered_placement(world):
     ret = mp.Manager().dict()
     mp.spawn(_selfcheck_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):
         for key, (ok, nb, ms) in ret[r].items():
             assert nb and ms, (r, key)
-            assert ok == (not key[3]), (r, key, ok)  # break_order -> the check fails on EVERY rank (MIN all-reduce)
+            assert ok == (not key[2]), (r, key, ok)  # break_order -> the check fails on EVERY rank (MIN all-reduce)
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -525,3 +535,50 @@ def test_pipeline_token_shard_33_frames(world):
         err, mag, shape, same_seed, refused = ret[r]
         assert err <= 1e-5 * max(mag, 1.0), (r, err)
         assert shape == (1, 4, 33, 2, 4) and same_seed and refused
+
+
+def _coherence_worker(rank, world, port, ret):
+    _init(rank, world, port)
+    from vorta_amd.patch._engine import check_rank_coherence
+    from vorta_amd.ulysses import SP_STATE
+    SP_STATE.setup_sp_group(world)
+    N = 12_000_000  # the size class where a checksum goes blind: sqrt(N) / N = 3e-4
+    res = {}
+    same = torch.randn(N, generator=torch.Generator().manual_seed(5)).view(1, -1, 3000)
+    # identical latents whose embedding went through another kernel on this rank: an ulp of bf16 apart, element by element
+    jitter = (same.to(torch.bfloat16).float() * (1.0 + (0.004 if rank else 0.0))).view_as(same)
+    other = torch.randn(N, generator=torch.Generator().manual_seed(100 + rank)).view(1, -1, 3000)
+    for name, x in (("same", same), ("ulp apart", jitter), ("different seeds", other)):
+        try:
+            check_rank_coherence(x)
+            res[name] = "ok"
+        except RuntimeError as e:
+            res[name] = "different latents" if "different latents" in str(e) else str(e)
+    bad = same.clone()
+    if rank == world - 1:
+        bad[0, 17, 5] = float("nan")
+    try:
+        check_rank_coherence(bad)
+        res["nan"] = "ok"
+    except RuntimeError as e:
+        res["nan"] = "not finite" if "not finite" in str(e) else str(e)
+    # what the old checksum (signed sum and abs-sum to 1e-3 of the abs-sum) said about the per-rank seeds: nothing
+    sums = torch.stack([other.sum(), other.abs().sum()]).reshape(1, 2)
+    every = [torch.empty_like(sums) for _ in range(world)]
+    dist.all_gather(every, sums)
+    every = torch.cat(every)
+    res["old checksum blind"] = bool(((every - every[:1]).abs() <= 1e-3 * every[:, 1].abs().max()).all())
+    ret[rank] = res
+    dist.barrier()
+    SP_STATE.cleanup()
+
+
+def test_rank_coherence_check_sees_per_rank_seeds_at_production_sizes():
+    """at 1e7+ elements two differently seeded noise tensors agree in sum and abs-sum to 3e-4 -- under
+    the old 1e-3 tolerance -- so per-rank seeds passed silently and every rank denoised another video.  The strided
+    element sample refuses them at any size, lets identical latents an ulp apart through, and tells NaN apart."""
+    ret = mp.Manager().dict()
+    mp.spawn(_coherence_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret[r] == {"same": "ok", "ulp apart": "ok", "different seeds": "different latents", "nan": "not finite",
+                          "old checksum blind": True}, ret[r]

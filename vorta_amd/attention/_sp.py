@@ -19,10 +19,18 @@ from ..ulysses.engine import (UlyssesLayout, VWire, balanced_head_order, balance
 
 _LAYOUTS = {}
 _BUFFERS = {}  # receive buffers per (geometry, head-slot count): kept when the layout cache is trimmed, least recently used out
-MAX_BUFFER_SETS = max(2, int(__import__("os").environ.get("VORTA_SP_BUFFER_SETS", "4")))
+# how many buffer sets stay resident: VORTA_SP_BUFFER_SETS, or (default) enough for every slot count one geometry can see --
+# under 'uneven' / 'split' placement a rank holds between 1 and 2 H / P (+ 1) head slots from layer to layer, and a bound below
+# that makes every layer a miss: 4 receive buffers reallocated and zero-filled per layer
+MAX_BUFFER_SETS = int(__import__("os").environ.get("VORTA_SP_BUFFER_SETS", "0"))
+
+
+def _buffer_set_limit(H: int, P: int) -> int:
+    return max(2, MAX_BUFFER_SETS) if MAX_BUFFER_SETS > 0 else max(4, 2 * (H // max(P, 1)) + 2)
 _ROUTINGS = {}  # (local expert ids, device) -> HeadRouting: the device tables are built once per distinct local mix
-# slot groups: a number, or "auto" (default) = `default_sp_groups` of the heads per rank and the precision (ulysses/state.py)
-SP_GROUPS = __import__("os").environ.get("VORTA_SP_GROUPS", "auto")
+# slot groups: a number (default 1: exchange, then attend), or "auto" = `default_sp_groups` of the heads per rank and the
+# precision (ulysses/state.py) -- ranked on an emulated wire only, so opt-in until a node run has measured the links
+SP_GROUPS = __import__("os").environ.get("VORTA_SP_GROUPS", "1")
 SP_GROUPS = SP_GROUPS if SP_GROUPS == "auto" else max(1, int(SP_GROUPS))
 
 
@@ -60,6 +68,7 @@ class _SpBuffers:
         self.vwire = None
         self._wire = None
         self.i8 = None
+        self.group_ops = {}  # the operand buffers as each slot group sees them (UlyssesLayout.group_operands)
 
     def fp8(self, mode=True):
         """(operands, v wire) of the e4m3 path; mode "fp8pv" (16-bit scores) / "i8pv" (int8 scores: + `self.i8`, the int8 key
@@ -96,8 +105,8 @@ def _layout(H, S, T, D, device, dtype, counts=None, extra_slots=0):
     bkey = (H, S, T, D, P, rank, str(device), dtype, lay.Hl)
     if bkey not in _BUFFERS:
         # bounded: a set is 4 buffers of rows_total x D plus the 8-bit copies -- hundreds of MB to GB; a process that
-        # sees several resolutions, text lengths or slot counts keeps the MAX_BUFFER_SETS most recently used ones
-        while len(_BUFFERS) >= MAX_BUFFER_SETS:
+        # sees several resolutions or text lengths keeps the `_buffer_set_limit` most recently used sets (every slot count of one geometry fits)
+        while len(_BUFFERS) >= _buffer_set_limit(H, P):
             _BUFFERS.pop(next(iter(_BUFFERS)))
         _BUFFERS[bkey] = _SpBuffers(lay)
     else:
@@ -122,8 +131,8 @@ def _routing(local_experts: tuple, device, q_ranges: tuple = ()) -> HeadRouting:
 def place_heads(experts, cost, P: int, S: int, dense_only: bool = False, placement: Optional[str] = None, groups: Optional[int] = None):
     """(placement taken, head order, heads per rank, query ranges or None) of one layer: VORTA_SP_PLACEMENT (default `auto`)
     resolved by `resolve_placement`, then the engine's placement of that name.
-    VORTA_SP_GROUPS (default auto: `default_sp_groups`, chosen on an emulated wire): the local heads travel in that many slot groups (as
-    equal as the slot count allows), so the exchange of one group overlaps the attention of another."""
+    VORTA_SP_GROUPS (default 1; `auto` = `default_sp_groups`, chosen on an emulated wire): the local heads travel in that many
+    slot groups (as equal as the slot count allows), so the exchange of one group overlaps the attention of another."""
     H = len(experts)
     groups = _sp_groups(H, P) if groups is None else groups
     placement = resolve_placement(SP_PLACEMENT if placement is None else placement, H, P)
@@ -180,16 +189,17 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
     lay, sb = _layout(H, S, T, D, q.device, q.dtype, counts, extra_slots=len(order) - H)
     bufs = sb.bufs
     groups = min(_sp_groups(H, P), min(counts))
-    geom = None if dense_only else geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
-                                                lowres_group_info.reduction_rate, q.device, row_map=lay.row_map)
+    sg = slot_groups(lay.Hl, groups)
+    sgs, _, _ = lay.grouping(len(sg))  # a slot group is a receive layout of its own inside the buffers (ulysses/engine.py)
+    # the routed geometry composed with each group's row map (one per distinct slot count, cached)
+    geoms = [None if dense_only else geometry_for(latent_shape, tile_size, window_size, lowres_group_info.window_size,
+                                                  lowres_group_info.reduction_rate, q.device, row_map=g.lay.row_map) for g in sgs]
     shards = [x[0, :, :Sl] for x in (q, k, v)]
     texts = [x[0, :, Sl:] for x in (q, k, v)] if T else None
-    qv, kv, vv, ov = (lay.head_view(b) for b in bufs)
     me = SP_STATE.group_local_rank
     local = [experts[h] for h in order[lay.starts[me]:lay.starts[me + 1]]]
     local_parts = [None] * len(local) if parts is None else parts[lay.starts[me]:lay.starts[me + 1]]
     ranges_of = lambda g0, g1: tuple((i - g0,) + tuple(local_parts[i]) for i in range(g0, g1) if local_parts[i] is not None)
-    rm = lay.row_map
     kv_splits = 1
     if not dense_only and SP_KV_SPLITS != "1":
         if SP_KV_SPLITS == "auto":
@@ -209,31 +219,35 @@ def sp_attention(q, k, v, T: int, routing_score: Optional[torch.Tensor], tau_spa
         vwire.lay = lay  # the layouts of one slot count share the buffers; the head offsets are this layer's
 
     def attend(g0, g1, gi):
+        grp = sgs[gi]
+        sub = grp.lay
+        b = [grp.buffer(x) for x in bufs]
+        qv, kv, vv, ov = (sub.head_view(x) for x in b)
+        rm = sub.row_map
         views = None
         if fp8 == "i8pv" or auto8:  # k of the slot group that has landed -> int8 (q by the kernel); v arrived as e4m3
-            i8 = lay.i8_views(bufs, sb.i8, slots=(g0, g1))
-            views = (qv[g0:g1], i8.k8[g0:g1], lay.head_view(vwire.buf)[g0:g1], vwire.descale(g0, g1), i8.heads(g0, g1))
+            i8 = sub.i8_views(b, lay.group_operands(grp, sb.i8, sb.group_ops))
+            views = (qv, i8.k8, grp.head_view(vwire.buf), vwire.descale(grp), i8)
             if auto8:  # + the 16-bit keys as they landed and the group's tail flags: each head to the kernel that holds it
-                views += (kv[g0:g1], ops.i8_tail_flags(i8.k8[g0:g1], row_map=rm[:S + T]))
+                views += (kv, ops.i8_tail_flags(i8.k8, row_map=rm[:S + T]))
         elif fp8 == "fp8pv":  # q, k as they landed; v arrived as e4m3 (converted on the send side)
-            views = (qv[g0:g1], kv[g0:g1], lay.head_view(vwire.buf)[g0:g1], vwire.descale(g0, g1))
+            views = (qv, kv, grp.head_view(vwire.buf), vwire.descale(grp))
         elif fp8:  # the slot group that has landed is converted while the next one is in flight
-            q8, k8, v8, vd, _ = lay.fp8_views(bufs, out=f8, slots=(g0, g1), vwire=vwire)
-            views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
+            q8, k8, v8, vd, _ = sub.fp8_views(b, out=lay.group_operands(grp, f8, sb.group_ops), vwire=vwire,
+                                              v_descale=None if vwire is None else vwire.descale(grp))
+            views = (q8, k8, v8, vd)
         if dense_only:
-            ops.attn_fwd(qv[g0:g1], kv[g0:g1], vv[g0:g1], ov[g0:g1], n_q=S + T, n_kv=S + te, q_valid=S + te,
-                         q_rows=rm[:S + T], kv_rows=rm[:S + te])
+            ops.attn_fwd(qv, kv, vv, ov, n_q=S + T, n_kv=S + te, q_valid=S + te, q_rows=rm[:S + T], kv_rows=rm[:S + te])
         else:
-            routed_attention(qv[g0:g1], kv[g0:g1], vv[g0:g1], _routing(tuple(local[g0:g1]), q.device, ranges_of(g0, g1)), geom,
-                             model=model, text_len=T, text_valid=te, out=ov[g0:g1], fp8=False, fp8_views=views,
+            routed_attention(qv, kv, vv, _routing(tuple(local[g0:g1]), q.device, ranges_of(g0, g1)), geoms[gi],
+                             model=model, text_len=T, text_valid=te, out=ov, fp8=False, fp8_views=views,
                              kv_splits=kv_splits)
-
-    sg = slot_groups(lay.Hl, groups)
 
     def prepare():
         # everything `attend` caches is built here, on the current stream, before the slot groups fork onto theirs
         if not dense_only:
-            geom.prebuild(te if model == "hunyuan" else 0)
+            for g in geoms:
+                g.prebuild(te if model == "hunyuan" else 0)
             for g0, g1 in sg:
                 _routing(tuple(local[g0:g1]), q.device, ranges_of(g0, g1))
 

@@ -61,6 +61,15 @@ constexpr int SMEM_I8 = (K_SLOTS_I8 + V_SLOTS_I8) * TILE8 + B_SLOTS_I8 * SC_BYTE
 constexpr int MAGIC_I = 0x4B400000;  // float bits of 1.5 * 2^23 = 12 582 912
 constexpr float MAGIC_F = 12582912.f;
 constexpr float SEED_LIMIT = 2000000.f;  // |q8 . k8| <= 2 064 512; the sum must stay below 2^22
+// Round 6 (the instruction COUNT of the loop): the 32 byte conversions of a block as 16 v_cvt_pknorm_u16_f32
+// (TWO scores per instruction: unorm16(x) = round(clamp(x, 0, 1) * 65535), with 1 / 65535 folded into the multiply-add that makes
+// y) + 8 v_perm_b32 (the low bytes of two such registers) = 24 instead of 32 v_cvt_pk_u8_f32.  tools/probe_cvt_pknorm.hip: what it
+// rounds to and what it costs; profiles/r06_i8_pknorm.txt: the same-box A/B.
+#ifndef VORTA_I8_PKNORM
+#define VORTA_I8_PKNORM 0
+#endif
+constexpr float K65 = 1.f / 65535.f;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
 
 struct ParamsI8 {
   Params p;
@@ -323,6 +332,15 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   f32x16 y0, y1;          // byte-domain scores (minus 8 e) of one key block (keys 0-31, 32-63 of the block)
   i32x16 n0, n1;          // raw accumulators of the block after it (written by the matrix part)
   float off8 = 0.f;       // ybias - m_run8 - MAGIC_F * m8: the addend of the conversion
+#if VORTA_I8_PKNORM
+  constexpr float YK_ = K65;           // the conversions take y / 65535 ...
+  const float m8n = m8 * K65;          // ... made by the same multiply-add with both constants divided
+  float off8n = 0.f;
+#else
+  constexpr float YK_ = 1.f;
+  const float m8n = m8;
+#define off8n off8
+#endif
   float offp0 = 0.f, offp1 = 0.f;  // the two tiles' conversion offsets of the block whose scores are in n0, n1
   float ecur = EBIAS;     // biased block exponent of key tile hh (the one whose scale this lane supplies) for the block in y0, y1
 
@@ -355,12 +373,22 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) yd1_[i_] = __builtin_fmaf(__int_as_float(a1_[i_]), m8, off_); \
   }
   // P' bytes straight from y - 8 e: rint, saturating at 0 (-inf of masked keys -> 0); the lane's largest is below 126.5
+#if VORTA_I8_PKNORM
+  // y0 / y1 hold (y - 8 e) / 65535: two per v_cvt_pknorm_u16_f32, the four low bytes of two results by one v_perm_b32
+#define PKN_(a_, b_) __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_u16(a_, b_))
+#define PACK_Y(pb_)                                                               \
+  _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_) {                              \
+    pb_[w_] = (int)__builtin_amdgcn_perm(PKN_(y0[4 * w_ + 2], y0[4 * w_ + 3]), PKN_(y0[4 * w_], y0[4 * w_ + 1]), 0x06040200u); \
+    pb_[4 + w_] = (int)__builtin_amdgcn_perm(PKN_(y1[4 * w_ + 2], y1[4 * w_ + 3]), PKN_(y1[4 * w_], y1[4 * w_ + 1]), 0x06040200u); \
+  }
+#else
 #define PACK_Y(pb_)                                                               \
   _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_)                                \
     _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_) {                            \
       pb_[w_] = __builtin_amdgcn_cvt_pk_u8_f32(y0[4 * w_ + b_], b_, pb_[w_]);     \
       pb_[4 + w_] = __builtin_amdgcn_cvt_pk_u8_f32(y1[4 * w_ + b_], b_, pb_[4 + w_]); \
     }
+#endif
 #define ROW_MAX(dst_, a_, b_)                                                      \
   {                                                                               \
     float mx_ = a_[0];                                                            \
@@ -390,8 +418,8 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     eh_ = fmaxf(__builtin_fmaf(ymx_, 0.125f, CE), EB_MIN);                        \
     const float ef_ = eh_ - EBIAS;                                                \
     auto e_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(ef_), __float_as_uint(ef_), false, false); \
-    off0_ = __builtin_fmaf(__uint_as_float(e_[0]), -8.f, off8);                   \
-    off1_ = __builtin_fmaf(__uint_as_float(e_[1]), -8.f, off8);                   \
+    off0_ = __builtin_fmaf(__uint_as_float(e_[0]), -8.f * YK_, off8n);            \
+    off1_ = __builtin_fmaf(__uint_as_float(e_[1]), -8.f * YK_, off8n);            \
   }
   // (the empty asm makes the lane term a value of THIS step: otherwise the 16 sums lane term + register row are hoisted out
   // of the loop into 16 registers for a branch taken once per workgroup)
@@ -445,8 +473,8 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   // asks at the same moment and the address unit takes 16 pieces per step, 16 cycles apiece -- with VALU work between
   // them the queue has drained when the next one comes (tools/trace_i8.py: 176-208 cycles per step for the requests).
 #define VALU_FMA()                                                                \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8, offp0); \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8, offp1);
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y0[i_] = __builtin_fmaf(__int_as_float(n0[i_]), m8n, offp0); \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) y1[i_] = __builtin_fmaf(__int_as_float(n1[i_]), m8n, offp1);
 #define VALU_PART(bs_, ss_, qa_, qb_, qc_)                                        \
   {                                                                               \
     const float sb_ = *(const float*)(smem + bias_rd + (bs_) * SC_BYTES);         \
@@ -484,12 +512,17 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
   // score half leaves the issue to the partner: +2 %, profiles/r05_i8_loop_experiments.txt 9; with the multiply-adds here as
   // well the P V half outgrows its MFMAs: -2 ... -3.5 %)
 #define SG_(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
+#if VORTA_I8_PKNORM
+#define NCVT_ 6 /* 16 v_cvt_pknorm_u16_f32 + 8 v_perm_b32 */
+#else
+#define NCVT_ 8 /* 32 v_cvt_pk_u8_f32 */
+#endif
 #define SCHED_M()                                                                 \
   SG_(0x100, 8)                                                                   \
-  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
-  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
-  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
-  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, 8)                                       \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, NCVT_)                                   \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, NCVT_)                                   \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, NCVT_)                                   \
+  SG_(0x008, 1) SG_(0x100, 4) SG_(0x002, NCVT_)                                   \
   SG_(0x008, 1)
   // score half (a basic block of its own behind the rare branches): the eight reads of key tile 1 under the four MFMAs of
   // tile 0 (whose operands are in registers: the wave goes from the branch straight into an MFMA), then tile 1
@@ -536,8 +569,14 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
     lt_[0] = 0.f;                                                                 \
     m_run8 = __builtin_fmaf(g_, 8.f, m_run8);                                     \
     off8 = __builtin_fmaf(g_, -8.f, off8);                                        \
+    RAISE_OFF8N_(g_)                                                              \
     ecur = fmaxf(ecur - g_, EB_MIN);                                              \
   }
+#if VORTA_I8_PKNORM
+#define RAISE_OFF8N_(g_) off8n = __builtin_fmaf(g_, -8.f * K65, off8n);
+#else
+#define RAISE_OFF8N_(g_)
+#endif
 #define MATRIX_PART(kr_, vr_, sr_, pbr_, scr_, pbw_, scw_, jabs_)                 \
   {                                                                               \
     PRIO_HI()                                                                     \
@@ -642,6 +681,9 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
       m_run8 = mx0;
       const float shift = ybias - m_run8;
       off8 = __builtin_fmaf(-MAGIC_F, m8, shift);
+#if VORTA_I8_PKNORM
+      off8n = off8 * K65;
+#endif
       // ... and its two key tiles take their block exponents from their own (masked) values
       float l0 = y0[0], l1 = y1[0];
 #pragma unroll
@@ -653,7 +695,7 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
       auto e = __builtin_amdgcn_permlane32_swap(__float_as_uint(ef), __float_as_uint(ef), false, false);
       const float sh0 = __builtin_fmaf(__uint_as_float(e[0]), -8.f, shift), sh1 = __builtin_fmaf(__uint_as_float(e[1]), -8.f, shift);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { y0[i] += sh0; y1[i] += sh1; }
+      for (int i = 0; i < 16; ++i) { y0[i] = (y0[i] + sh0) * YK_; y1[i] = (y1[i] + sh1) * YK_; }
     }
     __syncthreads();  // every wave has read K(0) and the bias tile of K(0) before their slots are overwritten
     {  // step 0: no PV yet -- the scores of block 1, then (role X) the VALU part of block 0
@@ -726,6 +768,12 @@ __device__ __forceinline__ void attn_i8_body(const ParamsI8& pp, char* __restric
 #undef PRIO_LO
 #undef PV_PART
 #undef RAISE_REF
+#undef RAISE_OFF8N_
+#undef PKN_
+#undef NCVT_
+#if !VORTA_I8_PKNORM
+#undef off8n
+#endif
 #undef MATRIX_PART
 #undef ROLE_Y_
 #undef STEP

@@ -208,9 +208,10 @@ __global__ void i8_head_scale_kernel(const IParams p) {
   }
 }
 
-// grid (heads), 1024 threads = 64 row lanes x 16 channel groups of 16: the sum of squares of ~1024 evenly spaced int8 rows of
-// the head in a FIXED order (row lane rl takes samples rl, rl + 64, ...; the 16 bytes of a lane in order; lanes pairwise at
-// distance 512, 256, ... 1): exact in int64, so the flag does not depend on the order at all
+// grid (heads), 1024 threads = 128 row lanes x 8 column lanes of 16 bytes (one 128-byte row per 8 threads: D == 128): the sum of
+// squares of ~1024 evenly spaced int8 rows of the head (row lane rl takes samples rl, rl + 128, ...; the 16 bytes of a lane in
+// order; lanes pairwise at distance 512, 256, ... 1): exact in int64, so the flag does not depend on the order at all
+static_assert(D == 128, "i8_tail_kernel reads a row as 8 lanes x 16 bytes and is launched with 1024 threads");
 __global__ __launch_bounds__(1024) void i8_tail_kernel(const char* k8, int64_t sh, int64_t ss, const int* row_map, int n_tokens,
                                                         int stride, int cand, float min_rms, int* flags) {
   const int h = blockIdx.x, t = threadIdx.x, cg = t & 7, rl = t >> 3;  // 8 lanes x 16 bytes per row, 128 row lanes
@@ -264,6 +265,9 @@ extern "C" int vorta_i8_tail_flags(const vorta_tensor* k8, int32_t heads, int32_
   if (heads == 0) return VORTA_OK;
   if (!k8->ptr || !flags || n_tokens == 0) return VORTA_EINVAL;
   if (((uintptr_t)k8->ptr & 15) || (k8->stride_s % 16) || (k8->stride_h % 16) || k8->stride_s < D) return VORTA_EINVAL;
+  // token = row (no row map): the heads' row ranges must not overlap -- a head stride shorter than n_tokens rows is a wrong
+  // view (with a row map the rows are the caller's: the struct carries no extent, the Python host checks the map's length)
+  if (!row_map && heads > 1 && k8->stride_h != 0 && llabs((long long)k8->stride_h) < (long long)n_tokens * k8->stride_s) return VORTA_EINVAL;
   int stride = n_tokens / SAMPLES;
   if (stride < 1) stride = 1;
   stride |= 1;

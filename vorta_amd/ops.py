@@ -570,6 +570,8 @@ def i8_tail_flags(k8: torch.Tensor, min_rms: Optional[float] = None, out: Option
         raise ValueError("i8_tail_flags takes the (H,S,D) int8 keys of i8_quantize_k")
     H = k8.shape[0]
     n = int(row_map.numel()) if row_map is not None else k8.shape[1]
+    if row_map is not None and (row_map.dtype != torch.int32 or not row_map.is_cuda or not row_map.is_contiguous()):
+        raise ValueError("i8_tail_flags: row_map must be a contiguous int32 device tensor (one row of the head's view per token)")
     if out is None:
         out = torch.empty((H,), dtype=torch.int32, device=k8.device)
     t = _tensor(k8)
@@ -584,7 +586,7 @@ def split_heads(flags: torch.Tensor, head_list: Optional[torch.Tensor], n_heads:
     (head_list, n_heads, n_heads_dev) slot-argument dicts for attn_fwd / coreset_select -- everything stays on the device."""
     _require_gpu(flags)
     dev = flags.device
-    lists = torch.empty((2, max(n_heads, 1)), dtype=torch.int32, device=dev)
+    lists = torch.zeros((2, max(n_heads, 1)), dtype=torch.int32, device=dev)  # (entries past counts[i] stay a valid head index)
     counts = torch.empty((2,), dtype=torch.int32, device=dev)
     _C.check(_C.lib().vorta_split_heads(head_list.data_ptr() if head_list is not None else None,
                                         n_heads_dev.data_ptr() if n_heads_dev is not None else None, int(n_heads),

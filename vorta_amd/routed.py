@@ -166,10 +166,23 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
 # VORTA_STA_MERGE=0: one group per tile, as round 1 (A/B)
 STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
 # process-wide default of `routed_attention(fp8=None)`: the processors of vorta.attention call it that way, so the
-# unchanged inference scripts pick the e4m3 path up from the environment or from `set_attention_precision("fp8")`
-# False (native), True (all e4m3), "fp8pv" (16-bit scores, e4m3 P V) or "i8pv" (int8 scores: one key scale per head, one query scale per wave; e4m3 P V)
+# unchanged inference scripts pick an 8-bit path up from the environment or from `set_attention_precision(...)`:
+# False (native), "fp8pv" (16-bit scores, e4m3 P V), "i8pv" (int8 scores: one key scale per head, one query scale per wave;
+# e4m3 P V) or "auto8" (per head one of the two).  True = both contractions in e4m3 is NOT a product precision (round 6,
+# VERDICT r05): 20.8-35.7 dB on structured inputs against the 40 dB bar; measurements reach it through
+# `routed_attention(fp8=True)`, `bench.py --dtype fp8` and `set_attention_precision("fp8", measurement_only=True)`.
+PRODUCT_PRECISIONS = ("native", "fp8pv", "i8pv", "auto8")
+_NOT_A_PRODUCT = ("'fp8' (q k^T AND P V in e4m3) is not a product precision: 3 mantissa bits on the scores give 20.8-35.7 dB on "
+                  "structured inputs (40.1 dB only on white noise; DESIGN.md (c)) against the 40 dB bar.  Use 'auto8' (int8 or "
+                  "16-bit scores per head, e4m3 P V: >= 40.9 dB on every input family, 1.6 x bf16), 'i8pv' or 'fp8pv'; the "
+                  "all-e4m3 kernels stay reachable for measurements: bench.py --dtype fp8, routed_attention(fp8=True), "
+                  "set_attention_precision('fp8', measurement_only=True)")
 _PREC_ENV = __import__("os").environ.get("VORTA_ATTENTION_PRECISION", "").lower()
-DEFAULT_FP8 = True if _PREC_ENV == "fp8" else (_PREC_ENV if _PREC_ENV in ("fp8pv", "i8pv", "auto8") else False)
+if _PREC_ENV == "fp8":
+    raise ValueError("VORTA_ATTENTION_PRECISION=fp8: " + _NOT_A_PRODUCT)
+if _PREC_ENV not in ("",) + PRODUCT_PRECISIONS:
+    raise ValueError(f"VORTA_ATTENTION_PRECISION={_PREC_ENV!r}: one of {PRODUCT_PRECISIONS}")
+DEFAULT_FP8 = _PREC_ENV if _PREC_ENV in ("fp8pv", "i8pv", "auto8") else False
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
 # the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
 FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
@@ -185,16 +198,23 @@ FUSED_TEXT_SPLITS = int(__import__("os").environ.get("VORTA_FUSED_TEXT_SPLITS", 
 FUSED_TEXT_FIRST = FUSED_TEXT_SPLITS > 0
 
 
-def set_attention_precision(precision: str) -> None:
-    """"native" (the dtype of q,k,v: the reference's behaviour), "fp8" (both contractions in e4m3: fastest, 40 dB against
-    native only where the softmax is flat), "fp8pv" (scores in 16 bits, P V in e4m3: >= 42 dB on every input family
-    tried), "i8pv" (scores in int8 at the e4m3 MFMA rate, P V in e4m3: >= 40 dB on every family, relative error <= 0.07 on
-    all but heavy-tailed inputs) or "auto8" ("i8pv" per head, with 16-bit scores -- "fp8pv" -- for the heads whose int8 keys
-    would be too coarse; chosen on the device); 16-bit output in every case"""
+def set_attention_precision(precision: str, *, measurement_only: bool = False) -> None:
+    """"native" (the dtype of q,k,v: the reference's behaviour), "fp8pv" (scores in 16 bits, P V in e4m3: >= 41 dB on every
+    input family tried), "i8pv" (scores in int8 at the e4m3 MFMA rate, P V in e4m3: >= 40 dB on every family, relative error
+    <= 0.07 on all but heavy-tailed inputs) or "auto8" ("i8pv" per head, with 16-bit scores -- "fp8pv" -- for the heads whose
+    int8 keys would be too coarse; chosen on the device); 16-bit output in every case.  Every product
+    precision holds the 40 dB bar on all seven input families of tests/_fp8_inputs.py at full size.
+    "fp8" (both contractions in e4m3) does not -- 20.8-35.7 dB on structured inputs -- and is refused unless
+    `measurement_only=True` (bench.py, the kernel tests)."""
     global DEFAULT_FP8
-    if precision not in ("native", "fp8", "fp8pv", "i8pv", "auto8"):
-        raise ValueError("precision is 'native', 'fp8', 'fp8pv', 'i8pv' or 'auto8'")
-    DEFAULT_FP8 = True if precision == "fp8" else (precision if precision in ("fp8pv", "i8pv", "auto8") else False)
+    if precision == "fp8":
+        if not measurement_only:
+            raise ValueError(_NOT_A_PRODUCT)
+        DEFAULT_FP8 = True
+        return
+    if precision not in PRODUCT_PRECISIONS:
+        raise ValueError(f"precision is one of {PRODUCT_PRECISIONS}")
+    DEFAULT_FP8 = precision if precision in ("fp8pv", "i8pv", "auto8") else False
 _SIDE_STREAMS: Dict[int, Tuple[torch.cuda.Stream, torch.cuda.Stream]] = {}
 
 
@@ -226,7 +246,7 @@ def routed_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, routing:
     fp8=True: both contractions in e4m3 (BASELINE.json configs[4]; no reference counterpart): q,k,v are converted once
     per call (vorta_fp8_quantize_qkv, or `fp8_operands` to reuse buffers) and every expert launch reads the e4m3
     copies; the coreset ranking still reads the 16-bit q/k (coreset_select.py:98-105 ranks in the input dtype).
-    fp8=None follows the process-wide default (`set_attention_precision`, VORTA_ATTENTION_PRECISION=fp8).
+    fp8=None follows the process-wide default (`set_attention_precision`, VORTA_ATTENTION_PRECISION).
     fp8_views = (q8, k8, v8, v_descale): e4m3 views with the geometry of q,k,v that were converted elsewhere (the
     sequence-parallel path converts the receive buffers once, vorta_amd/ulysses/engine.py).
     kv_splits > 1: the full-attention and coreset launches cut their KEYS into that many parts (+ a merge kernel) -- for

@@ -26,10 +26,10 @@ import torch.distributed as dist
 from .. import ops
 
 
-# Transport of the head exchange.  "a2a" (default): one all_to_all_single per tensor whenever the chunks are in rank
-# order (always, once the heads went through the staging pass); "p2p": grouped send/recv for everything.  Slot-group
-# (overlapped) exchanges and shards sent straight from a permuted-but-contiguous source always use send/recv.
-TRANSPORT = __import__("os").environ.get("VORTA_SP_TRANSPORT", "a2a")
+# Transport of the head exchange: ONE `all_to_all_single` per tensor and slot group (the collective the reference uses,
+# vorta/ulysses/utils.py:48,80) -- a slot group is a receive layout of its own (`UlyssesLayout.grouping`), so its chunks are
+# contiguous on both sides like the whole-tensor exchange's.  There is no second transport (rounds 2-5 kept grouped send / recv
+# for the slot groups: a branch the one-rank RCCL rehearsal could not reach).
 # staging passes of device tensors: one vorta_permute_heads launch each ("hip"); "torch" keeps the index ops the CPU
 # rehearsals use (A/B measurements only)
 HIP_STAGING = __import__("os").environ.get("VORTA_SP_STAGING", "hip") != "torch"
@@ -265,6 +265,9 @@ def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, g
     enqueues the attention over local head slots [g0, g1) of the layout buffers.  With one group this is
     scatter -> attention -> gather.  With several, the exchange of group g+1 and the return of group g-1 are in
     flight while group g computes (both run on the communicator's stream, the attention on the current one).
+    With several groups the receive buffers are GROUP-MAJOR: slot group gi is a receive layout of its own inside them
+    (`lay.grouping(len(groups))[0][gi]`: `.lay` the sub-layout with its row map, `.buffer(buf)` its rows, `.head_view(buf)`),
+    which is what `attend` reads and writes -- so every group's exchange is one all_to_all_single per tensor.
     `vwire`: v travels as e4m3 (converted on this side with the scales of the whole sequence) into `vwire.buf`.
     `prepare()`: builds, on the current stream and BEFORE the group streams fork, every cached device object `attend` would
     otherwise build lazily (geometry tables, routing lists): a table built inside group 0's stream is not ordered against
@@ -272,7 +275,7 @@ def exchange_and_attend(lay: "UlyssesLayout", shards, bufs, head_order, texts, g
     if prepare is not None:
         prepare()
     handles = lay.scatter_heads_start(shards, bufs[:3], head_order, texts, groups, vwire=vwire)
-    state = lay.gather_heads_begin(out_shard, head_order, parts)
+    state = lay.gather_heads_begin(out_shard, head_order, parts, n_groups=len(groups))
     back = []
     side = None
     if len(groups) > 1 and GROUP_STREAMS and out_shard.is_cuda:
@@ -327,8 +330,7 @@ def tag_rows(t: int, heads: Sequence[int], tokens: torch.Tensor, kind: int, D: i
 def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, bufs, vwire: Optional["VWire"] = None,
                        break_order: bool = False, parts=None) -> dict:
     """Push integer-tagged q, k, v (`tag_rows`: value = f(tensor, head, token, channel)) through THIS layout's own exchange
-    -- the staging pass, the all_to_all_single (even or per-rank splits) or the grouped send / recv of every slot group,
-    the text rows, v as e4m3 when it travels that way, the return trip of the output and the all-gather of the text
+    -- the staging pass, the all_to_all_single (even or per-rank splits) of every slot group, the text rows, v as e4m3 when it travels that way, the return trip of the output and the all-gather of the text
     outputs -- with identity in place of attention (o = q), and compare EXACTLY on every rank:
       * every row of every local head slot of the q, k, v receive buffers, read through `row_map` as the kernels read
         them, against the row that head and token should hold (v as e4m3: against the bytes and scales this rank computes
@@ -350,23 +352,22 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
     texts = [tag_rows(t, range(H), torch.arange(T), 2, D, dt, dev) for t in range(3)] if T else None
     out_shard = torch.zeros((H, Sl, D), dtype=dt, device=dev)
     out_text = torch.zeros((H, T, D), dtype=dt, device=dev) if T else None
-    rv = lay.rows_video
-
     my_parts = None if parts is None else list(parts)[lay.starts[me]:lay.starts[me + 1]]
 
+    sgs, _, _ = lay.grouping(len(groups))
+
     def attend(g0, g1, gi):  # identity attention: the output rows of a head slot are its query rows
-        bufs[3][:rv].view(P, Hl, Sl, D)[:, g0:g1].copy_(bufs[0][:rv].view(P, Hl, Sl, D)[:, g0:g1])
-        if T:
-            bufs[3][rv:].view(Hl, Sl, D)[g0:g1, :T].copy_(bufs[0][rv:].view(Hl, Sl, D)[g0:g1, :T])
+        sg = sgs[gi]
+        sg.buffer(bufs[3]).copy_(sg.buffer(bufs[0]))
         for i in range(g0, g1):  # a partial slot: only the query tokens of its range
             if my_parts is not None and my_parts[i] is not None:
                 t0, t1 = my_parts[i]
-                o_i = lay.head_view(bufs[3])[i]
+                o_i = sg.head_view(bufs[3])[i - g0]
                 keep = torch.zeros(S, dtype=torch.bool, device=dev)
                 keep[t0:t1] = True
-                o_i[lay.row_map[:S].long()[~keep]] = 0
+                o_i[sg.lay.row_map[:S].long()[~keep]] = 0
                 if T and t1 != S:  # only the part that ends at the last video token answers the text queries
-                    o_i[lay.row_map[S:S + T].long()] = 0
+                    o_i[sg.lay.row_map[S:S + T].long()] = 0
 
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
@@ -377,15 +378,17 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
     ms = (time.perf_counter() - t0) * 1e3
 
     failed = []
-    rm = lay.row_map.long()
     all_tok = torch.arange(S)
     n16 = 2 if vwire is not None else 3
-    for t in range(n16):
-        got = lay.head_view(bufs[t])
-        if not torch.equal(got[:, rm[:S]], tag_rows(t, mine, all_tok, 1, D, dt, dev)):
-            failed.append("qkv"[t] + " video rows")
-        if T and not torch.equal(got[:, rm[S:S + T]], tag_rows(t, mine, torch.arange(T), 2, D, dt, dev)):
-            failed.append("qkv"[t] + " text rows")
+    for sg in sgs:
+        rm = sg.lay.row_map.long()
+        mine_g = mine[sg.g0:sg.g1]
+        for t in range(n16):
+            got = sg.head_view(bufs[t])
+            if not torch.equal(got[:, rm[:S]], tag_rows(t, mine_g, all_tok, 1, D, dt, dev)):
+                failed.append("qkv"[t] + " video rows")
+            if T and not torch.equal(got[:, rm[S:S + T]], tag_rows(t, mine_g, torch.arange(T), 2, D, dt, dev)):
+                failed.append("qkv"[t] + " text rows")
     if vwire is not None:  # the bytes and scales of ONE conversion over the assembled sequence of this rank's heads
         v_full = tag_rows(2, mine, all_tok, 1, D, dt, dev)
         amax = torch.zeros((Hl, D), dtype=torch.float32, device=dev)
@@ -396,16 +399,18 @@ def exchange_selfcheck(lay: "UlyssesLayout", head_order: Sequence[int], groups, 
         exp8 = torch.empty((Hl, S, D), dtype=torch.uint8, device=dev)
         vd = torch.empty((Hl, D), dtype=torch.float32, device=dev)
         ops.fp8_v_convert(v_full, amax, exp8, v_descale=vd)
-        got8 = lay.head_view(vwire.buf)
-        if not torch.equal(got8[:, rm[:S]], exp8):
-            failed.append("v video rows (e4m3 on the wire)")
         if T:
             exp8t = torch.empty((Hl, T, D), dtype=torch.uint8, device=dev)
             ops.fp8_v_convert(v_txt, amax, exp8t)
-            if not torch.equal(got8[:, rm[S:S + T]], exp8t):
+        for sg in sgs:
+            rm = sg.lay.row_map.long()
+            got8 = sg.head_view(vwire.buf)
+            if not torch.equal(got8[:, rm[:S]], exp8[sg.g0:sg.g1]):
+                failed.append("v video rows (e4m3 on the wire)")
+            if T and not torch.equal(got8[:, rm[S:S + T]], exp8t[sg.g0:sg.g1]):
                 failed.append("v text rows (e4m3)")
-        if not torch.equal(vwire.descale(0, Hl), vd):
-            failed.append("v_descale")
+            if not torch.equal(vwire.descale(sg), vd[sg.g0:sg.g1]):
+                failed.append("v_descale")
     if not torch.equal(out_shard, shards[0]):
         failed.append("returned sequence shard")
     if T and not torch.equal(out_text, texts[0]):
@@ -460,10 +465,36 @@ class VWire:
     def stage(self) -> torch.Tensor:
         return self._stage[:self.lay.Hv]
 
-    def descale(self, g0: int, g1: int) -> torch.Tensor:
-        """v_descale rows of the local head slots [g0, g1)"""
-        b = self.lay.starts[self.lay.rank]
-        return self.descale_all[b + g0:b + g1]
+    def descale(self, sg: "SlotGroup") -> torch.Tensor:
+        """v_descale rows of this rank's head slots of slot group `sg` (`descale_all` is in the send order of the exchange:
+        group-major, rank by rank inside a group)"""
+        b = sg.first + sg.lay.starts[sg.lay.rank]
+        return self.descale_all[b:b + sg.lay.Hl]
+
+
+class SlotGroup:
+    """Slot group gi of a layout's G: a receive layout of its own -- `lay`: its sub-layout (this rank holds `lay.Hl` = g1 - g0
+    of its slots; every rank's count of the group's slots in `lay.counts`), `row0`: where its rows start in the parent's
+    buffers, `first`: where its slots start in the group-major send order."""
+    __slots__ = ("lay", "row0", "first", "g0", "g1")
+
+    def __init__(self, lay, row0, first, g0, g1):
+        self.lay, self.row0, self.first, self.g0, self.g1 = lay, row0, first, g0, g1
+
+    def buffer(self, buf: torch.Tensor) -> torch.Tensor:
+        """this group's rows of a parent-layout buffer ((rows_total, D), or (1, rows_total[, D]) operand arrays)"""
+        if buf.shape[0] == 1 and buf.dim() in (2, 3):
+            return buf[:, self.row0:self.row0 + self.lay.rows_total]
+        return buf[self.row0:self.row0 + self.lay.rows_total]
+
+    def head_view(self, buf: torch.Tensor) -> torch.Tensor:
+        return self.lay.head_view(self.buffer(buf))
+
+    def text_view(self, buf: torch.Tensor) -> torch.Tensor:
+        """(slots, T, D) view of the text rows parked behind the group's video rows"""
+        l = self.lay
+        b = self.buffer(buf)
+        return b.as_strided((l.Hl, l.T, l.D), (l.Sl * l.D, l.D, 1), b.storage_offset() + l.rows_video * l.D)
 
 
 def make_row_map(S: int, T: int, P: int, Hl: int, device) -> torch.Tensor:
@@ -514,10 +545,55 @@ class UlyssesLayout:
         if key not in UlyssesLayout._ROW_MAPS:
             UlyssesLayout._ROW_MAPS[key] = make_row_map(S, T, P, self.Hl, device)
         self.row_map = UlyssesLayout._ROW_MAPS[key]
-        # loopback: every pass of the exchange that runs on THIS rank's GPU (staging gathers, own-chunk copies, text
-        # rows, the attention on the received layout, the un-permute) with the transfers themselves left out -- one
-        # rank's compute at P > 1 on a single GPU (bench.py --emulate-rank); remote chunks keep what the buffers held
-        self.loopback = False
+        self._loopback = False
+        self._parent = None  # the layout whose slot group this one is (`grouping`)
+        self._groupings = {}
+
+    # loopback: every pass of the exchange that runs on THIS rank's GPU (staging gathers, own-chunk copies, text rows, the
+    # attention on the received layout, the un-permute) with the transfers themselves left out -- one rank's compute at
+    # P > 1 on a single GPU (bench.py --emulate-rank); remote chunks keep what the buffers held.  A slot group follows its parent.
+    @property
+    def loopback(self) -> bool:
+        return self._loopback if self._parent is None else self._parent.loopback
+
+    @loopback.setter
+    def loopback(self, value: bool):
+        self._loopback = bool(value)
+
+    def grouping(self, n_groups: int):
+        """(slot groups, perm, inv) of this layout cut into `n_groups` slot groups (`slot_groups` of every rank's head count).
+        Slot group gi is a receive layout of its own: rank j holds `slot_groups(counts[j], G)[gi]` of its slots, the group's
+        rows follow those of the groups before it in the buffers ((P + 1) * Sl rows per slot: P video chunks + the text
+        segment), its tokens are read through ITS row map (the chunk stride is the group's slot count, not Hl).  The send
+        side orders the heads group-major -- group by group, rank by rank inside a group: `perm[x]` = the position in the
+        head order (rank-major) of send position x, `inv` its inverse -- so a group's heads for all ranks are one
+        contiguous block with the ranks' chunks in rank order: one all_to_all_single per tensor and group.
+        One group: the layout itself, identity permutation."""
+        G = max(1, int(n_groups))
+        if G not in self._groupings:
+            if G > min(self.counts):
+                raise ValueError(f"{G} slot groups, but a rank holds only {min(self.counts)} heads")
+            if G == 1:
+                ident = list(range(self.Hv))
+                self._groupings[G] = ([SlotGroup(self, 0, 0, 0, self.Hl)], ident, ident)
+            else:
+                cuts = [slot_groups(c, G) for c in self.counts]  # per rank: [(p0, p1)] per group
+                sgs, perm, first = [], [], 0
+                for gi in range(G):
+                    counts_g = [cuts[j][gi][1] - cuts[j][gi][0] for j in range(self.P)]
+                    for j in range(self.P):
+                        perm += list(range(self.starts[j] + cuts[j][gi][0], self.starts[j] + cuts[j][gi][1]))
+                    sub = UlyssesLayout(sum(counts_g), self.S, self.T, self.D, self.P, self.rank, self.device, self.dtype,
+                                        self.group, counts=counts_g)
+                    sub._parent = self
+                    g0, g1 = cuts[self.rank][gi]
+                    sgs.append(SlotGroup(sub, (self.P + 1) * self.Sl * g0, first, g0, g1))
+                    first += sum(counts_g)
+                inv = [0] * len(perm)
+                for x, i in enumerate(perm):
+                    inv[i] = x
+                self._groupings[G] = (sgs, perm, inv)
+        return self._groupings[G]
 
     def new_buffer(self) -> torch.Tensor:
         # zeros: the rows between a head's T text rows and the next head's are never written, and the fp8 conversion
@@ -532,25 +608,24 @@ class UlyssesLayout:
                                torch.zeros(nws, dtype=torch.float32, device=self.device))
 
     def fp8_views(self, bufs: Sequence[torch.Tensor], scale: Optional[float] = None, out=None,
-                  slots: Optional[Sequence[int]] = None, vwire: Optional["VWire"] = None):
+                  vwire: Optional["VWire"] = None, v_descale: Optional[torch.Tensor] = None):
         """e4m3 copies of the q, k, v receive buffers for the fp8 attention kernels: ONE conversion of each whole buffer
         (the head views overlap, so converting per view would redo it Hl times) in the quantiser's segmented row layout
         -- row r belongs to head slot (r // Sl) % Hl, text rows behind the video rows -- so every local head keeps its
-        own scales and key centre.  `slots` = (g0, g1): only the rows of those head slots (the slot group that has
-        landed; scales are per head, so the bytes are the ones a single call writes).  `vwire`: v arrived as e4m3
-        (`out.v` is its receive buffer): q and k only.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
+        own scales and key centre.  A slot group converts the rows of ITS layout when it has landed (scales are per head, so
+        the bytes are the ones one call over all heads writes).  `vwire`: v arrived as e4m3 (`out.v` is its receive
+        buffer, `v_descale` its scales): q and k only.  Returns (q8, k8, v8 head views, v_descale (Hl, D), operands)."""
         from ..routed import FP8_CENTER_K
         x = [b.view(1, self.rows_total, self.D) for b in bufs[:3]]
         if vwire is not None:
-            if out is None or out.v.data_ptr() != vwire.buf.data_ptr():
-                raise ValueError("fp8_views(vwire=...): `out` must be the operands whose v is the e4m3 receive buffer")
+            if out is None or v_descale is None:
+                raise ValueError("fp8_views(vwire=...): `out` = the operands whose v is the e4m3 receive buffer, `v_descale` its scales")
             x[2] = None
         f8 = ops.fp8_quantize_qkv(*x, scale, out=out, center_k=FP8_CENTER_K, heads=self.Hl, seg_len=self.Sl,
-                                  tail_first=self.rows_video, tail_len=self.T,
-                                  slots=None if slots is None or tuple(slots) == (0, self.Hl) else tuple(slots))
+                                  tail_first=self.rows_video, tail_len=self.T)
         shape, stride = (self.Hl, self.rows_total - (self.Hl - 1) * self.Sl, self.D), (self.Sl * self.D, self.D, 1)
-        hv = lambda t: t[0].as_strided(shape, stride)
-        vd = f8.v_descale if vwire is None else vwire.descale(0, self.Hl)
+        hv = lambda t: t[0].as_strided(shape, stride, t[0].storage_offset())
+        vd = f8.v_descale if vwire is None else v_descale
         return hv(f8.q), hv(f8.k), hv(f8.v), vd, f8
 
     def i8_operands(self) -> "ops.I8Operands":
@@ -562,22 +637,41 @@ class UlyssesLayout:
                               torch.ones((self.Hl,), dtype=torch.float32, device=dev),
                               torch.zeros(2 * self.Hl * self.D + self.Hl, dtype=torch.float32, device=dev))
 
-    def i8_views(self, bufs: Sequence[torch.Tensor], out: "ops.I8Operands", slots: Optional[Sequence[int]] = None):
+    def i8_views(self, bufs: Sequence[torch.Tensor], out: "ops.I8Operands"):
         """int8 keys of the k receive buffer (q's is sampled for the statistics): ONE conversion of the buffer in the
-        quantiser's segmented row layout, every local head with its own centres, balance vector and scale; `slots` = (g0, g1):
-        only those head slots (the slot group that has landed).  Returns the I8Operands whose k8 / k_bias are head views."""
+        quantiser's segmented row layout, every local head with its own centres, balance vector and scale (a slot group:
+        the rows of its layout, when it has landed).  Returns the I8Operands whose k8 / k_bias are head views."""
         ops.i8_quantize_k(bufs[0].view(1, self.rows_total, self.D), bufs[1].view(1, self.rows_total, self.D), out=out,
-                          heads=self.Hl, seg_len=self.Sl, tail_first=self.rows_video, tail_len=self.T,
-                          slots=None if slots is None or tuple(slots) == (0, self.Hl) else tuple(slots))
+                          heads=self.Hl, seg_len=self.Sl, tail_first=self.rows_video, tail_len=self.T)
         rows = self.rows_total - (self.Hl - 1) * self.Sl
-        k8 = out.k8[0].as_strided((self.Hl, rows, self.D), (self.Sl * self.D, self.D, 1))
-        kb = out.k_bias[0].as_strided((self.Hl, rows), (self.Sl, 1))
+        k8 = out.k8[0].as_strided((self.Hl, rows, self.D), (self.Sl * self.D, self.D, 1), out.k8[0].storage_offset())
+        kb = out.k_bias[0].as_strided((self.Hl, rows), (self.Sl, 1), out.k_bias[0].storage_offset())
         return ops.I8Operands(k8, kb, out.q_prep, out.k_head_scale, out.ws)
+
+    def group_operands(self, sg: "SlotGroup", parent, cache: dict):
+        """the 8-bit operand buffers (`fp8_operands` / `i8_operands` of this layout) as slot group `sg` sees them: its rows
+        of the byte arrays, its heads of the per-head tensors, and a workspace of its own (the quantiser's workspace is
+        laid out by head count, and groups convert on different streams).  `cache`: where the caller keeps them."""
+        if sg.lay is self:
+            return parent
+        key = (id(parent), sg.row0, sg.lay.Hl)
+        got = cache.get(key)
+        if got is None:
+            n, D, dev = sg.lay.Hl, self.D, self.device
+            if isinstance(parent, ops.I8Operands):
+                got = ops.I8Operands(sg.buffer(parent.k8), sg.buffer(parent.k_bias), parent.q_prep[sg.g0:sg.g1],
+                                     parent.k_head_scale[sg.g0:sg.g1], torch.zeros(2 * n * D + n, dtype=torch.float32, device=dev))
+            else:
+                nws = ops._C.lib().vorta_fp8_quant_ws_floats(n, D)
+                got = ops.Fp8Operands(sg.buffer(parent.q), sg.buffer(parent.k), sg.buffer(parent.v),
+                                      parent.v_descale[sg.g0:sg.g1], torch.zeros(nws, dtype=torch.float32, device=dev))
+            got = cache[key] = (got, parent)  # (the parent is kept alive: the key holds its id)
+        return got[0]
 
     def head_view(self, buf: torch.Tensor) -> torch.Tensor:
         """(Hl, rows, D) overlapping view: head slot i starts i*Sl rows into the buffer."""
         return buf.as_strided((self.Hl, self.rows_total - (self.Hl - 1) * self.Sl, self.D),
-                              (self.Sl * self.D, self.D, 1))
+                              (self.Sl * self.D, self.D, 1), buf.storage_offset())
 
     def _peer(self, j: int) -> int:
         return dist.get_global_rank(self.group, j) if self.group is not None else j
@@ -587,40 +681,15 @@ class UlyssesLayout:
         # the process group is gloo but the tensors live on a GPU (tests / 1-GPU rehearsals); RCCL is direct.
         return (not self.loopback) and self.device.type == "cuda" and dist.get_backend(self.group) == "gloo"
 
-    def _start(self, p2p):
-        """Enqueue one group of point-to-point operations; returns a handle for `_finish`.
-        p2p: list of ("send"|"recv", tensor, peer).  RCCL: asynchronous (the transfer runs on the communicator's
-        stream, ordered after everything already enqueued on the current stream); gloo rehearsal: completes here."""
-        if not p2p:
-            return None
-        if self.loopback:
-            if EMULATE_LINK_GBPS > 0 and self.device.type == "cuda":
-                sends = [t.numel() * t.element_size() for k, t, j in p2p if k == "send"]
-                return _wire_sleep(self.device, max(sends, default=0))
-            return None
-        if not self._staged():
-            ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._peer(j), self.group) for k, t, j in p2p]
-            return ("works", dist.batch_isend_irecv(ops))
-        host = [(k, t, t.detach().to("cpu") if k == "send" else torch.empty(t.shape, dtype=t.dtype), j) for k, t, j in p2p]
-        ops = [dist.P2POp(dist.isend if k == "send" else dist.irecv, h, self._peer(j), self.group) for k, t, h, j in host]
-        for r in dist.batch_isend_irecv(ops):
-            r.wait()
-        for k, t, h, j in host:
-            if k == "recv":
-                t.copy_(h)
-        return None
-
     @staticmethod
     def _finish(handle):
-        """Make the current stream wait for a group started by `_start` (no host synchronisation under RCCL)."""
+        """Make the current stream wait for collectives started by `_start_a2a` / `_start_allreduce_max` (no host
+        synchronisation under RCCL)."""
         if handle is not None and handle[0] == "event":  # (the emulated wire of a loopback rank)
             torch.cuda.current_stream().wait_event(handle[1])
         elif handle is not None:
             for r in handle[1]:
                 r.wait()
-
-    def _run(self, p2p):
-        self._finish(self._start(p2p))
 
     def _start_a2a(self, pairs, in_rows: Optional[Sequence[int]] = None, out_rows: Optional[Sequence[int]] = None):
         """One `all_to_all_single` per (input, output) pair -- the collective the reference uses
@@ -629,6 +698,10 @@ class UlyssesLayout:
         `in_rows` / `out_rows`: rows per chunk when the ranks hold different numbers of heads (default: equal chunks).
         Asynchronous under RCCL; returns a handle for `_finish`."""
         me = self.rank
+        if self.P == 1 and not FORCE_COLLECTIVES and not self.loopback:  # a world of one: the collective is a copy
+            for i, o in pairs:
+                o.copy_(i)
+            return None
         if self.loopback:  # the own chunk is what the collective would have copied locally
             for i, o in pairs:
                 ni = list(in_rows) if in_rows is not None else [i.shape[0] // self.P] * self.P
@@ -693,32 +766,34 @@ class UlyssesLayout:
     def scatter_heads(self, shards: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor], head_order: Sequence[int],
                       texts: Optional[Sequence[torch.Tensor]] = None):
         """shards[t]: (H, Sl, D) sequence shard of tensor t (q, k, v; any strides); bufs[t]: its layout buffer.
-        ONE message per (tensor, peer): the Hl heads bound for rank j are contiguous on the wire and land as the
-        contiguous row block [j*Hl*Sl, (j+1)*Hl*Sl) of the receiver's buffer -- 2(P-1) point-to-point ops per
-        tensor in one group (per-head messages would be 2(P-1)Hl: ~1000 ops per layer at P=8, H=24, a host-side
-        cost of the same order as the layer's compute).  The sender needs those heads contiguous: they are read
-        straight from the shard when they already are (a run of consecutive heads of a contiguous shard),
-        otherwise one gather pass (`index_select` into a staging buffer) orders all heads at once -- the
-        projection output is a strided (S, H*D) view anyway, so this replaces the per-head `.contiguous()`."""
+        ONE collective per tensor: the Hl heads bound for rank j are contiguous on the wire and land as the contiguous
+        row block [j*Hl*Sl, (j+1)*Hl*Sl) of the receiver's buffer (per-head messages would be 2(P-1)Hl operations: ~1000
+        per layer at P=8, H=24, a host-side cost of the same order as the layer's compute).  The sender needs the heads
+        in destination order: one gather pass (`vorta_permute_heads` into a staging buffer) orders all heads at once --
+        the projection output is a strided (S, H*D) view anyway, so this replaces the per-head `.contiguous()` -- or none
+        when a contiguous shard already is in that order."""
         self._finish(self.scatter_heads_start(shards, bufs, head_order, texts)[0])
 
     def scatter_heads_start(self, shards: Sequence[torch.Tensor], bufs: Sequence[torch.Tensor],
                             head_order: Sequence[int], texts: Optional[Sequence[torch.Tensor]] = None,
                             groups: Optional[Sequence[Sequence[int]]] = None, vwire: Optional[VWire] = None):
-        """`scatter_heads` split by local head slots: `groups` = [(slot0, slot1), ...] (default: one group with all
-        Hl slots).  One point-to-point group is started per slot group, in order; returns their handles, so the
-        attention over the slots of group g can be enqueued after `_finish(handles[g])` while later groups are still
-        in flight.  `vwire`: the third tensor (v) is converted to e4m3 on this side and travels into `vwire.buf`
-        (bufs[2] is not used): abs-max of the shard, MAX all-reduce (in flight under the q/k staging pass), conversion
-        into destination head order (under the q/k transfers when they are one collective)."""
+        """`scatter_heads` split by local head slots: `groups` = [(slot0, slot1), ...] = `slot_groups(Hl, G)` (default: one
+        group with all Hl slots).  One all_to_all_single per tensor is started per slot group, in order, into the group's
+        own receive layout (`grouping`); returns the groups' handles, so the attention over the slots of group g can be
+        enqueued after `_finish(handles[g])` while later groups are still in flight.  `vwire`: the third tensor (v) is
+        converted to e4m3 on this side and travels into `vwire.buf` (bufs[2] is not used): abs-max of the shard, MAX
+        all-reduce (in flight under the q/k staging pass), conversion into send order (under group 0's q/k transfers)."""
         Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
-        blk = Hl * Sl
         starts, counts = self.starts, self.counts
         groups = [(0, Hl)] if groups is None else [tuple(g) for g in groups]
         if groups != slot_groups(Hl, len(groups)):
             raise ValueError(f"slot groups {groups} are not slot_groups({Hl}, {len(groups)})")
         if len(groups) > min(counts):
             raise ValueError(f"{len(groups)} slot groups, but a rank holds only {min(counts)} heads")
+        if len(head_order) != self.Hv:
+            raise ValueError(f"head order of {len(head_order)} slots, the layout has {self.Hv}")
+        sgs, perm, _ = self.grouping(len(groups))
+        send_order = [head_order[i] for i in perm]  # group-major (= head_order with one group)
         red = None
         v_shard = v_text = None
         if vwire is not None:
@@ -732,100 +807,90 @@ class UlyssesLayout:
             red = self._start_allreduce_max(vwire.amax)
         srcs = []
         staged = []
+        in_place = len(groups) == 1 and self.even and self.Hv == self.H and send_order == list(range(self.H))
         for t, (x, buf) in enumerate(zip(shards, bufs)):
-            direct = (self.even and self.Hv == self.H and x.is_contiguous()
-                      and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P)))
-            if direct:
+            if in_place and x.is_contiguous():  # already in destination order: sent straight from the shard
                 src = x
-                first = [self._run_of(head_order, j * Hl, Hl) for j in range(P)]
             else:
                 src = self._stage(("s", t))
                 staged.append((x, src))
-                first = list(starts[:P])
-            srcs.append((src, first, buf))
+            srcs.append((src, buf))
         if staged:  # one gather pass orders the heads of every staged tensor
             if staged[0][0].is_cuda and HIP_STAGING:
-                ops.permute_heads([x for x, _ in staged], [y for _, y in staged], src_map=self._head_map(head_order))
+                ops.permute_heads([x for x, _ in staged], [y for _, y in staged], src_map=self._head_map(send_order))
             else:  # CPU rehearsal (gloo)
-                idx = torch.as_tensor(list(head_order), device=staged[0][0].device)
+                idx = torch.as_tensor(send_order, device=staged[0][0].device)
                 for x, y in staged:
                     torch.index_select(x, 0, idx, out=y)
         mine = head_order[starts[me]:starts[me + 1]]
         if texts is not None and self.T:  # texts[t]: (H, T, D) replicated; its rows follow each local head slot's video
-            if texts[0].is_cuda and HIP_STAGING:
-                dsts = [buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1)) for buf in bufs]
-                ops.permute_heads(list(texts), dsts, src_map=self._head_map(mine))
-            else:
-                for t, buf in zip(texts, bufs):
-                    for i in range(Hl):
-                        r0 = self.rows_video + i * Sl
-                        buf[r0:r0 + self.T].copy_(t[mine[i]])
+            for sg in sgs:
+                mine_g = mine[sg.g0:sg.g1]
+                if texts[0].is_cuda and HIP_STAGING:
+                    ops.permute_heads(list(texts), [sg.text_view(buf) for buf in bufs], src_map=self._head_map(mine_g))
+                else:
+                    for t, buf in zip(texts, bufs):
+                        sg.text_view(buf).copy_(t[torch.as_tensor(list(mine_g), device=t.device)])
 
         def convert_v():
             self._finish(red)
-            ops.fp8_v_convert(v_shard, vwire.amax, vwire.stage, src_map=self._head_map(head_order),
+            ops.fp8_v_convert(v_shard, vwire.amax, vwire.stage, src_map=self._head_map(send_order),
                               v_descale=vwire.descale_all)
             if v_text is not None:
-                dst = vwire.buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1))
-                ops.fp8_v_convert(v_text, vwire.amax, dst, src_map=self._head_map(mine))
-            return (vwire.stage, list(starts[:P]), vwire.buf)
+                for sg in sgs:
+                    ops.fp8_v_convert(v_text, vwire.amax, sg.text_view(vwire.buf), src_map=self._head_map(mine[sg.g0:sg.g1]))
+            return (vwire.stage, vwire.buf)
 
-        in_rank_order = all(first == list(starts[:P]) for _, first, _ in srcs)
-        if TRANSPORT == "a2a" and groups == [(0, Hl)] and in_rank_order and (P > 1 or FORCE_COLLECTIVES):
-            # the whole exchange of a tensor is ONE collective: rank-ordered contiguous chunks on both sides (rows per
-            # chunk follow the ranks' head counts on the send side; every peer sends this rank's Hl heads)
-            splits = (None, None) if self.even else ([c * Sl for c in counts], [blk] * P)
-            h = self._start_a2a([(src.view(self.Hv * Sl, self.D), buf[:P * blk]) for src, _, buf in srcs], *splits)
-            if vwire is not None:  # converted while q and k are on the links
-                src, _, buf = convert_v()
-                hv = self._start_a2a([(src.view(self.Hv * Sl, self.D), buf[:P * blk])], *splits)
-                if hv is not None and hv[0] == "event":  # (emulated wire: the second sleep follows the first on the wire stream)
-                    h = hv
-                else:
-                    h = None if h is None and hv is None else ("works", (h[1] if h else []) + (hv[1] if hv else []))
-            return [h]
-        if vwire is not None:
-            srcs.append(convert_v())
-        for src, first, buf in srcs:
-            buf[me * blk:(me + 1) * blk].view(Hl, Sl, self.D).copy_(src[first[me]:first[me] + Hl])
+        def start(sg, pairs):
+            # chunk j of the send block = rank j's slots of this group; every peer sends this rank's slots of it
+            l = sg.lay
+            blk = l.Hl * Sl
+            splits = (None, None) if l.even else ([c * Sl for c in l.counts], [blk] * P)
+            return l._start_a2a([(src.view(self.Hv * Sl, self.D)[sg.first * Sl:(sg.first + l.Hv) * Sl],
+                                  sg.buffer(buf)[:P * blk]) for src, buf in pairs], *splits)
+
+        def join(h, hv):
+            if hv is not None and hv[0] == "event":  # (emulated wire: the second sleep follows the first on the wire stream)
+                return hv
+            return None if h is None and hv is None else ("works", (h[1] if h else []) + (hv[1] if hv else []))
+
         handles = []
-        for gi, (g0, g1) in enumerate(groups):
-            p2p = []
-            for src, first, buf in srcs:
-                for j in range(P):
-                    if j != me:  # rank j's slots of ITS group gi
-                        p0, p1 = slot_groups(counts[j], len(groups))[gi]
-                        p2p.append(("send", src[first[j] + p0:first[j] + p1], j))
-                for j in range(P):
-                    if j != me:
-                        p2p.append(("recv", buf[j * blk + g0 * Sl:j * blk + g1 * Sl], j))
-            handles.append(self._start(p2p))
+        v_pair = None
+        for gi, sg in enumerate(sgs):
+            h = start(sg, srcs)
+            if vwire is not None:
+                if v_pair is None:  # converted while group 0's q and k are on the links
+                    v_pair = convert_v()
+                h = join(h, start(sg, [v_pair]))
+            handles.append(h)
         return handles
 
     # ---- head shards -> sequence shards -------------------------------------------------------------
     def gather_heads(self, buf: torch.Tensor, out_shard: torch.Tensor, head_order: Sequence[int],
                      out_text: Optional[torch.Tensor] = None):
-        """inverse of scatter_heads for the attention output: out_shard (H, Sl, D), any strides.  One message per
-        peer; received head blocks go straight into out_shard when their heads are a consecutive run of a
-        contiguous out_shard, else through a staging buffer and one `index_copy_`."""
+        """inverse of scatter_heads for the attention output: out_shard (H, Sl, D), any strides.  One collective;
+        received head blocks go straight into out_shard when it is contiguous and the heads are in natural order, else
+        through a staging buffer and one un-permute pass."""
         state = self.gather_heads_begin(out_shard, head_order)
         self._finish(self.gather_heads_start(buf, state))
         self.gather_heads_end(buf, state, out_text)
 
     def gather_heads_begin(self, out_shard: torch.Tensor, head_order: Sequence[int],
-                           parts: Optional[Sequence[Optional[tuple]]] = None):
+                           parts: Optional[Sequence[Optional[tuple]]] = None, n_groups: int = 1):
         """`parts` (`split_placement`): parts[i] = (t0, t1) when slot i of the head order computed only those query tokens
-        of its head; this rank's token shard then takes each row of the head from the slot whose range holds it"""
-        Hl, P = self.Hl, self.P
+        of its head; this rank's token shard then takes each row of the head from the slot whose range holds it.
+        `n_groups`: the slot groups the output returns in (the staging buffer is in their group-major send order)."""
         if parts is not None and not any(x is not None for x in parts):
             parts = None
         if (parts is None) != (self.Hv == self.H):
             raise ValueError("a head order with split heads needs `parts`, and only such an order takes them")
-        direct = (parts is None and self.even and out_shard.is_contiguous()
-                  and all(self._run_of(head_order, j * Hl, Hl) is not None for j in range(P)))
+        sgs, perm, inv = self.grouping(n_groups)
+        send_order = [head_order[i] for i in perm]
+        direct = (parts is None and len(sgs) == 1 and self.even and out_shard.is_contiguous()
+                  and send_order == list(range(self.H)))
         dst = out_shard if direct else self._stage(("g", 0))
-        first = [self._run_of(head_order, j * Hl, Hl) if direct else self.starts[j] for j in range(P)]
-        state = dict(out_shard=out_shard, order=list(head_order), direct=direct, dst=dst, first=first, parts=None)
+        state = dict(out_shard=out_shard, order=list(head_order), direct=direct, dst=dst, parts=None, sgs=sgs,
+                     send_order=send_order)
         if parts is not None:
             lo, hi = self.rank * self.Sl, (self.rank + 1) * self.Sl  # this rank's tokens
             slot_of = [-1] * self.H
@@ -852,30 +917,27 @@ class UlyssesLayout:
                     text_slot[h] = i
             if self.T and min(text_slot) < 0:
                 raise ValueError("no part of a split head ends at the last video token (the owner of its text rows)")
-            state.update(parts=list(parts), slot_of=slot_of, extra=extra, text_slot=text_slot)
+            # slots are positions of the head order; the staging buffer holds them in send order (`inv`)
+            state.update(parts=list(parts), slot_of=[inv[i] for i in slot_of],
+                         extra=[(inv[i], h, r0, r1) for i, h, r0, r1 in extra], text_slot=text_slot)
         return state
 
     def gather_heads_start(self, buf: torch.Tensor, state, slots: Optional[Sequence[int]] = None, gi: int = 0,
                            n_groups: int = 1):
-        """send the attention output of local head slots [slot0, slot1) (default: all) -- slot group `gi` of `n_groups`
-        -- back; returns the handle"""
-        Hl, Sl, me, P = self.Hl, self.Sl, self.rank, self.P
-        blk = Hl * Sl
-        g0, g1 = (0, Hl) if slots is None else slots
-        dst, first = state["dst"], state["first"]
-        if TRANSPORT == "a2a" and (g0, g1) == (0, Hl) and first == list(self.starts[:P]) and (P > 1 or FORCE_COLLECTIVES):
-            splits = (None, None) if self.even else ([blk] * P, [c * Sl for c in self.counts])
-            return self._start_a2a([(buf[:P * blk], dst.view(self.Hv * Sl, self.D))], *splits)
-        dst[first[me] + g0:first[me] + g1].copy_(buf[me * blk + g0 * Sl:me * blk + g1 * Sl].view(g1 - g0, Sl, self.D))
-        p2p = []
-        for j in range(P):
-            if j != me:
-                p2p.append(("send", buf[j * blk + g0 * Sl:j * blk + g1 * Sl], j))
-        for j in range(P):
-            if j != me:  # rank j returns ITS slots of its group gi
-                p0, p1 = (0, self.counts[j]) if slots is None else slot_groups(self.counts[j], n_groups)[gi]
-                p2p.append(("recv", dst[first[j] + p0:first[j] + p1], j))
-        return self._start(p2p)
+        """send the attention output of slot group `gi` (of the `n_groups` the state was begun with; `slots` = its local
+        slot range, checked) back: one all_to_all_single; returns the handle"""
+        Sl, P = self.Sl, self.P
+        sgs = state["sgs"]
+        if n_groups != len(sgs) or not 0 <= gi < len(sgs):
+            raise ValueError(f"slot group {gi} of {n_groups}: the exchange was begun with {len(sgs)} groups")
+        sg = sgs[gi]
+        if slots is not None and tuple(slots) != (sg.g0, sg.g1):
+            raise ValueError(f"slot group {gi} holds local slots {(sg.g0, sg.g1)}, not {tuple(slots)}")
+        l = sg.lay
+        blk = l.Hl * Sl
+        splits = (None, None) if l.even else ([blk] * P, [c * Sl for c in l.counts])
+        dst = state["dst"].view(self.Hv * Sl, self.D)[sg.first * Sl:(sg.first + l.Hv) * Sl]
+        return l._start_a2a([(sg.buffer(buf)[:P * blk], dst)], *splits)
 
     def gather_heads_end(self, buf: torch.Tensor, state, out_text: Optional[torch.Tensor] = None):
         """after every slot group's handle was finished: un-permute (if staged) and all-gather the text rows"""
@@ -891,13 +953,14 @@ class UlyssesLayout:
                 out_shard[h, r0:r1].copy_(state["dst"][i, r0:r1])
         elif not state["direct"]:
             if out_shard.is_cuda and HIP_STAGING:
-                ops.permute_heads([state["dst"]], [out_shard], dst_map=self._head_map(head_order))
+                ops.permute_heads([state["dst"]], [out_shard], dst_map=self._head_map(state["send_order"]))
             else:
-                out_shard.index_copy_(0, torch.as_tensor(head_order, device=out_shard.device), state["dst"])
+                out_shard.index_copy_(0, torch.as_tensor(state["send_order"], device=out_shard.device), state["dst"])
         if out_text is not None and self.T:
             cap = max(self.counts)  # equal message sizes for the collective: padded to the largest head count
             local = torch.empty((cap, self.T, self.D), dtype=buf.dtype, device=buf.device)
-            local[:Hl].copy_(buf[self.rows_video:].as_strided((Hl, self.T, self.D), (Sl * self.D, self.D, 1)))
+            for sg in state["sgs"]:
+                local[sg.g0:sg.g1].copy_(sg.text_view(buf))
             if cap > Hl:
                 local[Hl:].zero_()
             parts = [torch.empty_like(local) for _ in range(self.P)]
@@ -953,9 +1016,20 @@ class _RankState:
                 self.vwire = VWire(lay, self.f8.v[0])
                 if loopback:
                     self.f8.v.random_(0, 120)  # finite e4m3 bytes in the chunks no peer fills
-        self.geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], lay.device,
-                                   row_map=lay.row_map)
-        self.geom.prebuild(te if cfg["model"] == "hunyuan" else 0)
+        self.cfg, self.te, self.lay = cfg, te, lay
+        self._geoms, self.group_ops = {}, {}
+        self.geom = self.geom_for(lay)
+
+    def geom_for(self, lay: UlyssesLayout):
+        """the routed geometry composed with a layout's row map (one per distinct slot count: slot groups of equal size share it)"""
+        from ..routed import RoutedGeometry
+        g = self._geoms.get(lay.Hl)
+        if g is None:
+            cfg = self.cfg
+            g = self._geoms[lay.Hl] = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"],
+                                                     lay.device, row_map=lay.row_map)
+            g.prebuild(self.te if cfg["model"] == "hunyuan" else 0)
+        return g
 
 
 class UlyssesRoutedAttention:
@@ -1049,30 +1123,42 @@ class UlyssesRoutedAttention:
         return exchange_selfcheck(lay, self.orders[l], self.groups[l], st.bufs, vwire=st.vwire, break_order=break_order,
                                   parts=self.parts[l])
 
-    def layer(self, l: int):
+    def layer(self, l: int, exchange_only: bool = False):
+        """one layer: exchange in, routed attention per slot group, exchange back.  `exchange_only`: every pass of the exchange
+        and no attention (bench.py's breakdown of what the exchange costs by itself)"""
         from ..routed import routed_attention
         shards, texts = self.sets[l % len(self.sets)]
         lay = self.lays[l]
         st = self.states[lay.Hl]
-        q, k, v, o = (lay.head_view(b) for b in st.bufs)
         if st.vwire is not None:
             st.vwire.lay = lay  # the layouts of one slot count share the state; the head offsets are the layer's
+        sgs, _, _ = lay.grouping(len(self.groups[l]))
+        geoms = [st.geom_for(sg.lay) for sg in sgs]  # built (and their tables) before the slot groups fork onto their streams
 
         def attend(g0, g1, gi):
+            if exchange_only:
+                return
+            sg = sgs[gi]
+            sub = sg.lay
+            b = [sg.buffer(x) for x in st.bufs]
+            q, k, v, o = (sub.head_view(x) for x in b)
             views = None
             if self.fp8 in ("i8pv", "auto8"):  # k of the slot group that has landed -> int8; q as it landed; v arrived as e4m3
-                i8 = lay.i8_views(st.bufs, st.i8, slots=(g0, g1))
-                views = (q[g0:g1], i8.k8[g0:g1], lay.head_view(st.vwire.buf)[g0:g1], st.vwire.descale(g0, g1),
-                         i8.heads(g0, g1))
+                i8 = sub.i8_views(b, lay.group_operands(sg, st.i8, st.group_ops))
+                views = (q, i8.k8, sg.head_view(st.vwire.buf), st.vwire.descale(sg), i8)
                 if self.fp8 == "auto8":  # + the 16-bit keys and the group's tail flags: each head to the kernel that holds it
-                    views += (k[g0:g1], ops.i8_tail_flags(i8.k8[g0:g1], row_map=lay.row_map[:lay.S + lay.T]))
+                    views += (k, ops.i8_tail_flags(i8.k8, row_map=sub.row_map[:lay.S + lay.T]))
             elif self.fp8 == "fp8pv":  # 16-bit q, k as they landed; v arrived as e4m3
-                views = (q[g0:g1], k[g0:g1], lay.head_view(st.vwire.buf)[g0:g1], st.vwire.descale(g0, g1))
+                views = (q, k, sg.head_view(st.vwire.buf), st.vwire.descale(sg))
             elif self.fp8:  # the slot group that has landed is converted while the next one is in flight
-                q8, k8, v8, vd, st.f8 = lay.fp8_views(st.bufs, out=st.f8, slots=(g0, g1), vwire=st.vwire)
-                views = (q8[g0:g1], k8[g0:g1], v8[g0:g1], vd[g0:g1])
-            routed_attention(q[g0:g1], k[g0:g1], v[g0:g1], self.routes[l][gi], st.geom, model=self.cfg["model"],
-                             text_len=self.cfg["text"], text_valid=self.te, out=o[g0:g1], concurrent=self.concurrent,
+                f8 = lay.group_operands(sg, st.f8, st.group_ops)
+                q8, k8, v8, vd, f8 = sub.fp8_views(b, out=f8, vwire=st.vwire,
+                                                   v_descale=None if st.vwire is None else st.vwire.descale(sg))
+                if sub is lay:
+                    st.f8 = f8
+                views = (q8, k8, v8, vd)
+            routed_attention(q, k, v, self.routes[l][gi], geoms[gi], model=self.cfg["model"],
+                             text_len=self.cfg["text"], text_valid=self.te, out=o, concurrent=self.concurrent,
                              fused=self.fused, sliding_block_rows=self.sliding_block_rows, fp8=False, fp8_views=views,
                              kv_splits=self.kv_splits[l])
 
@@ -1080,4 +1166,4 @@ class UlyssesRoutedAttention:
         # copied to the device in __init__)
         exchange_and_attend(lay, shards, st.bufs, self.orders[l], texts, self.groups[l], attend, self.out_shard,
                             self.out_text, vwire=st.vwire, parts=self.parts[l],
-                            prepare=lambda: st.geom.prebuild(self.te if self.cfg["model"] == "hunyuan" else 0))
+                            prepare=lambda: [g.prebuild(self.te if self.cfg["model"] == "hunyuan" else 0) for g in geoms])

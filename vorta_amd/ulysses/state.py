@@ -69,8 +69,9 @@ def resolve_placement(name: str, H: int, P: int) -> str:
 
 
 def default_sp_groups(heads_per_rank: int, precision=False) -> int:
-    """Slot groups of the exchange when nothing is asked for (`VORTA_SP_GROUPS=auto`, `bench.py --sp-groups auto`): the heads of a
-    rank travel in that many groups so that the exchange of one overlaps the attention of another.  Chosen from the one-GPU
+    """Slot groups of the exchange under `VORTA_SP_GROUPS=auto` / `bench.py --sp-groups auto` (opt-in; the default is ONE group
+    until a node run has measured the links): the heads of a rank travel in that many groups so that the exchange
+    of one overlaps the attention of another.  Chosen from the one-GPU
     emulation of the heaviest rank of 8 with an ASSUMED wire (60 / 150 GB/s per xGMI link + 10 us per collective;
     profiles/r05_sp_groups_emulated.txt) -- the RCCL transport has not run on a node yet:
       3 heads per rank (Hunyuan, 24 / 8): 1 group (2 / 3 groups lose 2-3 % at 150 GB/s, gain 2 % at 60);
@@ -78,6 +79,6 @@ def default_sp_groups(heads_per_rank: int, precision=False) -> int:
       5 heads per rank, int8 / e4m3 scores (the attention is 1.6-1.8 x shorter, the wire is not): 3 groups (-2 % / -9 %)."""
     if heads_per_rank < 4:
         return 1
-    if precision in ("i8pv", True, "fp8") and heads_per_rank >= 5:
+    if precision in ("i8pv", "auto8", True, "fp8") and heads_per_rank >= 5:  # ("auto8" runs the int8-score kernels)
         return 3
     return 2
