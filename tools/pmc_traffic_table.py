@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--json", required=True)
     ap.add_argument("--head", default=os.environ.get("VORTA_TREE_HEAD"), help="git head of the profiled tree (the GPU box has no .git: "
                     "the caller passes it, e.g. VORTA_TREE_HEAD=$(git rev-parse --short=12 HEAD) in the gpurun command)")
-    ap.add_argument("--source", default="tools/measure/r5_round.sh")
+    ap.add_argument("--source", default="tools/measure/r6_gpu.sh")
     a = ap.parse_args()
     import bench as B
     table = {}

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Join the [t0 .. t1] window each probe line prints with rocm-smi samples taken beside the run (tools/measure/r4_probe_shape.sh):
+"""Join the [t0 .. t1] window each probe line prints with rocm-smi samples taken beside the run (round 4: tools/measure/r4_probe_shape.sh in the history of the tree):
 mean socket power and sclk over the second half of each window."""
 import json
 import re

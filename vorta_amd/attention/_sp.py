@@ -39,9 +39,9 @@ def _sp_groups(H: int, P: int) -> int:
         return int(SP_GROUPS)
     from .. import routed as _routed
     return default_sp_groups(H // max(P, 1), _routed.DEFAULT_FP8)
-# fp8 under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_SP_V_WIRE=0 keeps the
-# 16-bit exchange with the receive-side conversion (A/B; same bytes in the operand buffers either way)
-SP_V_WIRE = __import__("os").environ.get("VORTA_SP_V_WIRE", "1") != "0"
+# e4m3 attention under sequence parallelism: v crosses the links as e4m3 (ulysses/engine.py VWire); VORTA_DEBUG=sp_v_wire=0 keeps
+# the 16-bit exchange with the receive-side conversion (A/B; same bytes in the operand buffers either way)
+SP_V_WIRE = __import__("vorta_amd._debug", fromlist=["flag"]).flag("sp_v_wire", "1") != "0"
 # head placement (VORTA_SP_PLACEMENT; bench.py --placement follows the same rule through `resolve_placement`):
 #   "auto" (default) = "even" when P divides the heads, "uneven" otherwise: the exchange with equal splits is the one every
 #       test and rehearsal exercises most, and on balanced routes the two are the same placement;

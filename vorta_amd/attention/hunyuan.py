@@ -50,9 +50,9 @@ def fused_norm_rope(x: torch.Tensor, norm, rope: Optional[Tuple[torch.Tensor, to
 
 # project video and text tokens straight into ONE (1, S+T, H*D) buffer per tensor: the `torch.cat([q, eq], dim=2)` of a
 # dual-stream block (hunyuan.py:106-134: a read and a write of all of q, k and v) and the input concat of a
-# single-stream block (hunyuan.py:47-48) disappear (SURVEY.md §8f N1 "+ text concat").  VORTA_JOINT_PROJECTION=0: the
+# single-stream block (hunyuan.py:47-48) disappear (SURVEY.md §8f N1 "+ text concat").  VORTA_DEBUG=joint_projection=0: the
 # reference's route (A/B, tests).
-JOINT_PROJECTION = __import__("os").environ.get("VORTA_JOINT_PROJECTION", "1") != "0"
+JOINT_PROJECTION = __import__("vorta_amd._debug", fromlist=["flag"]).flag("joint_projection", "1") != "0"
 
 
 def _linear_into(lin: torch.nn.Linear, x2d: torch.Tensor, dst: torch.Tensor) -> None:

@@ -9,7 +9,8 @@
 //
 // What an int32 accumulator must NOT cost is VALU work per score (a first version with a scale per key row -- convert,
 // multiply, multiply-add, exp2, pack: five instructions per score -- ran at the mixed kernel's 1.2 x of bf16, not at the
-// e4m3 kernel's 1.7 x).  Here a score costs TWO instructions between the score MFMA and the P V MFMA:
+// e4m3 kernel's 1.7 x).  Here a score costs TWO instructions between the score MFMA and the P V MFMA (round 6: 1.75 -- the
+// conversions two at a time, VORTA_I8_PKNORM below):
 //   * the accumulator starts from 0x4B400000 + seed[key] (the integer whose float reading is 1.5 2^23 + seed), so after the
 //     MFMAs its bits READ AS A FLOAT are 1.5 2^23 + (q8 . k8 + seed), exactly: no v_cvt_f32_i32;
 //   * one v_fma_f32 with the wave's unit (8 scale log2e sq sk) and an offset that folds the magic constant, the reference
@@ -65,8 +66,12 @@ constexpr float SEED_LIMIT = 2000000.f;  // |q8 . k8| <= 2 064 512; the sum must
 // (TWO scores per instruction: unorm16(x) = round(clamp(x, 0, 1) * 65535), with 1 / 65535 folded into the multiply-add that makes
 // y) + 8 v_perm_b32 (the low bytes of two such registers) = 24 instead of 32 v_cvt_pk_u8_f32.  tools/probe_cvt_pknorm.hip: what it
 // rounds to and what it costs; profiles/r06_i8_pknorm.txt: the same-box A/B.
+// Rounding: v_cvt_pknorm_u16_f32 gives rint(y) off the ties and rounds ties UP where v_cvt_pk_u8_f32 rounds them to even (0 of
+// 133 120 grid values differ off the ties); the folded constant moves 2 of 3 397 bytes by one unit (double rounding next to a tie).
+// Same issue cost per instruction (5.1-5.3 cycles, one wave).  Same box, alternating: Wan-14B-81f fused layer 26.35 -> 25.93 ms
+// (+1.6 %), Hunyuan-129f 38.10 -> 37.61 (+1.3 %); -DVORTA_I8_PKNORM=0 (variant builds) = the round-5 conversions.
 #ifndef VORTA_I8_PKNORM
-#define VORTA_I8_PKNORM 0
+#define VORTA_I8_PKNORM 1
 #endif
 constexpr float K65 = 1.f / 65535.f;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;

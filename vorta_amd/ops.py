@@ -37,8 +37,9 @@ class Timeline:
 
 
 _timeline: Optional[Timeline] = None
-DEFAULT_VARIANT = int(__import__("os").environ.get("VORTA_ATTN_VARIANT", "0"))
-NO_XCD_REMAP = int(__import__("os").environ.get("VORTA_NO_XCD_REMAP", "0"))
+from ._debug import flag as _debug_flag  # (A/B switches: one gate, VORTA_DEBUG)
+DEFAULT_VARIANT = int(_debug_flag("attn_variant", "0"))
+NO_XCD_REMAP = int(_debug_flag("no_xcd_remap", "0"))
 
 
 def set_timeline(t: Optional[Timeline]):

@@ -162,9 +162,10 @@ def _auto_splits(n_heads: int, n_q: int, n_kv: int) -> int:
     return max(1, min(want, kv_blocks // 8 if kv_blocks >= 16 else 1, 256))
 
 
+from ._debug import flag as _debug_flag  # the A/B switches below sit behind ONE gate: VORTA_DEBUG="key=value,..." (_debug.py)
 # merge query tiles of equal key lists into one group of the sliding-tile launch (RoutedGeometry.sta_launch_tables);
-# VORTA_STA_MERGE=0: one group per tile, as round 1 (A/B)
-STA_MERGE = __import__("os").environ.get("VORTA_STA_MERGE", "1") != "0"
+# sta_merge=0: one group per tile, as round 1 (A/B)
+STA_MERGE = _debug_flag("sta_merge", "1") != "0"
 # process-wide default of `routed_attention(fp8=None)`: the processors of vorta.attention call it that way, so the
 # unchanged inference scripts pick an 8-bit path up from the environment or from `set_attention_precision(...)`:
 # False (native), "fp8pv" (16-bit scores, e4m3 P V), "i8pv" (int8 scores: one key scale per head, one query scale per wave;
@@ -184,17 +185,17 @@ if _PREC_ENV not in ("",) + PRODUCT_PRECISIONS:
     raise ValueError(f"VORTA_ATTENTION_PRECISION={_PREC_ENV!r}: one of {PRODUCT_PRECISIONS}")
 DEFAULT_FP8 = _PREC_ENV if _PREC_ENV in ("fp8pv", "i8pv", "auto8") else False
 # the e4m3 conversion subtracts a per-head centre from the keys (softmax-invariant, buys back what a common component of
-# the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); VORTA_FP8_CENTER_K=0 turns it off (A/B)
-FP8_CENTER_K = __import__("os").environ.get("VORTA_FP8_CENTER_K", "1") != "0"
-# coreset expert, key side: VORTA_CORESET_KV_ORDER=group reads K/V through a group-major ascending row list (the same rows
+# the keys costs in e4m3: include/vorta_hip.h vorta_fp8_quant_args.flags); fp8_center_k=0 turns it off (A/B)
+FP8_CENTER_K = _debug_flag("fp8_center_k", "1") != "0"
+# coreset expert, key side: coreset_kv_order=group reads K/V through a group-major ascending row list (the same rows
 # as the reference's packed [centres | margins] list; softmax does not see key order).  Measured NEUTRAL at Hunyuan-129f
 # fp16 (coreset launch 1 111 vs 1 109 TFLOP/s, fused step 4 099 vs 4 094 ms, profiles/r03_coreset_kv_order.txt): the
 # launch's distance from the full-attention one is its tail (7.3 rounds of workgroups) and the row tables, not the
 # gather's locality -- so the default stays the reference's order.
-CORESET_KV_GROUP_MAJOR = __import__("os").environ.get("VORTA_CORESET_KV_ORDER", "packed") == "group"
+CORESET_KV_GROUP_MAJOR = _debug_flag("coreset_kv_order", "packed") == "group"
 # fused grid: the sliding expert's text-query segment goes first with at most this many key splits (0: as round 1 -- last,
 # with the stand-alone launch's split count; A/B)
-FUSED_TEXT_SPLITS = int(__import__("os").environ.get("VORTA_FUSED_TEXT_SPLITS", "1"))
+FUSED_TEXT_SPLITS = int(_debug_flag("fused_text_splits", "1"))
 FUSED_TEXT_FIRST = FUSED_TEXT_SPLITS > 0
 
 

@@ -30,16 +30,17 @@ from .. import ops
 # vorta/ulysses/utils.py:48,80) -- a slot group is a receive layout of its own (`UlyssesLayout.grouping`), so its chunks are
 # contiguous on both sides like the whole-tensor exchange's.  There is no second transport (rounds 2-5 kept grouped send / recv
 # for the slot groups: a branch the one-rank RCCL rehearsal could not reach).
-# staging passes of device tensors: one vorta_permute_heads launch each ("hip"); "torch" keeps the index ops the CPU
+from .._debug import flag as _debug_flag  # A/B switches: VORTA_DEBUG="key=value,..." (vorta_amd/_debug.py)
+# staging passes of device tensors: one vorta_permute_heads launch each ("hip"); sp_staging=torch keeps the index ops the CPU
 # rehearsals use (A/B measurements only)
-HIP_STAGING = __import__("os").environ.get("VORTA_SP_STAGING", "hip") != "torch"
-# slot groups attend on alternating HIP streams (VORTA_SP_GROUP_STREAMS=0: all on the current stream, A/B)
-GROUP_STREAMS = __import__("os").environ.get("VORTA_SP_GROUP_STREAMS", "1") != "0"
+HIP_STAGING = _debug_flag("sp_staging", "hip") != "torch"
+# slot groups attend on alternating HIP streams (sp_group_streams=0: all on the current stream, A/B)
+GROUP_STREAMS = _debug_flag("sp_group_streams", "1") != "0"
 # One-GPU emulation of a rank (loopback) with a WIRE: every collective of the exchange holds a side stream for the time its
 # largest chunk needs at this many GB/s per xGMI link (+ 10 us), and `_finish` makes the consumer wait for it -- so the
 # emulation ranks 1 / 2 / 3 slot groups by what the overlap hides.  0 (default) = transfers are free, as in rounds 2-4.
 # An ASSUMPTION about the links, not a measurement of them (profiles/r05_sp_groups_emulated.txt).
-EMULATE_LINK_GBPS = float(__import__("os").environ.get("VORTA_SP_EMULATE_LINK_GBPS", "0") or 0)
+EMULATE_LINK_GBPS = float(_debug_flag("sp_emulate_link_gbps", "0") or 0)
 # Rehearsal on a world of ONE rank (tests/test_hip_rccl_single_rank.py): issue the collectives of the whole-tensor exchange --
 # all_to_all_single with one chunk, the all-reduces, the text all-gather -- although there is no peer, so that the direct RCCL
 # branch runs on the one-GPU box (RCCL refuses two ranks on one device).  Off in every product run.
