@@ -1,6 +1,7 @@
 # Round 6: one parameterised script per kind of GPU call (PART=...), run through gpurun from the repo root:
 #   PART=tests   the GPU suite (verbose: a line per test), with a heartbeat so a long quiet test is not taken for a hang
 #   PART=probe   tools/probe_cvt_pknorm.hip (what v_cvt_pknorm_u16_f32 rounds to and costs)
+#   PART=shape   tools/probe_mfma_shape.hip part F (SHAPE_PARTS=32): the 16x16x32 step at 64 query rows per wave
 #   PART=i8ab    same-box alternating A/B of int8-score kernel variants (VARIANTS="pkn ...": libvorta_hip_<name>.so)
 #   PART=bench   the round's bench lines (+ rocprofv3 kernel stats of the default command)
 #   PART=psnr    tools/structured_psnr.py tables
@@ -24,6 +25,10 @@ tests)
 probe)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/probe_cvt_pknorm.hip -o /tmp/probe_cvt_pknorm 2> /dev/null
   timeout -k 10 120 /tmp/probe_cvt_pknorm | tee $O/probe_cvt_pknorm.txt
+  ;;
+shape)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -enable-post-misched=0 tools/probe_mfma_shape.hip -o /tmp/probe_shape 2> /dev/null
+  timeout -k 10 600 /tmp/probe_shape ${SHAPE_PARTS:-32} 2 | tee $O/probe_mfma_shape_partF.txt
   ;;
 i8ab)
   set -- $VARIANTS

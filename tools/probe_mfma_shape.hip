@@ -11,6 +11,8 @@
 //           MFMA = what 64 query rows per wave would read), and 16x16x32 (two 16-row query tiles per wave; a fragment
 //           feeds two MFMAs there by construction).  Not numerically meaningful -- the addresses, instruction mix and
 //           operand statistics are those of the product loop, the values are not checked.
+//   part F  (argv[1] & 32, round 6) the 16x16x32 step with FOUR 16-row query tiles per wave and one wave per SIMD (64 query rows per
+//           wave: every fragment feeds four MFMAs), beside the 32x32x16 step and part C's 16x16x32 step
 // Per variant: wall time (HIP events), TFLOP/s, shader clock inside the loop (s_memtime / s_memrealtime), shader cycles
 // per step.  2 waves per SIMD (512 threads, one workgroup per CU), every CU busy, ~2 s of back-to-back launches each.
 //   hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -mllvm -enable-post-misched=0 tools/probe_mfma_shape.hip -o /tmp/probe_shape
@@ -341,6 +343,111 @@ __global__ __launch_bounds__(512, 2) void attn_like(long long* out, int iters, c
   }
 }
 
+// ---------------------------------------------------------------- part F (round 6) -----------------------------------
+// the 16x16x32 step at 64 QUERY ROWS PER WAVE -- four 16-row query tiles per wave, ONE wave per SIMD (256
+// threads per workgroup, the 512-register budget), so that every K and V fragment feeds FOUR MFMAs (0.25 KiB of LDS reads per
+// MFMA; part C's 16x16x32 step read 0.5 KiB with two waves per SIMD and was issue-bound: 2 844 cycles against 2 202).  Same rows
+// per CU (256), same FLOPs per CU and step as part C.  Per wave and 64-key block: 64 + 64 MFMAs (1 024 issue cycles of 2 048 of
+// pipe), the VALU work of 64 x 64 scores, 16 K-fragment reads + 32 transposed V reads.
+template <typename T, int VALU>
+__global__ __launch_bounds__(256) void attn_like64(long long* out, int iters) {
+  using V8 = typename M<T>::v8;
+  using V4 = typename M<T>::v4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+  fill_lds<T, 1>(smem);
+  const int lane = threadIdx.x & 63;
+  V8 qf[16];  // [qt][ks]
+  _Pragma("unroll") for (int s = 0; s < 16; ++s)
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) qf[s][i] = rnd<T>(threadIdx.x * 128 + s * 8 + i + 4242, 0.35f);
+  int v_rd[4];
+  {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pp = i16 & 3;
+    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) v_rd[dt] = TILE + (4 * (g >> 1) + q4) * ROWB + ((dt ^ q4) << 6) + 32 * (g & 1) + 8 * pp;
+  }
+  int k16_rd[4];
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) k16_rd[ks] = (lane & 15) * ROWB + (((4 * ks + (lane >> 4)) ^ (lane & 15)) << 4);
+  float l_run = 0.f;
+  f32x4 o[8][4], sA[4][4], sB[4][4], minit;
+  _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) _Pragma("unroll") for (int i = 0; i < 4; ++i) o[dt][qt][i] = 0.f;
+  _Pragma("unroll") for (int kt = 0; kt < 4; ++kt) _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) _Pragma("unroll") for (int i = 0; i < 4; ++i) { sA[kt][qt][i] = -6.f; sB[kt][qt][i] = -7.f; }
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) minit[i] = -6.f;
+  asm volatile("" : "+v"(minit));
+#define STEP64(c_, n_)                                                                                           \
+  {                                                                                                              \
+    _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_) {                                                        \
+      _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                      \
+        const V8 kf_ = *(const V8*)(smem + k16_rd[ks_] + 16 * kt_ * ROWB);                                       \
+        _Pragma("unroll") for (int qt_ = 0; qt_ < 4; ++qt_)                                                      \
+          n_[kt_][qt_] = M<T>::m16(kf_, qf[4 * qt_ + ks_], ks_ == 0 ? minit : n_[kt_][qt_]);                     \
+      }                                                                                                          \
+    }                                                                                                            \
+    V8 pb_[2][4]; /* [k-step of 32 keys][query tile] */                                                          \
+    if (VALU) {                                                                                                  \
+      float lsum_ = 0.f;                                                                                         \
+      _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_)                                                        \
+        _Pragma("unroll") for (int qt_ = 0; qt_ < 4; ++qt_)                                                      \
+          _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+            c_[kt_][qt_][i_] = __builtin_amdgcn_exp2f(c_[kt_][qt_][i_]);                                         \
+            lsum_ += c_[kt_][qt_][i_];                                                                           \
+          }                                                                                                      \
+      l_run += lsum_;                                                                                            \
+    }                                                                                                            \
+    _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_)                                                             \
+      _Pragma("unroll") for (int qt_ = 0; qt_ < 4; ++qt_)                                                        \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                       \
+          pb_[s_][qt_][e_] = (T)c_[2 * s_][qt_][e_];                                                             \
+          pb_[s_][qt_][4 + e_] = (T)c_[2 * s_ + 1][qt_][e_];                                                     \
+        }                                                                                                        \
+    _Pragma("unroll") for (int dt_ = 0; dt_ < 8; ++dt_) {                                                        \
+      _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) {                                                         \
+        const V4 lo_ = M<T>::tr(smem + v_rd[dt_ & 3] + (32 * s_ + 16 * (dt_ >> 2)) * ROWB);                     \
+        const V4 hi_ = M<T>::tr(smem + v_rd[dt_ & 3] + (32 * s_ + 16 * (dt_ >> 2) + 8) * ROWB);                 \
+        V8 vf_;                                                                                                  \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { vf_[e_] = lo_[e_]; vf_[4 + e_] = hi_[e_]; }           \
+        _Pragma("unroll") for (int qt_ = 0; qt_ < 4; ++qt_) o[dt_][qt_] = M<T>::m16(vf_, pb_[s_][qt_], o[dt_][qt_]); \
+      }                                                                                                          \
+    }                                                                                                            \
+    if (VALU) {                                                                                                  \
+      int m0_ = __float_as_int(n_[0][0][0]), m1_ = __float_as_int(n_[0][1][0]);                                  \
+      _Pragma("unroll") for (int kt_ = 0; kt_ < 4; ++kt_)                                                        \
+        _Pragma("unroll") for (int qt_ = 0; qt_ < 4; qt_ += 2) {                                                 \
+          m0_ = max(max(m0_, __float_as_int(n_[kt_][qt_][1])), __float_as_int(n_[kt_][qt_][2]));                 \
+          m1_ = max(max(m1_, __float_as_int(n_[kt_][qt_ + 1][1])), __float_as_int(n_[kt_][qt_ + 1][2]));         \
+          m0_ = max(max(m0_, __float_as_int(n_[kt_][qt_][3])), __float_as_int(n_[kt_][qt_ + 1][3]));             \
+          m1_ = max(max(m1_, __float_as_int(n_[kt_][qt_ + 1][0])), __float_as_int(n_[kt_][qt_][0]));             \
+        }                                                                                                        \
+      mx_ = max(mx_, max(m0_, m1_));                                                                             \
+    }                                                                                                            \
+    /* issue recipe: score half -- per K fragment read four MFMAs, a probability's exp + pack under each; P V half -- per */ \
+    /* pair of transposed reads four MFMAs with the max / sum work under them                                              */ \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                         \
+      _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);    \
+      }                                                                                                          \
+    }                                                                                                            \
+    _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                                                          \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                         \
+      _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_) {                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);    \
+      }                                                                                                          \
+    }                                                                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                              \
+  }
+  int mx_ = 0;
+  const Stamp s0 = stamp();
+  for (int it = 0; it < iters; ++it) {
+    STEP64(sA, sB)
+    STEP64(sB, sA)
+  }
+  const Stamp s1 = stamp();
+#undef STEP64
+  float s = l_run + (float)mx_;
+  _Pragma("unroll") for (int dt = 0; dt < 8; ++dt) _Pragma("unroll") for (int qt = 0; qt < 4; ++qt) _Pragma("unroll") for (int i = 0; i < 4; ++i) s += o[dt][qt][i];
+  if (threadIdx.x == 0) { out[blockIdx.x * 4] = s1.cyc - s0.cyc; out[blockIdx.x * 4 + 1] = s1.real - s0.real; out[blockIdx.x * 4 + 2] = (long long)s; }
+}
+
 // ---------------------------------------------------------------- host ----------------------------------------------
 static int cmp_ll(const void* a, const void* b) { long long x = *(const long long*)a, y = *(const long long*)b; return x < y ? -1 : x > y; }
 static double now() { struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
@@ -404,6 +511,12 @@ void all(long long* d, int parts) {
   snprintf(lab, sizeof lab, "%s step 1 KiB LDS/MFMA + 32 KiB K/V stream per block (L2 hits), %s", M<T>::name(), WHAT);      \
   run(lab, d, G, 2.0 * 32 * 64 * 128 * 2 * 2, 2.0, 12000, [&](int it) {                                                    \
     hipLaunchKernelGGL((attn_like<T, 0, 1, 1, PAIR>), dim3(G), dim3(512), 0, 0, d, it, (const char*)g_src, 8192); });
+#define ATT64(VALU)                                                                                                        \
+  snprintf(lab, sizeof lab, "%s step 16x16x32, 64 rows per wave, 1 wave per SIMD (0.25 KiB per MFMA), %s", M<T>::name(),    \
+           VALU ? "exp+sum+cvt+max" : "cvt only");                                                                         \
+  /* 4 waves of 64 rows: `run` counts 8 waves per workgroup, so half the per-wave figure keeps the workgroup's FLOPs right */ \
+  run(lab, d, G, 2.0 * 32 * 64 * 128 * 2 * 2, 2.0, 12000, [&](int it) { hipLaunchKernelGGL((attn_like64<T, VALU>), dim3(G), dim3(256), 0, 0, d, it); });
+  if (parts & 32) { ATT(0, 1) ATT(2, 1) ATT64(1) ATT(0, 0) ATT(2, 0) ATT64(0) }
   if (parts & 16) {
     ATT(0, 1)
     ATTE(0, "vmcnt(0) + barrier per block (the product)")
