@@ -59,6 +59,24 @@ def build(force: bool = False, verbose: bool = True, extra_flags=None, suffix: s
     return lib
 
 
+SP_LIB = os.path.join(CSRC, "libvorta_sp.so")
+
+
+def build_sp(force: bool = False, verbose: bool = True) -> str:
+    """libvorta_sp.so (include/vorta_sp.h): the Ulysses exchange on RCCL behind a C ABI -- host code, linked against librccl; a
+    library of its own, so that libvorta_hip.so (kernels) keeps depending on the HIP runtime alone"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, "sp_rccl.hip")
+    if force or _newer(src, SP_LIB) or _newer(os.path.join(INCLUDE, "vorta_sp.h"), SP_LIB):
+        rocm = os.path.dirname(os.path.dirname(hipcc))
+        cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE, src, "-o", SP_LIB,
+               "-L" + os.path.join(rocm, "lib"), "-lrccl"]
+        if verbose:
+            print("[vorta_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SP_LIB
+
+
 def kernel_resources(source: str):
     """Compile one source to gfx950 assembly with the product flags and return, per kernel symbol, the register /
     spill / scratch / LDS figures of its code-object metadata (works without a GPU)."""
@@ -81,3 +99,4 @@ def kernel_resources(source: str):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv or bool(os.environ.get("VORTA_BUILD_SUFFIX")))
+    build_sp(force="--force" in sys.argv)
