@@ -42,8 +42,12 @@ def lib():
     """the library, every declared symbol bound (a missing one raises: the header and the build must agree)"""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(PATH):
-            raise RuntimeError(f"{PATH} is missing: python -m vorta_amd.build (needs librccl)")
+        if not os.path.exists(PATH):  # not built yet: build it (hipcc + librccl; seconds), loudly if that fails
+            from ..build import build_sp
+            try:
+                build_sp(verbose=False)
+            except Exception as exc:
+                raise RuntimeError(f"{PATH} is missing and could not be built (python -m vorta_amd.build; needs hipcc and librccl): {exc}")
         l = C.CDLL(PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError names the missing symbol
