@@ -2,8 +2,8 @@
 
 Replaces the per-expert all_to_all_4D / shrink_dim / all_gather choreography of the reference
 (hunyuan.py:147-164,184-187,423-431,453-455,481-489,500-503; wan.py:110-117,138-139,146-147,245-248,267-268,
-280-283,291-292): ALL heads are resharded once per layer, before routing, with one contiguous message per
-(head, peer); routing then happens on the local heads, so any expert mix works under SP (the reference needs
+280-283,291-292): ALL heads are resharded once per layer, before routing, with one all_to_all_single per tensor whose
+chunks are contiguous on both sides; routing then happens on the local heads, so any expert mix works under SP (the reference needs
 h_e % P == 0 for every expert).
 """
 from typing import Optional

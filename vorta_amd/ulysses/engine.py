@@ -14,6 +14,9 @@ mix works), and the head -> rank placement is free: `balanced_head_order` gives 
 of expert costs (routes depend only on the timestep, so they are known when the layer starts).
 Text tokens are replicated: each rank copies its heads' text rows behind the video rows
 (`shrink_dim` in the reference, hunyuan.py:158-160) and the text outputs are all-gathered over heads (:187).
+The transport is ONE `all_to_all_single` per tensor -- the reference's collective (utils.py:48,80) -- for the whole layer, or per
+slot group when the exchange is overlapped with the attention: a slot group is a receive layout of its own inside the same
+buffers (`UlyssesLayout.grouping`), with its own row map.
 """
 from __future__ import annotations
 
