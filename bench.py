@@ -461,30 +461,53 @@ def supervise(args) -> int:
         return rc, rcs, held
 
     rc, rcs, held = attempt(0, [], None)
-    if all(x == 0 for x in rcs) or args.conservative or args.no_fallback:
-        if rank == 0:
-            for l in held:
-                print(l, flush=True)
-        return rc if rc != 0 else max(rcs, key=abs)
-    first_error = f"exit codes {rcs}"
+    # Rank 0 decides for everyone (the others cannot see its child's stdout): the attempt counts when every child left with 0 --
+    # or when the measurement was made and printed and only the TEARDOWN of some rank failed (a crash in a communicator's
+    # destructor must not throw a finished measurement away).  A failed attempt is final under --conservative / --no-fallback.
     if rank == 0:
+        measured = any(l.startswith('{"metric"') for l in held)
+        clean = all(x == 0 for x in rcs)
+        first_error = f"exit codes {rcs}"
         errs = [l for l in held if l.startswith('{"error"')]
         if errs:
             try:
                 first_error = json.loads(errs[-1]).get("error", first_error) + f" (exit codes {rcs})"
             except ValueError:
                 pass
+        if clean or measured or args.conservative or args.no_fallback:
+            decision = "accept" if (clean or measured) else "final"
+        else:
+            decision = "fallback"
+        store.set("a0/decision", decision + "\n" + first_error)
+    else:
+        store.wait(["a0/decision"], timedelta(seconds=120))
+    decision, first_error = store.get("a0/decision").decode().split("\n", 1)
+    if decision != "fallback":
+        if rank == 0:
+            for l in held:
+                print(l, flush=True)
+            if decision == "accept" and any(rcs):
+                print(f"[bench] the measurement was printed; exit codes {rcs} came from the ranks' teardown", file=sys.stderr, flush=True)
+        if decision == "accept":
+            return 0
+        return rc if rc != 0 else max(rcs, key=abs)
+    if rank == 0:
         for l in held:
             print("[bench attempt 0] " + l, file=sys.stderr, flush=True)
         print(f"[bench] first attempt failed ({first_error}); one fresh --conservative child per rank", file=sys.stderr, flush=True)
-        store.set("a0/error", first_error)
-    else:
-        store.wait(["a0/error"], timedelta(seconds=60))
-        first_error = store.get("a0/error").decode()
     rc, rcs, held = attempt(1, ["--conservative"], first_error)
     if rank == 0:
         for l in held:
             print(l, flush=True)
+        if any(l.startswith('{"metric"') for l in held) and any(rcs):
+            print(f"[bench] the fallback's measurement was printed; exit codes {rcs} came from the ranks' teardown", file=sys.stderr, flush=True)
+            store.set("a1/accept", "1")
+        else:
+            store.set("a1/accept", "0")
+    else:
+        store.wait(["a1/accept"], timedelta(seconds=120))
+    if store.get("a1/accept") == b"1":
+        return 0
     return rc if rc != 0 else max(rcs, key=abs)
 
 
@@ -502,7 +525,7 @@ def attempt_store(attempt: int, world: int, timeout):
 def stub_worker(args, rank: int, world: int, attempt: int) -> int:
     """CPU stand-in of a worker for the supervisor's rehearsal (VORTA_BENCH_STUB = comma-separated behaviours of the FIRST attempt:
     "fail" every rank exits 3 after a collective, "fail0" only rank 0 raises while the others wait in a collective, "hang1" rank 1
-    never joins): a real gloo process group per attempt (its own rendezvous prefix), one all-reduce, ONE JSON line from rank 0."""
+    never joins, "teardown1" rank 1 exits non-zero after the line was printed): a real gloo process group per attempt (its own rendezvous prefix), one all-reduce, ONE JSON line from rank 0."""
     import torch.distributed as dist
     from datetime import timedelta
     how = os.environ["VORTA_BENCH_STUB"].split(",") if attempt == 0 and not args.conservative else []
@@ -526,6 +549,8 @@ def stub_worker(args, rank: int, world: int, attempt: int) -> int:
                           **({"fallback": "conservative", "first_attempt_error": os.environ.get("VORTA_BENCH_FIRST_ATTEMPT_ERROR", "")}
                              if attempt > 0 else {})}), flush=True)
     dist.destroy_process_group()
+    if "teardown1" in how and rank == 1:  # the measurement is out; this rank's exit fails
+        return 7
     return 0
 
 

@@ -60,3 +60,12 @@ def test_no_fallback_and_conservative_leave_a_failed_attempt_final():
     assert len(lines) == 1 and "error" in lines[0], r.stdout[-1000:]
     r = _run("ok", ["--conservative"])
     assert r.returncode == 0 and _json_lines(r.stdout)[0]["conservative"] is True
+
+
+def test_a_failed_teardown_does_not_throw_a_finished_measurement_away():
+    """rank 1 leaves with a non-zero code AFTER rank 0 printed the line: the attempt counts (exit code 0, no fallback)"""
+    r = _run("teardown1")
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["metric"] == "stub" and "fallback" not in lines[0] and lines[0]["conservative"] is False
+    assert "teardown" in r.stderr and "first attempt failed" not in r.stderr
