@@ -311,7 +311,8 @@ def processor_level(cfg, mix, dev, dt, fp8):
 XGMI_LINK_GBPS = 153.0  # per direction and link, 7 links per GPU (MI355X_MICROARCH.md)
 
 
-def exchange_breakdown(sp, cfg, args, ms_per_step, barrier, dist, dev, world, fp8, backend, reps: int = 2):
+def exchange_breakdown(sp, cfg, args, ms_per_step, barrier, dist, dev, world, fp8, backend,
+                       reps: int = int(os.environ.get("VORTA_BENCH_BREAKDOWN_REPS", "2"))):
     """Two more passes over the same layers, each bracketed like the timed region (barrier + synchronize, MAX over ranks):
       * exchange only -- staging pass, every slot group's all_to_all_single in and back, text all-gather, un-permute, NO attention:
         `exchange_ms_per_layer`, and with the bytes a rank puts on each link, the rate the links reached;

@@ -7,6 +7,9 @@
 #   PART=psnr    tools/structured_psnr.py tables
 #   PART=pmc     counter passes (FETCH_SIZE, WRITE_SIZE, MFMA-busy family, GRBM_GUI_ACTIVE: one family per pass, no trace domains)
 #                of WORKLOADS="cfg:mix:dtype ..." and the tables tools/pmc_traffic_table.py / pmc_summary.py fold them into
+#   PART=fullsp  BASELINE configs[3] / [4] at FULL SIZE through the N > 1 code path on ONE GPU: RANKS (default 2) ranks sharing the GPU,
+#                gloo host-staged messages (VORTA_BENCH_BACKEND=gloo): the tagged self-check, the step and the exchange breakdown on the
+#                production shapes (the rates say nothing about xGMI; the bytes and the index maps are the production's)
 #   PART=lines   the other configurations' lines + the heaviest rank of 8 + the processor-level line (LINES="cfg:dtype ...")
 # VORTA_TREE_HEAD = git head of the tree (the box has no .git), stamped into the traffic table.
 set -ux
@@ -91,6 +94,15 @@ pmc)
     tail -12 $O/r06_pmc_$tag.txt
   done
   rm -rf $OO/pmc $OO/pmc_mfma_* $OO/pmc_gui_*  # the raw counter csvs are large
+  ;;
+fullsp)
+  for c in ${CONFIGS:-hunyuan-129f:fp16}; do
+    VORTA_BENCH_BACKEND=gloo VORTA_BENCH_BREAKDOWN_REPS=1 VORTA_BENCH_TIMEOUT_S=600 timeout -k 10 ${LIMIT:-1000} python3 bench.py --gpus ${RANKS:-2} \
+      --config ${c%%:*} --dtype ${c##*:} --steps 1 --warmup 0 --no-cpu-baseline ${EXTRA:-} > $O/fullsp_${c%%:*}_${c##*:}_p${RANKS:-2}.json 2> $O/fullsp_err.txt
+    echo "rc=$?"; tail -3 $O/fullsp_err.txt | cut -c1-300
+    python3 -c "
+import json; d=json.loads([l for l in open('$O/fullsp_${c%%:*}_${c##*:}_p${RANKS:-2}.json') if l.startswith('{')][-1]); print({k: d.get(k) for k in ('n_gpus','ms_per_step','exchange_selfcheck','exchange','fallback','error')})"
+  done
   ;;
 lines)
   NB="--no-cpu-baseline --no-gemm-ceiling"
