@@ -479,14 +479,20 @@ def dense_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, kv_val
 
 
 _GEOMETRY_CACHE: Dict[tuple, RoutedGeometry] = {}
+_GEOMETRY_CACHE_MAX = 48
 
 
 def geometry_for(latent, tile, window, group, rate, device, row_map: Optional[torch.Tensor] = None) -> RoutedGeometry:
     """Process-wide cache: the tables are built once per geometry, not once per layer call."""
     key = (tuple(latent), tuple(tile), tuple(window), tuple(group), float(rate), str(device),
            None if row_map is None else (row_map.data_ptr(), row_map.numel()))
-    g = _GEOMETRY_CACHE.get(key)
+    g = _GEOMETRY_CACHE.pop(key, None)
     if g is None:
         g = RoutedGeometry(latent, tile, window, group, rate, torch.device(device), row_map=row_map)
-        _GEOMETRY_CACHE[key] = g
+        # bounded: a geometry holds its sliding-tile tables (13 MB at Hunyuan-129f) and, under sequence parallelism, there is one
+        # per distinct slot count of a rank (slot groups and uneven placements: up to ~2 H / P of them per resolution); the least
+        # recently used one goes when a process has seen more than this many (the row maps they are keyed on are never freed)
+        while len(_GEOMETRY_CACHE) >= _GEOMETRY_CACHE_MAX:
+            _GEOMETRY_CACHE.pop(next(iter(_GEOMETRY_CACHE)))
+    _GEOMETRY_CACHE[key] = g  # most recently used last
     return g
