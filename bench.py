@@ -643,7 +643,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if (world > 1 and os.environ.get("VORTA_BENCH_WORKER") != "1"
+    # VORTA_BENCH_FORCE_SP=1 (tests/test_hip_bench.py, with VORTA_SP_FORCE_COLLECTIVES=1): ONE rank takes the whole N > 1 path --
+    # supervisor, process group on "nccl", the exchange's collectives on a world of one, self-check, breakdown -- the only
+    # end-to-end rehearsal of `bench.py --gpus N` on RCCL that a one-GPU box allows (RCCL refuses two ranks on one device)
+    sp_run = world > 1 or os.environ.get("VORTA_BENCH_FORCE_SP") == "1"
+    if (sp_run and os.environ.get("VORTA_BENCH_WORKER") != "1"
             and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"):
         # started by torch.distributed.run (the driver's N > 1 command, or `self_launch` above): this process stays GPU-free
         # and supervises a child; without the launcher's store (another launcher) the process is the worker itself
@@ -658,7 +662,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    if world > 1:
+    if sp_run:
         # a collective that never completes must not eat the caller's whole time limit and leave no line: the process group's
         # watchdog aborts the ranks after this long (VORTA_BENCH_TIMEOUT_S), and `guarded` below turns that into one JSON line
         from datetime import timedelta
@@ -673,7 +677,7 @@ def main():
     me = {"rank": rank, "local_rank": local_rank, "device": dev_index, "name": props.name,
           "uuid": str(getattr(props, "uuid", "")), "host": os.uname().nodename, "pid": os.getpid()}
     ranks_seen = [me]
-    if world > 1:
+    if sp_run:
         ranks_seen = [None] * world
         dist.all_gather_object(ranks_seen, me)
 
@@ -709,7 +713,7 @@ def main():
         if P != 1:
             raise SystemExit("--level processor runs on one GPU")
         one_step, fp_tensor, layer_ids, proc_info = processor_level(cfg, args.mix, dev, dt, fp8)
-    elif P == 1:
+    elif P == 1 and not sp_run:
         geom = RoutedGeometry(cfg["latent"], cfg["tile"], cfg["window"], cfg["group"], cfg["rate"], dev)
         routings = [HeadRouting.from_expert_ids(e, dev) for e in layer_ids]
         sets = []
@@ -745,14 +749,14 @@ def main():
                     sp.layer(l)
 
     def barrier():
-        if world > 1:
+        if sp_run:
             dist.barrier()
         torch.cuda.synchronize()
 
     # N > 1: before anything is timed, prove that the exchange moves the right bytes on THIS transport (RCCL on the driver's
     # node, gloo in the one-GPU rehearsals): vorta_amd/ulysses/engine.py exchange_selfcheck on layer 0's placement
     selfcheck = None
-    if world > 1 and not args.no_selfcheck:
+    if sp_run and not emu and not args.no_selfcheck:
         # (VORTA_SP_SELFCHECK_BREAK=1, tests only: breaks the FIRST attempt, so the fallback has something to recover from)
         selfcheck = sp.selfcheck(0, break_order=os.environ.get("VORTA_SP_SELFCHECK_BREAK") == "1" and attempt == 0)
         if not selfcheck["ok"]:
@@ -780,16 +784,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ops.set_timeline(None)
-    if world > 1:
+    if sp_run:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / args.steps
     # order-independent fingerprint of the last layer's output (all ranks): lets two runs of one workload -- other slot
     # groups, v on the wire or not -- be compared bit for bit from their JSON lines
-    fp_t = (fp_tensor() if proc_info is not None else out if P == 1 else sp.out_shard).contiguous().view(torch.int16).to(torch.int64)
+    fp_t = (fp_tensor() if proc_info is not None else out if (P == 1 and not sp_run) else sp.out_shard).contiguous().view(torch.int16).to(torch.int64)
     fingerprint = (fp_t * (torch.arange(fp_t.numel(), device=dev).view(fp_t.shape) % 8191 + 1)).sum().reshape(1)
-    if world > 1:
+    if sp_run:
         fingerprint = fingerprint * (rank + 1)
         dist.all_reduce(fingerprint)
     fingerprint = int(fingerprint.item())
@@ -797,7 +801,7 @@ def main():
 
     # ---- N > 1: what the exchange costs and how much of it the step hides (after the timed region, never part of `value`) ----
     exchange = None
-    if world > 1:
+    if sp_run and not emu:
         exchange = exchange_breakdown(sp, cfg, args, ms_per_step, barrier, dist, dev, world, fp8, backend)
 
     # ---- roofline of the dominant kernel symbol (largest share of the timed region) ----
@@ -836,7 +840,7 @@ def main():
             if wl is not None:
                 pmc_file = os.path.basename(f)
                 break
-        if wl is not None and world == 1 and not emu and proc_info is None:
+        if wl is not None and world == 1 and not sp_run and not emu and proc_info is None:
             base = dom_sym.split("<")[0]
             hit = [v for k_, v in wl["kernels"].items() if base in k_]
             if len(hit) == 1:
@@ -868,19 +872,19 @@ def main():
             "upper bound of the %d-GPU value, not a measurement of it" % (emu, emu)} if emu else {}),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
-        "backend": (backend if world > 1 else None), "output_fingerprint": fingerprint,
+        "backend": (backend if sp_run else None), "output_fingerprint": fingerprint,
         **({"exchange_selfcheck": selfcheck} if selfcheck is not None else {}),
         **({"fallback": "conservative", "first_attempt_error": os.environ.get("VORTA_BENCH_FIRST_ATTEMPT_ERROR", "")}
            if attempt > 0 else {}),
         **({"exchange": exchange} if exchange is not None else {}),
-        "process_group": {"world_size": dist.get_world_size() if world > 1 else 1,
-                          "backend": dist.get_backend() if world > 1 else None,
+        "process_group": {"world_size": dist.get_world_size() if sp_run else 1,
+                          "backend": dist.get_backend() if sp_run else None,
                           "distinct_devices": len({(r["host"], r["uuid"] or r["device"]) for r in ranks_seen}),
                           "ranks": ranks_seen},
         "config": {"workload": f"{args.config}: {cfg['model']} latent {cfg['latent']} S={S} text {T}/{te} H={H} "
                                f"layers={L} x{cfg['fwd_per_step']} fwd/step; tile {cfg['tile']} window {cfg['window']} "
                                f"coreset {cfg['group']} r={cfg['rate']}; routing mix '{args.mix}' (rng 1234+layer)",
-                   "parallelism": "single GPU" if P == 1 else (f"heaviest rank (layer by layer) of ulysses sp{P}, emulated on one GPU, no transfers"
+                   "parallelism": "single GPU" if (P == 1 and not sp_run) else (f"heaviest rank (layer by layer) of ulysses sp{P}, emulated on one GPU, no transfers"
                                                                if emu else f"ulysses sp{P} (RCCL all-to-all over xGMI)")
                    + (f", {args.sp_groups} overlapped slot groups" if args.sp_groups > 1 else "")
                    + (f", key splits {args.kv_splits} (per layer: {sorted(set(sp.kv_splits))})" if P > 1 and args.kv_splits != "1" else "")
@@ -910,7 +914,7 @@ def main():
         "switches": {"env": {k_: v_ for k_, v_ in sorted(os.environ.items()) if k_.startswith("VORTA_")},
                      "library": __import__("vorta_amd._C", fromlist=["lib"]).lib().vorta_build_info().decode()},
     }
-    if world == 1 and not args.no_gemm_ceiling:
+    if world == 1 and not sp_run and not args.no_gemm_ceiling:
         # context for `frac`: what a plain library GEMM (hipBLASLt via torch.matmul, same dtype) sustains on THIS
         # box right now -- the practical MFMA ceiling under the chip's power/clock management (measured after the
         # timed region, never part of `value`)
@@ -939,16 +943,16 @@ def main():
         except Exception as exc:  # context only: never let it cost the bench line
             roofline["library_gemm_tflops"] = None
             roofline["library_gemm_error"] = f"{type(exc).__name__}: {exc}"[:200]
-    if world == 1 and not args.no_gemm_ceiling and not emu and proc_info is None:
+    if world == 1 and not sp_run and not args.no_gemm_ceiling and not emu and proc_info is None:
         borrowed_dense(cfg, S, te, H, L, dev, roofline, res, achieved, layer_ids)
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not emu and proc_info is None:
+        if world == 1 and not sp_run and not args.no_cpu_baseline and not emu and proc_info is None:
             res["cpu_baseline"] = cpu_baseline(cfg, layer_ids, cfg["dtype"])
         abandoned = res.pop("_abandoned_thread", False)
         print(json.dumps(res), flush=True)
         if abandoned:  # the line is out; do not wait for a thread that may never return
             os._exit(0)
-    if world > 1:
+    if sp_run:
         dist.destroy_process_group()
 
 

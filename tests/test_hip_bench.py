@@ -226,3 +226,32 @@ def test_bench_processor_level_line():
         j = _line(r.stdout)
         assert j["config"]["call_path"]["level"] == "processor" and j["config"]["call_path"]["sync_debug_mode"] == "error"
         assert j["value"] > 0 and "cpu_baseline" not in j and j["roofline"]["achieved"] > 0
+
+
+def test_bench_multi_gpu_path_end_to_end_on_rccl_with_one_rank():
+    """The whole `bench.py --gpus N` path on a REAL RCCL process group -- the launcher, the GPU-free supervisor, the per-attempt
+    rendezvous store, init_process_group("nccl", device_id=...), the exchange's collectives (all_to_all_single, all-reduce,
+    all-gather), the tagged self-check, the timed step, the exchange breakdown, the teardown -- with ONE rank (VORTA_BENCH_FORCE_SP=1
+    + VORTA_SP_FORCE_COLLECTIVES=1): RCCL refuses two ranks on one device, so this is the only end-to-end rehearsal of the
+    driver's multi-GPU command a one-GPU box allows.  Its layer output equals the single-GPU run's (same fingerprint)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", VORTA_BENCH_FORCE_SP="1", VORTA_SP_FORCE_COLLECTIVES="1")
+    base = ["--gpus", "1", "--config", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-gemm-ceiling"]
+    fps = {}
+    for dtype, extra in (("bf16", []), ("i8pv", ["--sp-groups", "2"])):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), "bench.py"] + base + ["--dtype", dtype] + extra, cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (dtype, r.stdout[-1500:], r.stderr[-3000:])
+        j = _line(r.stdout)
+        assert j["backend"] == "nccl" and j["process_group"]["backend"] == "nccl" and j["process_group"]["world_size"] == 1
+        assert j["exchange_selfcheck"]["ok"] is True and j["exchange"]["exchange_ms_per_layer"] > 0 and "fallback" not in j
+        assert "ulysses sp1" in j["config"]["parallelism"]
+        fps[dtype] = j["output_fingerprint"]
+        single = subprocess.run([sys.executable, "bench.py"] + base + ["--dtype", dtype], cwd=ROOT,
+                                env={k: v for k, v in env.items() if not k.startswith("VORTA_")}, capture_output=True, text=True, timeout=600)
+        assert single.returncode == 0, single.stderr[-2000:]
+        assert _line(single.stdout)["output_fingerprint"] == fps[dtype] != 0, dtype
