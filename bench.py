@@ -354,6 +354,8 @@ def exchange_breakdown(sp, cfg, args, ms_per_step, barrier, dist, dev, world, fp
     for lay in sp.lays:
         peers = [j for j in range(lay.P) if j != lay.rank]
         chunk = lambda heads: heads * lay.Sl * lay.D
+        if not peers:  # a world of one (the RCCL rehearsal): nothing leaves the rank
+            continue
         link_in += max(chunk(lay.counts[j]) for j in peers) * (2 * esz + v_bytes)  # q, k, v to the peer holding most heads
         link_out += chunk(lay.Hl) * esz  # o back: this rank's slots to every peer
         egress += sum(chunk(lay.counts[j]) for j in peers) * (2 * esz + v_bytes) + len(peers) * chunk(lay.Hl) * esz
@@ -401,8 +403,9 @@ def supervise(args) -> int:
     with `--conservative` (auto placement, one slot group, v in 16 bits: the oldest form of the exchange), whose line carries
     `"fallback": "conservative"` and `"first_attempt_error"`.  The supervisors agree through the launcher's own TCPStore
     (TORCHELASTIC_USE_AGENT_STORE; each attempt's ranks rendezvous under their own prefix of it, `attempt_store`), so a
-    failed first attempt cannot leave a multi-GPU run without a number.  Rank 0's supervisor relays its child's stdout; the JSON
-    lines of a failed attempt that is followed by a fallback go to stderr, so stdout carries ONE JSON line."""
+    failed first attempt cannot leave a multi-GPU run without a number.  Rank 0's supervisor relays its child's stdout: JSON lines to
+    stdout, everything else (RCCL's version banner, warnings) to stderr; the JSON lines of a failed attempt that is followed by a
+    fallback go to stderr too, so stdout carries ONE JSON line and nothing else."""
     import subprocess
     from datetime import timedelta
 
@@ -436,9 +439,9 @@ def supervise(args) -> int:
                 for line in proc.stdout:
                     if line.startswith("{"):
                         held.append(line.rstrip("\n"))
-                    else:
-                        sys.stdout.write(line)
-                        sys.stdout.flush()
+                    else:  # (RCCL prints its version banner on stdout: stdout is kept for the JSON line)
+                        sys.stderr.write(line)
+                        sys.stderr.flush()
             th = threading.Thread(target=pump, daemon=True)
             th.start()
         t0 = time.perf_counter()

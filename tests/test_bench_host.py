@@ -35,7 +35,7 @@ def test_supervised_run_relays_one_line():
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     lines = _json_lines(r.stdout)
     assert len(lines) == 1 and lines[0]["metric"] == "stub" and lines[0]["value"] == 3.0 and "fallback" not in lines[0]
-    assert "[stub] a line that is not JSON" in r.stdout  # other output is relayed as it comes
+    assert "[stub] a line that is not JSON" in r.stderr and r.stdout.strip().count("\n") == 0  # stdout: the JSON line alone
 
 
 @pytest.mark.parametrize("stub", ["fail", "fail0", "hang1"])
