@@ -429,7 +429,8 @@ def supervise(args) -> int:
         if first_error is not None:
             env["VORTA_BENCH_FIRST_ATTEMPT_ERROR"] = first_error[:600]
         cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra
-        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else None, text=True)
+        # (the other ranks' children print nothing of the contract: their stdout joins stderr, stdout stays the JSON line's)
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=True)
         current["proc"] = proc
         held = []
         if rank == 0:
