@@ -396,7 +396,7 @@ def self_launch(n: int) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def supervise(args) -> int:
+def supervise(args):
     """One of the N processes a launcher (torch.distributed.run) started for a multi-GPU run, acting as a GPU-FREE supervisor: it
     runs the measurement in a CHILD process (same arguments, same rank environment; never an exec) and, when ANY rank's first
     attempt fails -- a self-check mismatch, an RCCL error, a collective that never completes -- starts ONE fresh child per rank
@@ -411,8 +411,15 @@ def supervise(args) -> int:
 
     from torch.distributed import PrefixStore, TCPStore
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    store = PrefixStore("/vorta_bench_supervisor", TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world,
-                                                            False, timedelta(seconds=120)))
+    try:
+        store = PrefixStore("/vorta_bench_supervisor", TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world,
+                                                                False, timedelta(seconds=120)))
+        store.set(f"hello/{rank}", "1")
+        store.wait([f"hello/{j}" for j in range(world)], timedelta(seconds=120))  # every rank supervises, or none does
+    except Exception as exc:  # noqa: BLE001 -- no store to agree through: this process runs the measurement itself, as before round 6
+        print(f"[bench] rank {rank}: cannot reach the launcher's store ({type(exc).__name__}: {exc}); running unsupervised",
+              file=sys.stderr, flush=True)
+        return None
     cap_s = float(os.environ.get("VORTA_BENCH_ATTEMPT_TIMEOUT_S", "1500"))
     current = {}
 
@@ -523,7 +530,10 @@ def attempt_store(attempt: int, world: int, timeout):
     if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() != "true":
         return {}
     from torch.distributed import PrefixStore, TCPStore
-    store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, False, timeout)
+    try:
+        store = TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, False, timeout)
+    except Exception:  # noqa: BLE001 -- let init_process_group's own rendezvous report it
+        return {}
     return dict(store=PrefixStore(f"/vorta_bench/attempt_{attempt}", store), rank=int(os.environ["RANK"]), world_size=world)
 
 
@@ -655,7 +665,9 @@ def main():
             and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"):
         # started by torch.distributed.run (the driver's N > 1 command, or `self_launch` above): this process stays GPU-free
         # and supervises a child; without the launcher's store (another launcher) the process is the worker itself
-        sys.exit(supervise(args))
+        rc = supervise(args)  # (None: the launcher's store could not be reached -- carry on as the worker)
+        if rc is not None:
+            sys.exit(rc)
     attempt = int(os.environ.get("VORTA_BENCH_ATTEMPT", "0"))
     if os.environ.get("VORTA_BENCH_STUB"):  # tests/test_bench_host.py: the supervisor's protocol on CPU ranks, no GPU anywhere
         sys.exit(stub_worker(args, rank, world, attempt))
